@@ -1,0 +1,179 @@
+"""Pin the CPU oracle against golden vectors captured from the REFERENCE's own modules
+(tools/make_golden.py, run in the build container).  CPU-only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_ref
+from oracle.model_ref import discriminator_ref, generator_ref
+from oracle.ops_ref import fused_leaky_relu_ref, modulated_conv2d_ref, upfirdn2d_ref, make_blur_kernel
+from oracle.train_ref import (d_decisions_ref, d_filter_fim_ref, d_logistic_loss_ref, d_r1_loss_ref,
+                              fisher_sample_ref, g_decisions_ref, g_filter_fim_ref,
+                              g_nonsaturating_loss_ref, g_path_regularize_ref)
+from rick_amd.synth import synth_latents, synth_reals, synth_state_dict, synth_tensor
+from tests.cases import UPFIRDN_CASES, upfirdn_kernel
+
+
+def close(a, b, rtol, atol=0.0):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max() if a.size else 0.0
+    ref = np.abs(b).max() if b.size else 0.0
+    assert err <= atol + rtol * ref, f'max err {err:.3e} vs ref max {ref:.3e}'
+
+
+@pytest.mark.parametrize('case', UPFIRDN_CASES, ids=[c[0] for c in UPFIRDN_CASES])
+def test_upfirdn2d_oracle(case, golden):
+    tag, up, down, p0, p1, n, c, h, w, ks = case
+    g = golden('ops')
+    k = upfirdn_kernel(ks, up).double()
+    x = synth_tensor(f'upfirdn/{tag}/x', (n, c, h, w)).double().requires_grad_(True)
+    y = upfirdn2d_ref(x, k, up, down, (p0, p1))
+    close(y.detach(), g[f'{tag}/y'], 1e-13)
+    gy = synth_tensor(f'upfirdn/{tag}/gy', y.shape).double().requires_grad_(True)
+    (gx,) = torch.autograd.grad(y, x, gy, create_graph=True)
+    close(gx.detach(), g[f'{tag}/gx'], 1e-13)
+    ggx = synth_tensor(f'upfirdn/{tag}/ggx', x.shape).double()
+    (ggy,) = torch.autograd.grad(gx, gy, ggx)
+    close(ggy, g[f'{tag}/ggy'], 1e-13)
+    # scalar C restatement (fp32, fmaf chain) vs the reference's fp32 CPU result and vs fp64
+    yc = c_ref.upfirdn2d_c(x.detach().float().numpy(), k.float().numpy(), (up, up), (down, down), (p0, p1, p0, p1))
+    close(yc, g[f'{tag}/y32'], 2e-6)
+    close(yc, g[f'{tag}/y'], 2e-6)
+
+
+@pytest.mark.parametrize('tag,shape', [('act2d', (3, 8)), ('act4d', (2, 5, 6, 6))])
+def test_fused_leaky_relu_oracle(tag, shape, golden):
+    g = golden('ops')
+    x = synth_tensor(f'act/{tag}/x', shape).double().requires_grad_(True)
+    b = synth_tensor(f'act/{tag}/b', (shape[1],)).double().requires_grad_(True)
+    y = fused_leaky_relu_ref(x, b)
+    close(y.detach(), g[f'{tag}/y'], 1e-14)
+    gy = synth_tensor(f'act/{tag}/gy', shape).double().requires_grad_(True)
+    gx, gb = torch.autograd.grad(y, (x, b), gy, create_graph=True)
+    close(gx.detach(), g[f'{tag}/gx'], 1e-14)
+    close(gb.detach(), g[f'{tag}/gb'], 1e-13)
+    ggx = synth_tensor(f'act/{tag}/ggx', shape).double()
+    ggb = synth_tensor(f'act/{tag}/ggb', (shape[1],)).double()
+    (ggy,) = torch.autograd.grad((gx, gb), gy, (ggx, ggb))
+    close(ggy, g[f'{tag}/ggy'], 1e-14)
+    # C restatement of the kernel switch: forward (act=3, grad=0) and grad (grad=1, ref=y)
+    yc = c_ref.bias_act_c(x.detach().float().numpy(), b.detach().float().numpy(), None, 3, 0, 0.2, 2 ** 0.5)
+    close(yc, g[f'{tag}/y'], 1e-6)
+    gxc = c_ref.bias_act_c(gy.detach().float().numpy(), None, yc, 3, 1, 0.2, 2 ** 0.5)
+    close(gxc, g[f'{tag}/gx'], 1e-6)
+
+
+@pytest.mark.parametrize('tag', ['plain', 'up', 'rgb'])
+def test_modulated_conv_oracle(tag, golden):
+    g = golden('layers')
+    B, CI, CO, R, SD = 3, 16, 24, 8, 32
+    co = 3 if tag == 'rgb' else CO
+    k = 1 if tag == 'rgb' else 3
+    shapes = {'weight': (1, co, CI, k, k), 'modulation.weight': (CI, SD), 'modulation.bias': (CI,)}
+    sd = synth_state_dict(shapes, dtype=torch.float64)
+    w = sd['weight'].requires_grad_(True)
+    mw = sd['modulation.weight'].requires_grad_(True)
+    mb = sd['modulation.bias'].requires_grad_(True)
+    x = synth_tensor(f'modconv/{tag}/x', (B, CI, R, R)).double().requires_grad_(True)
+    s = synth_tensor(f'modconv/{tag}/s', (B, SD)).double().requires_grad_(True)
+    y = modulated_conv2d_ref(x, s, w, mw, mb, demodulate=(tag != 'rgb'), upsample=(tag == 'up'),
+                             blur_kernel=make_blur_kernel([1, 3, 3, 1]).double())
+    close(y.detach(), g[f'{tag}/y'], 1e-12)
+    gy = synth_tensor(f'modconv/{tag}/gy', y.shape).double()
+    grads = torch.autograd.grad(y, [x, s, w, mw, mb], gy, create_graph=True)
+    for n, gr in zip(('gx', 'gs', 'gw', 'gmw', 'gmb'), grads):
+        close(gr.detach(), g[f'{tag}/{n}'], 1e-11)
+    pl = grads[1].pow(2).sum()
+    close(pl.detach(), g[f'{tag}/pl'], 1e-11)
+    gg = torch.autograd.grad(pl, [x, w, s], allow_unused=True)
+    for n, gr, t in zip(('pl_gx', 'pl_gw', 'pl_gs'), gg, (x, w, s)):
+        close(torch.zeros_like(t) if gr is None else gr, g[f'{tag}/{n}'], 1e-10)
+
+
+def _model_case(g, tag, size, B, dtype, rtol, latents=None, grads=True, reg=True):
+    shapes_g, shapes_d = _shapes(size)
+    sg = {k: v.to(dtype) for k, v in synth_state_dict(shapes_g).items()}
+    sd = {k: v.to(dtype) for k, v in synth_state_dict(shapes_d).items()}
+    for v in list(sg.values()) + list(sd.values()):
+        v.requires_grad_(True)
+    z = (latents if latents is not None else synth_latents(B, seed=size)).to(dtype)
+    real = synth_reals(B, size=size, seed=size).to(dtype)
+    fake, _ = generator_ref(sg, [z], size=size, randomize_noise=False)
+    close(fake.detach().mean(dim=(2, 3)), g[f'{tag}/img_mean'], rtol, atol=rtol)
+    close(fake.detach().reshape(B, -1)[:, torch.from_numpy(g[f'{tag}/img_idx'])], g[f'{tag}/img_samples'], rtol)
+    if f'{tag}/img' in g:
+        close(fake.detach(), g[f'{tag}/img'], rtol)
+    fake_pred, feat = discriminator_ref(sd, fake, size=size)
+    real_pred, _ = discriminator_ref(sd, real, size=size)
+    close(fake_pred.detach(), g[f'{tag}/fake_pred'], rtol, atol=rtol)
+    close(real_pred.detach(), g[f'{tag}/real_pred'], rtol, atol=rtol)
+    close([float(f.abs().mean()) for f in feat], g[f'{tag}/feat_absmean'], rtol)
+    d_loss = d_logistic_loss_ref(real_pred, fake_pred)
+    g_loss = g_nonsaturating_loss_ref(fake_pred)
+    close(d_loss.detach(), g[f'{tag}/d_loss'], rtol)
+    close(g_loss.detach(), g[f'{tag}/g_loss'], rtol)
+    if grads:
+        pk_d = [k for k in sd if not k.endswith('.kernel')]
+        gd = torch.autograd.grad(d_loss, [sd[k] for k in pk_d], retain_graph=True)
+        for k, gr in zip(pk_d, gd):
+            close(float((gr.double() ** 2).sum()), g[f'{tag}/d_grad2/{k}'], 50 * rtol, atol=1e-30)
+        pk_g = [k for k in sg if not k.startswith('noises.')]
+        gg = torch.autograd.grad(g_loss, [sg[k] for k in pk_g], retain_graph=True)
+        for k, gr in zip(pk_g, gg):
+            close(float((gr.double() ** 2).sum()), g[f'{tag}/g_grad2/{k}'], 50 * rtol, atol=1e-30)
+    if reg:
+        real_r = real.clone().requires_grad_(True)
+        rp, _ = discriminator_ref(sd, real_r, size=size)
+        r1 = d_r1_loss_ref(rp, real_r)
+        close(r1.detach(), g[f'{tag}/r1'], 10 * rtol)
+        pk_d = [k for k in sd if not k.endswith('.kernel')]
+        gr1 = torch.autograd.grad(10 / 2 * r1 * 16 + 0 * rp[0].sum(), [sd[k] for k in pk_d], allow_unused=True)
+        for k, gr in zip(pk_d, gr1):
+            v = 0.0 if gr is None else float((gr.double() ** 2).sum())
+            close(v, g[f'{tag}/r1_grad2/{k}'], 100 * rtol, atol=1e-30)
+        pb = max(1, B // 2)
+        img, lat = generator_ref(sg, [z[:pb]], size=size, return_latents=True, randomize_noise=False)
+        pl_noise = synth_tensor(f'plnoise/{size}', img.shape).to(dtype)
+        pen, _, lens = g_path_regularize_ref(img, lat, 0, pl_noise)
+        close(lens.detach(), g[f'{tag}/pl_lengths'], 10 * rtol)
+        close(pen.detach(), g[f'{tag}/pl_loss'], 10 * rtol)
+        pk_g = [k for k in sg if not k.startswith('noises.')]
+        gpl = torch.autograd.grad(8 * pen + 0 * img[0, 0, 0, 0], [sg[k] for k in pk_g], allow_unused=True)
+        for k, gr in zip(pk_g, gpl):
+            v = 0.0 if gr is None else float((gr.double() ** 2).sum())
+            close(v, g[f'{tag}/pl_grad2/{k}'], 100 * rtol, atol=1e-30)
+
+
+def _shapes(size):
+    from tests.shapes import discriminator_shapes, generator_shapes
+    return generator_shapes(size), discriminator_shapes(size)
+
+
+def test_models_small_fp64(golden):
+    g = golden('small')
+    _model_case(g, 's32_f64', 32, 2, torch.float64, 1e-10)
+    _model_case(g, 's16_f64', 16, 4, torch.float64, 1e-10)
+
+
+def test_models_256_fp32_forward(golden):
+    g = golden('full256')
+    lat = torch.from_numpy(np.concatenate([golden('noise_latents')[f'noise_{j:04d}'] for j in range(2)], 0))
+    torch.set_num_threads(8)
+    _model_case(g, 'f256', 256, 2, torch.float32, 2e-4, latents=lat, grads=False, reg=False)
+
+
+def test_decisions_restated(golden):
+    """np.percentile freeze/ft/prune split on a captured FIM (train_dynamic_update_prune.py:279-393)."""
+    g = golden('full256')
+    conv = np.concatenate([g[f'fisher/g_conv/{k}'] for k in range(12)])
+    assert conv.shape == (4864,)
+    for fq, pq in ((40, 0.1), (85, 0.075)):
+        cut, pr = np.percentile(conv, fq), np.percentile(conv, pq)
+        nfreeze = int((conv > cut).sum())
+        nprune = int((conv <= pr).sum())
+        assert abs(nfreeze - round(4864 * (100 - fq) / 100)) <= 2
+        assert 1 <= nprune <= 6

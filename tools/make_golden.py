@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python modules on CPU.
+
+Runs only in the build container (needs /root/reference); the GPU box sees only the
+committed .npz fixtures.  Import recipe: SURVEY.md Appendix B — the two JIT CUDA
+extensions are replaced by (i) a pure-torch stand-in for `fused.fused_bias_act` that
+restates the switch at op/fused_bias_act_kernel.cu:28-47 (fused_act.py has no CPU
+branch) and (ii) a dummy for `upfirdn2d_op` (never called: CPU tensors are routed to
+the reference's own `upfirdn2d_native`, op/upfirdn2d.py:146-149).  Everything else
+(autograd Functions, all nn.Modules, estimate_fisher) is the reference's code.
+
+Inputs are never stored when they can be regenerated from rick_amd.synth (closed-form,
+seeded by key name); only outputs are.
+
+usage: python tools/make_golden.py [--only ops|layers|small|full|latents]
+"""
+import argparse
+import importlib.util
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+from rick_amd.synth import synth_latents, synth_reals, synth_state_dict, synth_tensor  # noqa: E402
+from tests.cases import UPFIRDN_CASES, upfirdn_kernel  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def import_reference():
+    import torch.utils.cpp_extension as cpp
+
+    class _Fused:
+        @staticmethod
+        def fused_bias_act(x, b, ref, act, grad, alpha, scale):
+            if b.numel():
+                x = x + b.reshape(1, -1, *([1] * (x.ndim - 2)))
+            if act == 3 and grad == 0:
+                y = torch.where(x > 0, x, x * alpha)
+            elif act == 3 and grad == 1:
+                y = torch.where(ref > 0, x, x * alpha)
+            elif grad == 2:
+                y = torch.zeros_like(x)
+            else:
+                y = x
+            return y * scale
+
+    def fake_load(name, sources=None, **kw):
+        return _Fused if name == 'fused' else types.SimpleNamespace()
+
+    cpp.load = fake_load
+    sys.path.insert(0, REF)
+    import op  # noqa: F401  (reference package, CPU routing)
+    spec = importlib.util.spec_from_file_location(
+        'mpt', os.path.join(REF, 'gan_training/models/model_probe_tune.py'))
+    mpt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mpt)
+    return op, mpt
+
+
+def np32(t):
+    return t.detach().cpu().numpy().astype(np.float32) if t.dtype != torch.float64 else t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------- ops
+def gen_ops(op):
+    out = {}
+    for (tag, up, down, p0, p1, n, c, h, w, ks) in UPFIRDN_CASES:
+        k = upfirdn_kernel(ks, up).double()
+        x = synth_tensor(f'upfirdn/{tag}/x', (n, c, h, w)).double().requires_grad_(True)
+        y = op.upfirdn2d(x, k, up=up, down=down, pad=(p0, p1))
+        gy = synth_tensor(f'upfirdn/{tag}/gy', y.shape).double().requires_grad_(True)
+        (gx,) = torch.autograd.grad(y, x, gy, create_graph=True)
+        ggx = synth_tensor(f'upfirdn/{tag}/ggx', x.shape).double()
+        (ggy,) = torch.autograd.grad(gx, gy, ggx)
+        # fp32 forward too (bit-level comparison target for the C oracle's fmaf chain is not
+        # claimed; fp32 result kept for tolerance checks)
+        y32 = op.upfirdn2d(x.detach().float(), k.float(), up=up, down=down, pad=(p0, p1))
+        out[f'{tag}/y'] = y.detach().numpy()
+        out[f'{tag}/gx'] = gx.detach().numpy()
+        out[f'{tag}/ggy'] = ggy.detach().numpy()
+        out[f'{tag}/y32'] = y32.numpy()
+    # fused leaky relu through the reference's autograd Functions (op/fused_act.py:19-70)
+    for tag, shape in (('act2d', (3, 8)), ('act4d', (2, 5, 6, 6))):
+        x = synth_tensor(f'act/{tag}/x', shape).double().requires_grad_(True)
+        b = synth_tensor(f'act/{tag}/b', (shape[1],)).double().requires_grad_(True)
+        y = op.fused_leaky_relu(x, b)
+        gy = synth_tensor(f'act/{tag}/gy', shape).double().requires_grad_(True)
+        gx, gb = torch.autograd.grad(y, (x, b), gy, create_graph=True)
+        ggx = synth_tensor(f'act/{tag}/ggx', shape).double()
+        ggb = synth_tensor(f'act/{tag}/ggb', (shape[1],)).double()
+        (ggy,) = torch.autograd.grad((gx, gb), gy, (ggx, ggb))
+        out[f'{tag}/y'] = y.detach().numpy()
+        out[f'{tag}/gx'] = gx.detach().numpy()
+        out[f'{tag}/gb'] = gb.detach().numpy()
+        out[f'{tag}/ggy'] = ggy.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, 'ops.npz'), **out)
+    print('ops.npz', len(out), 'arrays')
+
+
+# ----------------------------------------------------------------------------- layers
+def gen_layers(mpt):
+    out = {}
+    B, CI, CO, R, SD = 3, 16, 24, 8, 32
+    for tag, kw in (('plain', dict(kernel_size=3)), ('up', dict(kernel_size=3, upsample=True)),
+                    ('rgb', dict(kernel_size=1, demodulate=False))):
+        co = 3 if tag == 'rgb' else CO
+        m = mpt.ModulatedConv2d(CI, co, style_dim=SD, **kw).double()
+        sd = synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, dtype=torch.float64)
+        m.load_state_dict(sd, strict=False)
+        x = synth_tensor(f'modconv/{tag}/x', (B, CI, R, R)).double().requires_grad_(True)
+        s = synth_tensor(f'modconv/{tag}/s', (B, SD)).double().requires_grad_(True)
+        y = m(x, s)
+        gy = synth_tensor(f'modconv/{tag}/gy', y.shape).double()
+        params = [m.weight, m.modulation.weight, m.modulation.bias]
+        grads = torch.autograd.grad(y, [x, s] + params, gy, create_graph=True)
+        # PLR-style second-order scalar: || d<y,gy>/ds ||^2, differentiated w.r.t. weight and x
+        pl = grads[1].pow(2).sum()
+        gg = torch.autograd.grad(pl, [x, m.weight, s], allow_unused=True)
+        gg = [torch.zeros_like(t) if g_ is None else g_ for g_, t in zip(gg, [x, m.weight, s])]
+        out[f'{tag}/y'] = y.detach().numpy()
+        for n, g in zip(('gx', 'gs', 'gw', 'gmw', 'gmb'), grads):
+            out[f'{tag}/{n}'] = g.detach().numpy()
+        out[f'{tag}/pl'] = pl.detach().numpy()
+        for n, g in zip(('pl_gx', 'pl_gw', 'pl_gs'), gg):
+            out[f'{tag}/{n}'] = g.detach().numpy()
+    # minibatch stddev via the reference Discriminator tail is covered in 'small'
+    np.savez_compressed(os.path.join(OUT, 'layers.npz'), **out)
+    print('layers.npz', len(out), 'arrays')
+
+
+# ------------------------------------------------------------------------ whole models
+def softplus(x):
+    return torch.nn.functional.softplus(x)
+
+
+def build(mpt, size, dtype):
+    g = mpt.Generator(size, 512, 8, channel_multiplier=2)
+    d = mpt.Discriminator(size, channel_multiplier=2)
+    sg = synth_state_dict({k: v.shape for k, v in g.state_dict().items()})
+    sd = synth_state_dict({k: v.shape for k, v in d.state_dict().items()})
+    g.load_state_dict(sg, strict=False)
+    d.load_state_dict(sd, strict=False)
+    return g.to(dtype), d.to(dtype)
+
+
+def grad_summ(named, grads):
+    """per-key sum(g^2) (== Fisher mass) — compact fingerprint of every parameter gradient."""
+    return {k: float((g.double() ** 2).sum()) if g is not None else 0.0 for (k, _), g in zip(named, grads)}
+
+
+def model_case(mpt, size, B, dtype, out, tag, latents=None, full_arrays=False):
+    g, d = build(mpt, size, dtype)
+    z = (latents if latents is not None else synth_latents(B, seed=size)).to(dtype)
+    real = synth_reals(B, size=size, seed=size).to(dtype)
+    gp, dp = list(g.named_parameters()), list(d.named_parameters())
+
+    fake, _ = g([z], randomize_noise=False)
+    fake_pred, feat_f = d(fake)
+    real_pred, _ = d(real)
+    d_loss = softplus(-real_pred).mean() + softplus(fake_pred).mean()
+    g_loss = softplus(-fake_pred).mean()
+    gd = torch.autograd.grad(d_loss, [p for _, p in dp], retain_graph=True, allow_unused=True)
+    gg = torch.autograd.grad(g_loss, [p for _, p in gp], retain_graph=True, allow_unused=True)
+    out[f'{tag}/img_mean'] = np32(fake.mean(dim=(2, 3)))
+    out[f'{tag}/img_std'] = np32(fake.std(dim=(2, 3)))
+    idx = torch.from_numpy(np.random.RandomState(0).randint(0, fake[0].numel(), size=4096))
+    out[f'{tag}/img_idx'] = idx.numpy()
+    out[f'{tag}/img_samples'] = np32(fake.reshape(B, -1)[:, idx])
+    if full_arrays:
+        out[f'{tag}/img'] = np32(fake)
+    out[f'{tag}/fake_pred'] = np32(fake_pred)
+    out[f'{tag}/real_pred'] = np32(real_pred)
+    out[f'{tag}/d_loss'] = np32(d_loss)
+    out[f'{tag}/g_loss'] = np32(g_loss)
+    out[f'{tag}/feat_absmean'] = np.array([float(f.abs().mean()) for f in feat_f])
+    for k, v in grad_summ(dp, gd).items():
+        out[f'{tag}/d_grad2/{k}'] = np.float64(v)
+    for k, v in grad_summ(gp, gg).items():
+        out[f'{tag}/g_grad2/{k}'] = np.float64(v)
+
+    # R1 (train_dynamic_update_prune.py:89-96, 465-475)
+    real_r = real.clone().requires_grad_(True)
+    rp, _ = d(real_r)
+    (gr,) = torch.autograd.grad(rp.sum(), real_r, create_graph=True)
+    r1 = gr.pow(2).reshape(B, -1).sum(1).mean()
+    gr1 = torch.autograd.grad(10 / 2 * r1 * 16 + 0 * rp[0].sum(), [p for _, p in dp], allow_unused=True)
+    out[f'{tag}/r1'] = np32(r1)
+    for k, v in grad_summ(dp, gr1).items():
+        out[f'{tag}/r1_grad2/{k}'] = np.float64(v)
+
+    # PLR (train_dynamic_update_prune.py:104-118, 548-566) with a shared seeded noise image
+    pb = max(1, B // 2)
+    img, lat = g([z[:pb]], return_latents=True, randomize_noise=False)
+    pl_noise = synth_tensor(f'plnoise/{size}', img.shape).to(dtype)
+    (gl,) = torch.autograd.grad((img * pl_noise / math.sqrt(size * size)).sum(), lat, create_graph=True)
+    pl_len = torch.sqrt(gl.pow(2).sum(2).mean(1))
+    pl_mean = 0 + 0.01 * (pl_len.mean() - 0)
+    pl_loss = (pl_len - pl_mean).pow(2).mean()
+    gpl = torch.autograd.grad(2 * 4 * pl_loss + 0 * img[0, 0, 0, 0], [p for _, p in gp], allow_unused=True)
+    out[f'{tag}/pl_lengths'] = np32(pl_len)
+    out[f'{tag}/pl_loss'] = np32(pl_loss)
+    for k, v in grad_summ(gp, gpl).items():
+        out[f'{tag}/pl_grad2/{k}'] = np.float64(v)
+    return g, d
+
+
+def gen_small(mpt):
+    out = {}
+    model_case(mpt, 32, 2, torch.float64, out, 's32_f64', full_arrays=True)
+    model_case(mpt, 16, 4, torch.float64, out, 's16_f64', full_arrays=True)
+    np.savez_compressed(os.path.join(OUT, 'small.npz'), **out)
+    print('small.npz', len(out), 'arrays')
+
+
+def gen_latents():
+    lat = {f'noise_{j:04d}': torch.load(os.path.join(REF, '_noise', f'{j:04d}.pt')).numpy() for j in range(10)}
+    lat['sample_z'] = torch.load(os.path.join(REF, 'noise.pt')).numpy()
+    np.savez_compressed(os.path.join(OUT, 'noise_latents.npz'), **lat)
+    print('noise_latents.npz', len(lat), 'arrays')
+
+
+def gen_full(mpt):
+    """256 px, fp32 (the reference's arithmetic type), on the shipped _noise latents."""
+    out = {}
+    lat = torch.cat([torch.load(os.path.join(REF, '_noise', f'{j:04d}.pt')) for j in range(2)], 0)
+    g, d = model_case(mpt, 256, 2, torch.float32, out, 'f256', latents=lat)
+
+    # Fisher sample j=0 exactly as train_dynamic_update_prune.py:231-248 (batch 1, real[0])
+    z0 = lat[0:1]
+    real = synth_reals(2, size=256, seed=256)
+    fake, _ = g([z0.view(1, -1)], randomize_noise=False)
+    fp, _ = d(fake)
+    rp, _ = d(real[0].view(1, 3, 256, 256))
+    g_loss = softplus(-fp).mean()
+    d_loss = softplus(-rp).mean() + softplus(fp).mean()
+    _, fg = g.estimate_fisher(g_loss)
+    _, fd = d.estimate_fisher(d_loss)
+    out['fisher/g_loss'] = np32(g_loss)
+    out['fisher/d_loss'] = np32(d_loss)
+    # per-filter FIM vectors (train_dynamic_update_prune.py:279-299, 334-353)
+    fgn = {k: v.numpy() for k, v in fg.items()}
+    fdn = {k: v.numpy() for k, v in fd.items()}
+    for k in range(12):
+        out[f'fisher/g_conv/{k}'] = fgn[f'convs.{k}.conv.weight'].mean(axis=(0, 2, 3, 4))
+        out[f'fisher/g_fc/{k}'] = (fgn[f'convs.{k}.conv.modulation.weight'].mean(axis=1)
+                                   + fgn[f'convs.{k}.conv.modulation.bias']) / 2
+    for b in range(1, 7):
+        for li in range(2):
+            wk, bk = f'convs.{b}.conv{li + 1}.{li}.weight', f'convs.{b}.conv{li + 1}.{li + 1}.bias'
+            out[f'fisher/d/{wk}'] = (fdn[wk].mean(axis=(1, 2, 3)) + fdn[bk]) / 2
+        sk = f'convs.{b}.skip.1.weight'
+        out[f'fisher/d/{sk}'] = fdn[sk].mean(axis=(1, 2, 3))
+    for k, v in fgn.items():
+        out[f'fisher/g_sum/{k}'] = np.float64(v.astype(np.float64).sum())
+    for k, v in fdn.items():
+        out[f'fisher/d_sum/{k}'] = np.float64(v.astype(np.float64).sum())
+    np.savez_compressed(os.path.join(OUT, 'full256.npz'), **out)
+    print('full256.npz', len(out), 'arrays')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default=None)
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(1)
+    op, mpt = import_reference()
+    todo = [a.only] if a.only else ['latents', 'ops', 'layers', 'small', 'full']
+    if 'latents' in todo:
+        gen_latents()
+    if 'ops' in todo:
+        gen_ops(op)
+    if 'layers' in todo:
+        gen_layers(mpt)
+    if 'small' in todo:
+        gen_small(mpt)
+    if 'full' in todo:
+        gen_full(mpt)
+
+
+if __name__ == '__main__':
+    main()
