@@ -1,0 +1,179 @@
+/* rick_hip.h — C ABI of librick_hip.so: the MI355X (gfx950) kernels behind the RICK
+ * StyleGAN2 train-step hot path.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + explicit sizes; no framework types; fp32 tensors unless said;
+ *   - launched asynchronously on `stream` (a hipStream_t passed as void*), never
+ *     synchronises, never allocates; workspaces are caller-provided;
+ *   - returns 0 on success, RICK_EINVAL for bad arguments, or 1000 + hipError_t from
+ *     hipGetLastError() after the launch (the reference's extensions raise through
+ *     TORCH_CHECK -> RuntimeError, op/upfirdn2d.cpp:8,15-16; the Python binding in
+ *     rick_amd/_lib.py turns a non-zero status into RuntimeError);
+ *   - re-entrant, no global mutable state (the reference ops are called from
+ *     DataParallel worker threads, train_dynamic_update_prune.py:941-944).
+ *
+ * Activation layout: 4-D activations are channels-last ("NHWC": [N, H, W, C] in memory);
+ * this is the reference extension's own [major, H, W, minor] view
+ * (op/upfirdn2d_kernel.cu:209-240) with major = N, minor = C.  RGB-side tensors (3 channels)
+ * stay planar ([N, 3, H, W], i.e. major = N*3, minor = 1).
+ */
+#ifndef RICK_HIP_H
+#define RICK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RICK_EINVAL 22
+#define RICK_MAX_TAPS 16
+
+int rick_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * upfirdn2d — replaces upfirdn2d_op.upfirdn2d(input[M,H,W,minor], kernel, up_x, up_y,
+ * down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1) (op/upfirdn2d.cpp:12-19,
+ * op/upfirdn2d_kernel.cu:209-369).  out is [major, out_h, out_w, minor] with
+ * out_h = (in_h*up_y + pad_y0 + pad_y1 - kh)/down_y + 1 (kernel.cu:237-240); the caller
+ * allocates it.  Forward, backward (flipped kernel, up<->down, op/upfirdn2d.py:19-60) and
+ * double-backward are the same entry with different parameters.  Tap order and fmaf
+ * accumulation match oracle/csrc/oracle_ops.c bit for bit. */
+int rick_upfirdn2d_f32(const float *input, const float *kernel, float *out,
+                       int64_t major, int in_h, int in_w, int minor, int kh, int kw,
+                       int up_x, int up_y, int down_x, int down_y,
+                       int pad_x0, int pad_x1, int pad_y0, int pad_y1, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * fused bias + activation — replaces fused.fused_bias_act(input, bias, refer, act, grad,
+ * alpha, scale) (op/fused_bias_act.cpp:11-21, op/fused_bias_act_kernel.cu:18-99):
+ *   v = x[i] + (bias ? bias[(i / step_b) % size_b] : 0)
+ *         + (noise ? nw[0] * noise[((i / n_div) % noise_nb) * noise_hw + (i / hw_div) % noise_hw] : 0)
+ *   act*10+grad: 30: v>0 ? v : v*alpha   31: ref>0 ? v : v*alpha   10/11: v   12/32: 0
+ *   out[i] = y * scale
+ * NULL bias / ref / noise mean "absent" (the reference passes empty tensors).  The noise
+ * term is this build's fusion of NoiseInjection (model_probe_tune.py:293-298) into the same
+ * pass; nw is a device pointer to the scalar noise strength. */
+int rick_bias_act_f32(const float *x, const float *bias, const float *ref, float *out,
+                      int64_t n, int64_t step_b, int64_t size_b, int act, int grad,
+                      float alpha, float scale,
+                      const float *noise, const float *nw, int64_t n_div, int64_t hw_div,
+                      int64_t noise_nb, int64_t noise_hw, void *stream);
+
+/* Backward of the fused activation for a [rows, C] (channels-last) tensor in ONE pass:
+ *   gx[r,c] = scale * g[r,c] * (ref[r,c] > 0 ? 1 : alpha)          (fused_act.py:28-30)
+ *   gb[c]   = sum_r gx[r,c]                                          (fused_act.py:32-37)
+ *   gnw     = sum_{r,c} gx[r,c] * noise[(r / rows_per_img % noise_nb)*noise_hw + r % noise_hw]
+ * The per-channel / scalar sums use wavefront shuffles + a deterministic two-stage
+ * reduction through `partials` (float[(C + 1) * rick_bias_act_bwd_blocks(rows, C)]).
+ * gb / gnw / noise may be NULL. */
+int rick_bias_act_bwd_blocks(int64_t rows, int C);
+int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx, float *gb, float *gnw,
+                          const float *noise, int64_t rows, int C, int64_t rows_per_img,
+                          int64_t noise_nb, int64_t noise_hw, float alpha, float scale,
+                          float *partials, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Convolution family (replaces the F.conv2d / F.conv_transpose2d calls of
+ * model_probe_tune.py:122,265,274,280 and their autograd).  One implicit-GEMM MFMA kernel,
+ * parameterised by a tap table, covers 3x3/1x1, stride 1/2, transposed stride 2, and the
+ * data-gradient of each.  fp32 in HBM; operands are split into bf16 hi + bf16 lo on the
+ * way into LDS and multiplied as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with
+ * fp32 accumulation (split = 2), or hi*hi only (split = 1).
+ *
+ * Geometry: activations NHWC.  The launch covers a grid of GH x GW "positions" per image;
+ * position (gy, gx) writes output pixel (gy*os + oy0, gx*os + ox0) of [N, OH, OW, Co] and
+ * tap t reads input pixel (gy*is + dy[t], gx*is + dx[t]) of [N, IH, IW, Ci] (zero outside)
+ * with packed weight slice wt[t]:
+ *   out[n, pix, co] = alpha * oscale[n, co] * sum_t sum_ci W[wt[t]][co][ci] *
+ *                     (iscale[n, ci] * x[n, inpix(t), ci])
+ * oscale / iscale (NULL = 1) carry StyleGAN2's demodulation / modulation
+ * (model_probe_tune.py:246-251) without materialising per-sample weights. */
+typedef struct {
+    int N, IH, IW, Ci;      /* input  [N, IH, IW, Ci] */
+    int OH, OW, Co;         /* output [N, OH, OW, Co] */
+    int GH, GW;             /* positions per image */
+    int is, os, oy0, ox0;   /* input stride, output stride / offset */
+    int ntaps;              /* taps used by this launch */
+    int nslices;            /* tap slices in the packed weight / in gw (wt[t] < nslices) */
+    int dy[RICK_MAX_TAPS], dx[RICK_MAX_TAPS], wt[RICK_MAX_TAPS];
+    int split;              /* 1 = bf16, 2 = bf16x3 (fp32-grade) */
+    float alpha;
+} rick_conv_geom;
+
+/* Packed-weight buffer size in bytes for `nslices` tap slices of a [Co, Ci] matrix. */
+int64_t rick_conv_packed_bytes(int Co, int Ci, int nslices);
+/* Pack W (element (co, ci, slice s) at w[co*s_co + ci*s_ci + s*s_t]) * scale into the MFMA
+ * A-operand LDS image (bf16 hi/lo, swizzled, zero padded to 128 x 32 tiles). */
+int rick_conv_pack_weight(const float *w, int64_t s_co, int64_t s_ci, int64_t s_t,
+                          int Co, int Ci, int nslices, float scale, void *packed, void *stream);
+int rick_conv_igemm_f32(const float *x, const void *packed_w, float *out,
+                        const float *iscale, const float *oscale,
+                        const rick_conv_geom *g, void *stream);
+
+/* Weight gradient for the same geometry:
+ *   gw[(co, ci, t)] = alpha * sum_{n, pos} (ascale[n,co] * gy[n, outpix(pos), co]) *
+ *                                           (bscale[n,ci] * x[n, inpix(pos, t), ci])
+ * written to gw[co*s_co + ci*s_ci + wt[t]*s_t].  Split-K over position tiles with a
+ * deterministic second-stage reduction through `workspace`
+ * (rick_conv_wgrad_workspace_bytes bytes).  `accumulate` != 0 adds into gw. */
+int64_t rick_conv_wgrad_workspace_bytes(const rick_conv_geom *g);
+int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw,
+                        int64_t s_co, int64_t s_ci, int64_t s_t,
+                        const float *ascale, const float *bscale,
+                        const rick_conv_geom *g, int accumulate, void *workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Thin (J <= 4 channel) products for the RGB side (ToRGB 1x1 modulated conv,
+ * model_probe_tune.py:351-370; discriminator input conv, :679).  x is NHWC [N, P, C],
+ * the thin tensor is planar [N, J, P], W is [N or 1, J, C] (w_bstride = J*C or 0).
+ *   fwd :  t[n,j,p]  = sum_c x[n,p,c] * W[n,j,c]  (+ add[n,j,p] if add)
+ *   bwdx:  x[n,p,c]  = sum_j t[n,j,p] * W[n,j,c]
+ *   wgrad: G[n,j,c]  = sum_p t[n,j,p] * x[n,p,c]   (partials: float[N*J*C*rick_thin_wgrad_blocks]) */
+int rick_thin_fwd_f32(const float *x, const float *W, int64_t w_bstride, const float *add,
+                      float *t, int N, int64_t P, int C, int J, void *stream);
+int rick_thin_bwdx_f32(const float *t, const float *W, int64_t w_bstride, float *x,
+                       int N, int64_t P, int C, int J, void *stream);
+int rick_thin_wgrad_blocks(int64_t P);
+int rick_thin_wgrad_f32(const float *t, const float *x, float *G, int N, int64_t P, int C, int J,
+                        float *partials, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Elementwise / reduction helpers on NHWC [N, P, C] tensors. */
+/* y[n,p,c] = x[n,p,c] * s[n,c] */
+int rick_chan_scale_f32(const float *x, const float *s, float *y, int N, int64_t P, int C, void *stream);
+/* d[n,c] = sum_p a[n,p,c] * b[n,p,c]; partials: float[N*C*rick_hw_dot_blocks(P)] */
+int rick_hw_dot_blocks(int64_t P);
+int rick_hw_dot_f32(const float *a, const float *b, float *d, int N, int64_t P, int C,
+                    float *partials, void *stream);
+/* y = (a + b) * alpha  (ResBlock merge, model_probe_tune.py:658); b may be NULL */
+int rick_add_scale_f32(const float *a, const float *b, float *y, int64_t n, float alpha, void *stream);
+
+/* Minibatch standard deviation (model_probe_tune.py:748-756) on NHWC x[B, P, C] with
+ * group = B: out[B, P, C+1], channel C = mean_{p,c} sqrt(var_b(x) + 1e-8); backward. */
+int rick_mbstd_fwd_f32(const float *x, float *out, float *stat, int B, int P, int C, void *stream);
+int rick_mbstd_bwd_f32(const float *x, const float *gout, float *gx, int B, int P, int C, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fisher information + optimiser side (train_dynamic_update_prune.py:252-269, 279-299,
+ * 427-438, 68-73, 908-931). */
+/* acc[i] += g[i]^2 */
+int rick_sq_accumulate_f32(float *acc, const float *g, int64_t n, void *stream);
+/* out[f] = scale * sum_{o, i} x[o*outer_stride + f*filter_stride + i], i < inner
+ * (per-filter mean of a Fisher tensor: one wavefront-shuffle reduction per filter) */
+int rick_filter_reduce_f32(const float *x, float *out, int64_t outer, int64_t outer_stride,
+                           int64_t nfilters, int64_t filter_stride, int64_t inner,
+                           float scale, void *stream);
+/* Masked Adam over a flat parameter buffer (mask bits: 1 = freeze (grad := 0),
+ * 2 = prune (param := 0, grad := 0); mask may be NULL), torch.optim.Adam semantics
+ * (no weight decay, no amsgrad), bias corrections passed in. */
+int rick_masked_adam_f32(float *p, float *g, float *m, float *v, const uint8_t *mask, int64_t n,
+                         float lr, float beta1, float beta2, float eps, float bc1, float bc2,
+                         void *stream);
+/* ema[i] = ema[i]*decay + p[i]*(1-decay) */
+int rick_ema_f32(float *ema, const float *p, int64_t n, float decay, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RICK_HIP_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of librick_hip.so (C ABI in include/rick_hip.h).
+
+The product path has NO fallback: if the shared library is missing the import fails, and
+every op raises on non-CUDA tensors.  PyTorch is used only for device memory, streams and
+autograd bookkeeping.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'librick_hip.so')
+MAX_TAPS = 16
+
+c_fp = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_f = ctypes.c_float
+
+
+class ConvGeom(ctypes.Structure):
+    """rick_conv_geom (include/rick_hip.h)."""
+    _fields_ = [('N', c_int), ('IH', c_int), ('IW', c_int), ('Ci', c_int),
+                ('OH', c_int), ('OW', c_int), ('Co', c_int),
+                ('GH', c_int), ('GW', c_int),
+                ('is_', c_int), ('os', c_int), ('oy0', c_int), ('ox0', c_int),
+                ('ntaps', c_int), ('nslices', c_int),
+                ('dy', c_int * MAX_TAPS), ('dx', c_int * MAX_TAPS), ('wt', c_int * MAX_TAPS),
+                ('split', c_int), ('alpha', c_f)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/rick_hip.h
+SIGNATURES = {
+    'rick_abi_version': (c_int, []),
+    'rick_upfirdn2d_f32': (c_int, [c_fp, c_fp, c_fp, c_i64] + [c_int] * 13 + [c_fp]),
+    'rick_bias_act_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f,
+                                  c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_fp]),
+    'rick_bias_act_bwd_blocks': (c_int, [c_i64, c_int]),
+    'rick_bias_act_bwd_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_i64, c_i64, c_i64,
+                                      c_f, c_f, c_fp, c_fp]),
+    'rick_conv_packed_bytes': (c_i64, [c_int, c_int, c_int]),
+    'rick_conv_pack_weight': (c_int, [c_fp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_f, c_fp, c_fp]),
+    'rick_conv_igemm_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(ConvGeom), c_fp]),
+    'rick_conv_wgrad_workspace_bytes': (c_i64, [ctypes.POINTER(ConvGeom)]),
+    'rick_conv_wgrad_f32': (c_int, [c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_fp, c_fp,
+                                    ctypes.POINTER(ConvGeom), c_int, c_fp, c_fp]),
+    'rick_thin_fwd_f32': (c_int, [c_fp, c_fp, c_i64, c_fp, c_fp, c_int, c_i64, c_int, c_int, c_fp]),
+    'rick_thin_bwdx_f32': (c_int, [c_fp, c_fp, c_i64, c_fp, c_int, c_i64, c_int, c_int, c_fp]),
+    'rick_thin_wgrad_blocks': (c_int, [c_i64]),
+    'rick_thin_wgrad_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_int, c_fp, c_fp]),
+    'rick_chan_scale_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_fp]),
+    'rick_hw_dot_blocks': (c_int, [c_i64]),
+    'rick_hw_dot_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_fp, c_fp]),
+    'rick_add_scale_f32': (c_int, [c_fp, c_fp, c_fp, c_i64, c_f, c_fp]),
+    'rick_mbstd_fwd_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
+    'rick_mbstd_bwd_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
+    'rick_sq_accumulate_f32': (c_int, [c_fp, c_fp, c_i64, c_fp]),
+    'rick_filter_reduce_f32': (c_int, [c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_fp]),
+    'rick_masked_adam_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_fp]),
+    'rick_ema_f32': (c_int, [c_fp, c_fp, c_i64, c_f, c_fp]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f'{LIB_PATH} not found: build the HIP extension first '
+        f'(python -c "import __graft_entry__ as g; g.build()" or make -C rick_amd/csrc). '
+        'rick_amd has no CPU or eager fallback.')
+
+lib = ctypes.CDLL(LIB_PATH)
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here == missing export
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f'{what} failed with status {rc} '
+                           f'({"invalid argument" if rc == 22 else "hipError " + str(rc - 1000)})')
+
+
+def require_cuda_f32(*tensors):
+    """Mirrors CHECK_CUDA of the reference binding (op/upfirdn2d.cpp:8,15-16): the HIP path is
+    the only path; CPU tensors are an error, never a silent fallback."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('rick_amd ops require CUDA/HIP tensors (no CPU fallback); got device '
+                               + str(t.device))
+        if t.dtype != torch.float32:
+            raise RuntimeError(f'rick_amd ops compute in float32; got {t.dtype}')
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()

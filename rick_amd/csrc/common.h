@@ -1,0 +1,37 @@
+// Shared helpers for the gfx950 kernels of librick_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rick_hip.h"
+
+#define RICK_LAUNCH_STATUS()                                   \
+    do {                                                       \
+        hipError_t e__ = hipGetLastError();                    \
+        return e__ == hipSuccess ? 0 : 1000 + (int)e__;        \
+    } while (0)
+
+__host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+__host__ __device__ __forceinline__ int floor_div_i(int a, int b) {
+    int c = a / b;
+    if (c * b > a) c--;
+    return c;
+}
+
+// 64-lane wavefront sum via DPP-free shuffles (wave64 on gfx950).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Block-wide sum for blockDim.x == 256 (4 waves); result valid in every thread.
+__device__ __forceinline__ float block_sum_256(float v, float *red /* >= 4 floats of LDS */) {
+    v = wave_sum(v);
+    const int wid = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wid] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}

@@ -1,0 +1,461 @@
+// HBM-bound kernels of the hot path: fused bias/noise/LeakyReLU (+ one-pass backward with
+// wavefront-shuffle reductions), modulation helpers, ResBlock merge, minibatch-stddev,
+// Fisher grad^2 accumulation, per-filter reduction, masked Adam, EMA.
+#include "common.h"
+
+// ------------------------------------------------------------------------ bias + act (fwd)
+// Semantics: op/fused_bias_act_kernel.cu:18-49 (+ fused NoiseInjection, model_probe_tune.py:293-298)
+struct BiasActParams {
+    int64_t n, step_b, size_b, n_div, hw_div, noise_nb, noise_hw;
+    int act, grad;
+    float alpha, scale;
+};
+
+__device__ __forceinline__ float act_apply(float v, float r, int mode, float alpha) {
+    switch (mode) {
+        case 30: return v > 0.f ? v : v * alpha;
+        case 31: return r > 0.f ? v : v * alpha;
+        case 12:
+        case 32: return 0.f;
+        default: return v;
+    }
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void bias_act_kernel(const float *__restrict__ x, const float *__restrict__ b,
+                                                       const float *__restrict__ ref, float *__restrict__ out,
+                                                       const float *__restrict__ noise, const float *__restrict__ nw,
+                                                       BiasActParams p) {
+    const int mode = p.act * 10 + p.grad;
+    const float nwv = noise ? nw[0] : 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    if (VEC4) {
+        // requires n % 4 == 0, step_b == 1, size_b % 4 == 0, hw_div % 4 == 0 (channels-last rows)
+        const int64_t n4 = p.n >> 2;
+        for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += stride) {
+            const int64_t i = i4 << 2;
+            float4 v = reinterpret_cast<const float4 *>(x)[i4];
+            if (b) {
+                const float4 bv = *reinterpret_cast<const float4 *>(b + (i % p.size_b));
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            if (noise) {
+                const float nv = nwv * noise[((i / p.n_div) % p.noise_nb) * p.noise_hw + (i / p.hw_div) % p.noise_hw];
+                v.x += nv; v.y += nv; v.z += nv; v.w += nv;
+            }
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ref) r = reinterpret_cast<const float4 *>(ref)[i4];
+            float4 y;
+            y.x = act_apply(v.x, r.x, mode, p.alpha) * p.scale;
+            y.y = act_apply(v.y, r.y, mode, p.alpha) * p.scale;
+            y.z = act_apply(v.z, r.z, mode, p.alpha) * p.scale;
+            y.w = act_apply(v.w, r.w, mode, p.alpha) * p.scale;
+            reinterpret_cast<float4 *>(out)[i4] = y;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n; i += stride) {
+            float v = x[i];
+            if (b) v += b[(i / p.step_b) % p.size_b];
+            if (noise) v += nwv * noise[((i / p.n_div) % p.noise_nb) * p.noise_hw + (i / p.hw_div) % p.noise_hw];
+            const float r = ref ? ref[i] : 0.f;
+            out[i] = act_apply(v, r, mode, p.alpha) * p.scale;
+        }
+    }
+}
+
+static inline int ew_grid(int64_t work_items) {
+    int64_t g = cdiv64(work_items, 256);
+    if (g > 256 * 16) g = 256 * 16;   // 16 blocks per CU, grid-stride beyond
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int rick_bias_act_f32(const float *x, const float *bias, const float *ref, float *out,
+                                 int64_t n, int64_t step_b, int64_t size_b, int act, int grad,
+                                 float alpha, float scale, const float *noise, const float *nw,
+                                 int64_t n_div, int64_t hw_div, int64_t noise_nb, int64_t noise_hw,
+                                 void *stream) {
+    if (!x || !out || n < 0 || (bias && (step_b <= 0 || size_b <= 0))) return RICK_EINVAL;
+    if (noise && (!nw || n_div <= 0 || hw_div <= 0 || noise_nb <= 0 || noise_hw <= 0)) return RICK_EINVAL;
+    if (n == 0) return 0;
+    BiasActParams p{n, step_b > 0 ? step_b : 1, size_b > 0 ? size_b : 1, n_div, hw_div, noise_nb, noise_hw,
+                    act, grad, alpha, scale};
+    const bool vec = (n % 4 == 0) && (!bias || (step_b == 1 && size_b % 4 == 0)) &&
+                     (!noise || (hw_div % 4 == 0 && n_div % 4 == 0)) &&
+                     (((uintptr_t)x | (uintptr_t)out | (uintptr_t)(ref ? ref : x) | (uintptr_t)(bias ? bias : x)) % 16 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec)
+        hipLaunchKernelGGL(bias_act_kernel<true>, dim3(ew_grid(n / 4)), dim3(256), 0, st, x, bias, ref, out, noise, nw, p);
+    else
+        hipLaunchKernelGGL(bias_act_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, st, x, bias, ref, out, noise, nw, p);
+    RICK_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------- bias + act (backward)
+// One pass over g / ref: writes gx and per-block partial sums for gb[C] and gnw.
+// Block = 256 threads handling a contiguous slab of rows; thread t owns column group
+// (t % cg) and walks rows t / cg, t / cg + rpb, ...  (cg = min(C/4 or C, 256) lanes per row).
+#define BAB_ROWS_PER_BLOCK 64
+
+extern "C" int rick_bias_act_bwd_blocks(int64_t rows, int C) {
+    (void)C;
+    int64_t nb = cdiv64(rows, BAB_ROWS_PER_BLOCK);
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restrict__ g, const float *__restrict__ ref,
+                                                           float *__restrict__ gx, const float *__restrict__ noise,
+                                                           float *__restrict__ partials, int64_t rows, int C,
+                                                           int64_t rows_per_img, int64_t noise_nb, int64_t noise_hw,
+                                                           float alpha, float scale, int want_gb) {
+    extern __shared__ float lds[];   // [256 * (VEC4 ? 4 : 1)] column partials + 4 for block_sum
+    const int W = VEC4 ? 4 : 1;
+    const int ncol = C / W;                       // column groups per row
+    const int nb = gridDim.x;
+    const int64_t rows_per_block = cdiv64(rows, nb);
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float nsum = 0.f;
+    float *pb = partials + (int64_t)blockIdx.x * (C + 1);
+    // column groups are processed in chunks of up to 256 lanes
+    for (int cbase = 0; cbase < ncol; cbase += 256) {
+        const int cg = ncol - cbase < 256 ? ncol - cbase : 256;   // lanes per row in this chunk
+        const int rpb = 256 / cg;                                  // rows handled concurrently
+        const int lane_c = threadIdx.x % cg, lane_r = threadIdx.x / cg;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (lane_r < rpb) {
+            for (int64_t r = r0 + lane_r; r < r1; r += rpb) {
+                const int64_t off = r * C + (int64_t)(cbase + lane_c) * W;
+                float nv = 0.f;
+                if (noise) nv = noise[((r / rows_per_img) % noise_nb) * noise_hw + r % noise_hw];
+                if (VEC4) {
+                    const float4 gv = *reinterpret_cast<const float4 *>(g + off);
+                    const float4 rv = *reinterpret_cast<const float4 *>(ref + off);
+                    float4 o;
+                    o.x = gv.x * (rv.x > 0.f ? 1.f : alpha) * scale;
+                    o.y = gv.y * (rv.y > 0.f ? 1.f : alpha) * scale;
+                    o.z = gv.z * (rv.z > 0.f ? 1.f : alpha) * scale;
+                    o.w = gv.w * (rv.w > 0.f ? 1.f : alpha) * scale;
+                    *reinterpret_cast<float4 *>(gx + off) = o;
+                    acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
+                    nsum += (o.x + o.y + o.z + o.w) * nv;
+                } else {
+                    const float o = g[off] * (ref[off] > 0.f ? 1.f : alpha) * scale;
+                    gx[off] = o;
+                    acc[0] += o;
+                    nsum += o * nv;
+                }
+            }
+        }
+        if (want_gb) {
+            __syncthreads();
+            for (int j = 0; j < W; j++) lds[threadIdx.x * W + j] = (lane_r < rpb) ? acc[j] : 0.f;
+            __syncthreads();
+            // reduce over the rpb row-lanes sharing a column group
+            if (threadIdx.x < cg) {
+                for (int j = 0; j < W; j++) {
+                    float s = 0.f;
+                    for (int rr = 0; rr < rpb; rr++) s += lds[(rr * cg + threadIdx.x) * W + j];
+                    pb[(cbase + threadIdx.x) * W + j] = s;
+                }
+            }
+        }
+    }
+    if (noise) {
+        const float tot = block_sum_256(nsum, lds + 256 * W);
+        if (threadIdx.x == 0) pb[C] = tot;
+    }
+}
+
+// out[c] = sum_b partials[b*(stride) + c]
+__global__ __launch_bounds__(256) void partial_colsum_kernel(const float *__restrict__ partials, float *__restrict__ out,
+                                                             int nb, int stride, int ncols, int col0) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncols) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; b++) s += partials[(int64_t)b * stride + col0 + c];
+    out[c] = s;
+}
+
+extern "C" int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx, float *gb, float *gnw,
+                                     const float *noise, int64_t rows, int C, int64_t rows_per_img,
+                                     int64_t noise_nb, int64_t noise_hw, float alpha, float scale,
+                                     float *partials, void *stream) {
+    if (!g || !ref || !gx || rows <= 0 || C <= 0 || ((gb || gnw) && !partials)) return RICK_EINVAL;
+    if (gnw && !noise) return RICK_EINVAL;
+    if (noise && (rows_per_img <= 0 || noise_nb <= 0 || noise_hw <= 0)) return RICK_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = rick_bias_act_bwd_blocks(rows, C);
+    const bool vec = (C % 4 == 0) && (((uintptr_t)g | (uintptr_t)ref | (uintptr_t)gx) % 16 == 0);
+    const size_t lds = (256 * 4 + 8) * sizeof(float);
+    const float *nz = gnw ? noise : nullptr;
+    if (vec)
+        hipLaunchKernelGGL(bias_act_bwd_kernel<true>, dim3(nb), dim3(256), lds, st, g, ref, gx, nz, partials, rows, C,
+                           rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0);
+    else
+        hipLaunchKernelGGL(bias_act_bwd_kernel<false>, dim3(nb), dim3(256), lds, st, g, ref, gx, nz, partials, rows, C,
+                           rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0);
+    if (gb) hipLaunchKernelGGL(partial_colsum_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partials, gb, nb, C + 1, C, 0);
+    if (gnw) hipLaunchKernelGGL(partial_colsum_kernel, dim3(1), dim3(256), 0, st, partials, gnw, nb, C + 1, 1, C);
+    RICK_LAUNCH_STATUS();
+}
+
+// --------------------------------------------------------------------- modulation helpers
+// y[n,p,c] = x[n,p,c] * s[n,c]
+__global__ __launch_bounds__(256) void chan_scale_kernel(const float *__restrict__ x, const float *__restrict__ s,
+                                                         float *__restrict__ y, int64_t PC, int C, int64_t total4) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += stride) {
+        const int64_t i = i4 << 2;
+        const int64_t n = i / PC;
+        const int c = (int)(i % C);
+        const float4 xv = reinterpret_cast<const float4 *>(x)[i4];
+        const float4 sv = *reinterpret_cast<const float4 *>(s + n * C + c);
+        reinterpret_cast<float4 *>(y)[i4] = make_float4(xv.x * sv.x, xv.y * sv.y, xv.z * sv.z, xv.w * sv.w);
+    }
+}
+__global__ __launch_bounds__(256) void chan_scale_scalar_kernel(const float *__restrict__ x, const float *__restrict__ s,
+                                                                float *__restrict__ y, int64_t PC, int C, int64_t total) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride)
+        y[i] = x[i] * s[(i / PC) * C + i % C];
+}
+
+extern "C" int rick_chan_scale_f32(const float *x, const float *s, float *y, int N, int64_t P, int C, void *stream) {
+    if (!x || !s || !y || N <= 0 || P <= 0 || C <= 0) return RICK_EINVAL;
+    const int64_t total = (int64_t)N * P * C;
+    hipStream_t st = (hipStream_t)stream;
+    if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)s | (uintptr_t)y) % 16 == 0))
+        hipLaunchKernelGGL(chan_scale_kernel, dim3(ew_grid(total / 4)), dim3(256), 0, st, x, s, y, P * C, C, total / 4);
+    else
+        hipLaunchKernelGGL(chan_scale_scalar_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, s, y, P * C, C, total);
+    RICK_LAUNCH_STATUS();
+}
+
+// d[n,c] = sum_p a[n,p,c]*b[n,p,c].  grid (blocks_p, N); partials [blk][n][c]
+#define HWDOT_ROWS 128
+extern "C" int rick_hw_dot_blocks(int64_t P) {
+    int64_t nb = cdiv64(P, HWDOT_ROWS);
+    if (nb > 512) nb = 512;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+__global__ __launch_bounds__(256) void hw_dot_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                     float *__restrict__ partials, int64_t P, int C) {
+    extern __shared__ float lds[];
+    const int n = blockIdx.y, N = gridDim.y, nb = gridDim.x;
+    const int64_t ppb = cdiv64(P, nb);
+    const int64_t p0 = (int64_t)blockIdx.x * ppb, p1 = p0 + ppb < P ? p0 + ppb : P;
+    const float *an = a + (int64_t)n * P * C, *bn = b + (int64_t)n * P * C;
+    float *pb = partials + ((int64_t)blockIdx.x * N + n) * C;
+    for (int cbase = 0; cbase < C; cbase += 256) {
+        const int cg = C - cbase < 256 ? C - cbase : 256;
+        const int rpb = 256 / cg;
+        const int lane_c = threadIdx.x % cg, lane_r = threadIdx.x / cg;
+        float acc = 0.f;
+        if (lane_r < rpb)
+            for (int64_t p = p0 + lane_r; p < p1; p += rpb) {
+                const int64_t off = p * C + cbase + lane_c;
+                acc += an[off] * bn[off];
+            }
+        __syncthreads();
+        lds[threadIdx.x] = lane_r < rpb ? acc : 0.f;
+        __syncthreads();
+        if (threadIdx.x < cg) {
+            float s = 0.f;
+            for (int rr = 0; rr < rpb; rr++) s += lds[rr * cg + threadIdx.x];
+            pb[cbase + threadIdx.x] = s;
+        }
+    }
+}
+
+extern "C" int rick_hw_dot_f32(const float *a, const float *b, float *d, int N, int64_t P, int C,
+                               float *partials, void *stream) {
+    if (!a || !b || !d || !partials || N <= 0 || P <= 0 || C <= 0 || N > 65535) return RICK_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = rick_hw_dot_blocks(P);
+    hipLaunchKernelGGL(hw_dot_kernel, dim3(nb, N), dim3(256), 256 * sizeof(float), st, a, b, partials, P, C);
+    hipLaunchKernelGGL(partial_colsum_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, st, partials, d, nb, N * C, N * C, 0);
+    RICK_LAUNCH_STATUS();
+}
+
+__global__ __launch_bounds__(256) void add_scale_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                        float *__restrict__ y, int64_t n, float alpha) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t n4 = n >> 2;
+    for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += stride) {
+        float4 av = reinterpret_cast<const float4 *>(a)[i4];
+        if (b) {
+            const float4 bv = reinterpret_cast<const float4 *>(b)[i4];
+            av.x += bv.x; av.y += bv.y; av.z += bv.z; av.w += bv.w;
+        }
+        reinterpret_cast<float4 *>(y)[i4] = make_float4(av.x * alpha, av.y * alpha, av.z * alpha, av.w * alpha);
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        y[i] = (a[i] + (b ? b[i] : 0.f)) * alpha;
+}
+
+extern "C" int rick_add_scale_f32(const float *a, const float *b, float *y, int64_t n, float alpha, void *stream) {
+    if (!a || !y || n < 0) return RICK_EINVAL;
+    if (n == 0) return 0;
+    if (((uintptr_t)a | (uintptr_t)y | (uintptr_t)(b ? b : a)) % 16 != 0) return RICK_EINVAL;
+    hipLaunchKernelGGL(add_scale_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, y, n, alpha);
+    RICK_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------- minibatch stddev
+// x[B, P, C] (NHWC, P = H*W), group = B (model_probe_tune.py:748-756 with group == batch):
+//   sd[p,c] = sqrt(mean_b (x - mean_b x)^2 + 1e-8);  stat = mean_{p,c} sd
+//   out[b,p,0:C] = x[b,p,:], out[b,p,C] = stat.
+// Single block (the tensor is B x 16 x 512): wavefront-shuffle block reduction.
+__global__ __launch_bounds__(256) void mbstd_fwd_kernel(const float *__restrict__ x, float *__restrict__ out,
+                                                        float *__restrict__ stat, int B, int P, int C) {
+    __shared__ float red[8];
+    const int PC = P * C;
+    float local = 0.f;
+    for (int i = threadIdx.x; i < PC; i += 256) {
+        float mean = 0.f;
+        for (int b = 0; b < B; b++) mean += x[(int64_t)b * PC + i];
+        mean /= B;
+        float var = 0.f;
+        for (int b = 0; b < B; b++) {
+            const float d = x[(int64_t)b * PC + i] - mean;
+            var += d * d;
+        }
+        local += sqrtf(var / B + 1e-8f);
+    }
+    const float tot = block_sum_256(local, red) / PC;
+    if (threadIdx.x == 0) stat[0] = tot;
+    const int C1 = C + 1;
+    for (int64_t i = threadIdx.x; i < (int64_t)B * P * C1; i += 256) {
+        const int c = (int)(i % C1);
+        const int64_t bp = i / C1;
+        out[i] = c < C ? x[bp * C + c] : tot;
+    }
+}
+
+// gx[b,p,c] = gout[b,p,c] + G/(P*C) * (x[b,p,c]-mean[p,c]) / (B * sd[p,c]),  G = sum_{b,p} gout[b,p,C]
+__global__ __launch_bounds__(256) void mbstd_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gout,
+                                                        float *__restrict__ gx, int B, int P, int C) {
+    __shared__ float red[8];
+    const int PC = P * C, C1 = C + 1;
+    float gl = 0.f;
+    for (int i = threadIdx.x; i < B * P; i += 256) gl += gout[(int64_t)i * C1 + C];
+    const float G = block_sum_256(gl, red) / PC;
+    for (int i = threadIdx.x; i < PC; i += 256) {
+        const int p = i / C, c = i - p * C;
+        float mean = 0.f;
+        for (int b = 0; b < B; b++) mean += x[(int64_t)b * PC + i];
+        mean /= B;
+        float var = 0.f;
+        for (int b = 0; b < B; b++) {
+            const float d = x[(int64_t)b * PC + i] - mean;
+            var += d * d;
+        }
+        const float sd = sqrtf(var / B + 1e-8f);
+        for (int b = 0; b < B; b++) {
+            const float d = x[(int64_t)b * PC + i] - mean;
+            gx[(int64_t)b * PC + i] = gout[((int64_t)b * P + p) * C1 + c] + G * d / (B * sd);
+        }
+    }
+}
+
+extern "C" int rick_mbstd_fwd_f32(const float *x, float *out, float *stat, int B, int P, int C, void *stream) {
+    if (!x || !out || !stat || B <= 0 || P <= 0 || C <= 0) return RICK_EINVAL;
+    hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, out, stat, B, P, C);
+    RICK_LAUNCH_STATUS();
+}
+extern "C" int rick_mbstd_bwd_f32(const float *x, const float *gout, float *gx, int B, int P, int C, void *stream) {
+    if (!x || !gout || !gx || B <= 0 || P <= 0 || C <= 0) return RICK_EINVAL;
+    hipLaunchKernelGGL(mbstd_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, gout, gx, B, P, C);
+    RICK_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------ Fisher / optimiser
+__global__ __launch_bounds__(256) void sq_acc_kernel(float *__restrict__ acc, const float *__restrict__ g, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float v = g[i];
+        acc[i] = __builtin_fmaf(v, v, acc[i]);
+    }
+}
+extern "C" int rick_sq_accumulate_f32(float *acc, const float *g, int64_t n, void *stream) {
+    if (!acc || !g || n < 0) return RICK_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sq_acc_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, acc, g, n);
+    RICK_LAUNCH_STATUS();
+}
+
+// One wavefront per filter: lanes stride over (outer, inner), shuffle-reduce.
+__global__ __launch_bounds__(256) void filter_reduce_kernel(const float *__restrict__ x, float *__restrict__ out,
+                                                            int64_t outer, int64_t outer_stride, int64_t nfilters,
+                                                            int64_t filter_stride, int64_t inner, float scale) {
+    const int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= nfilters) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int64_t o = 0; o < outer; o++) {
+        const float *base = x + o * outer_stride + f * filter_stride;
+        for (int64_t i = lane; i < inner; i += 64) s += base[i];
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[f] = s * scale;
+}
+extern "C" int rick_filter_reduce_f32(const float *x, float *out, int64_t outer, int64_t outer_stride,
+                                      int64_t nfilters, int64_t filter_stride, int64_t inner, float scale,
+                                      void *stream) {
+    if (!x || !out || outer <= 0 || nfilters <= 0 || inner <= 0) return RICK_EINVAL;
+    hipLaunchKernelGGL(filter_reduce_kernel, dim3((unsigned)cdiv64(nfilters, 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, out, outer, outer_stride, nfilters, filter_stride, inner, scale);
+    RICK_LAUNCH_STATUS();
+}
+
+__global__ __launch_bounds__(256) void masked_adam_kernel(float *__restrict__ p, float *__restrict__ g,
+                                                          float *__restrict__ m, float *__restrict__ v,
+                                                          const uint8_t *__restrict__ mask, int64_t n, float lr,
+                                                          float beta1, float beta2, float eps, float bc1, float bc2) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float step_size = lr / bc1;
+    const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float gv = g[i], pv = p[i];
+        if (mask) {
+            const uint8_t mk = mask[i];
+            if (mk & 2) pv = 0.f;
+            if (mk & 3) { gv = 0.f; g[i] = 0.f; }
+        }
+        // torch.optim.Adam single-tensor: m.lerp_(g, 1-b1); v = b2*v + (1-b2) g^2
+        const float mv = m[i] + (gv - m[i]) * (1.f - beta1);
+        const float vv = v[i] * beta2 + (1.f - beta2) * gv * gv;
+        m[i] = mv;
+        v[i] = vv;
+        const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+        p[i] = pv - step_size * (mv / denom);
+    }
+}
+extern "C" int rick_masked_adam_f32(float *p, float *g, float *m, float *v, const uint8_t *mask, int64_t n,
+                                    float lr, float beta1, float beta2, float eps, float bc1, float bc2,
+                                    void *stream) {
+    if (!p || !g || !m || !v || n < 0) return RICK_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(masked_adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, mask, n,
+                       lr, beta1, beta2, eps, bc1, bc2);
+    RICK_LAUNCH_STATUS();
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float *__restrict__ e, const float *__restrict__ p, int64_t n, float decay) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float om = 1.f - decay;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) e[i] = e[i] * decay + p[i] * om;
+}
+extern "C" int rick_ema_f32(float *ema, const float *p, int64_t n, float decay, void *stream) {
+    if (!ema || !p || n < 0) return RICK_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(ema_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, ema, p, n, decay);
+    RICK_LAUNCH_STATUS();
+}
+
+extern "C" int rick_abi_version(void) { return 1; }

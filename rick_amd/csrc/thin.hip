@@ -1,0 +1,158 @@
+// Thin (J <= 4) channel products for the RGB side of the networks — HBM-bound, so no MFMA:
+// each NHWC activation element is read exactly once, dot products are finished with
+// wavefront shuffles, reductions over pixels are two-stage and deterministic.
+//   ToRGB (model_probe_tune.py:351-370):  rgb[n,j,p] = sum_c x[n,p,c] * (scale*w[j,c]*s[n,c]) + ...
+//   D input conv (model_probe_tune.py:679): y[n,p,co] = sum_j img[n,j,p] * (scale*w[co,j])
+#include "common.h"
+
+#define THIN_MAXJ 4
+
+// t[n,j,p] = sum_c x[n,p,c] * W[n,j,c] (+ add[n,j,p]);  LPP lanes cooperate on one pixel.
+__global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__ x, const float *__restrict__ W,
+                                                       int64_t w_bstride, const float *__restrict__ add,
+                                                       float *__restrict__ t, int64_t P, int C, int J, int lpp) {
+    const int n = blockIdx.y;
+    const int pix_per_block = 256 / lpp;
+    const int sub = threadIdx.x % lpp, pl = threadIdx.x / lpp;
+    const float *Wn = W + (int64_t)n * w_bstride;
+    const int C4 = C >> 2;
+    for (int64_t p0 = (int64_t)blockIdx.x * pix_per_block; p0 < P; p0 += (int64_t)gridDim.x * pix_per_block) {
+        const int64_t p = p0 + pl;
+        float acc[THIN_MAXJ] = {0.f, 0.f, 0.f, 0.f};
+        if (p < P) {
+            const float4 *xp = reinterpret_cast<const float4 *>(x + ((int64_t)n * P + p) * C);
+            for (int c4 = sub; c4 < C4; c4 += lpp) {
+                const float4 xv = xp[c4];
+#pragma unroll
+                for (int j = 0; j < THIN_MAXJ; j++)
+                    if (j < J) {
+                        const float4 wv = *reinterpret_cast<const float4 *>(Wn + (int64_t)j * C + c4 * 4);
+                        acc[j] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < THIN_MAXJ; j++)
+            for (int off = lpp >> 1; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off, 64);
+        if (p < P && sub < J) {
+            // lane `sub` writes output channel j = sub (select without dynamic register indexing)
+            float v = acc[0];
+            if (sub == 1) v = acc[1];
+            if (sub == 2) v = acc[2];
+            if (sub == 3) v = acc[3];
+            const int64_t o = ((int64_t)n * J + sub) * P + p;
+            if (add) v += add[o];
+            t[o] = v;
+        }
+    }
+}
+
+extern "C" int rick_thin_fwd_f32(const float *x, const float *W, int64_t w_bstride, const float *add, float *t,
+                                 int N, int64_t P, int C, int J, void *stream) {
+    if (!x || !W || !t || N <= 0 || P <= 0 || C <= 0 || C % 4 || J < 1 || J > THIN_MAXJ || N > 65535) return RICK_EINVAL;
+    int lpp = 64;
+    while (lpp > C / 4) lpp >>= 1;
+    if (lpp < J) lpp = 4;   // J <= 4 lanes needed for the store; C%4==0 && C>=4 guarantees c4 loop ok
+    int64_t nb = cdiv64(P, 256 / lpp);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(thin_fwd_kernel, dim3((unsigned)nb, N), dim3(256), 0, (hipStream_t)stream, x, W, w_bstride, add, t,
+                       P, C, J, lpp);
+    RICK_LAUNCH_STATUS();
+}
+
+// x[n,p,c] = sum_j t[n,j,p] * W[n,j,c]
+__global__ __launch_bounds__(256) void thin_bwdx_kernel(const float *__restrict__ t, const float *__restrict__ W,
+                                                        int64_t w_bstride, float *__restrict__ x, int64_t P, int C, int J) {
+    const int n = blockIdx.y;
+    const int C4 = C >> 2;
+    const int64_t total4 = P * C4;
+    const float *Wn = W + (int64_t)n * w_bstride;
+    const float *tn = t + (int64_t)n * J * P;
+    float4 *xn = reinterpret_cast<float4 *>(x + (int64_t)n * P * C);
+    for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * 256) {
+        const int64_t p = i4 / C4;
+        const int c4 = (int)(i4 - p * C4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < THIN_MAXJ; j++)
+            if (j < J) {
+                const float tv = tn[(int64_t)j * P + p];
+                const float4 wv = *reinterpret_cast<const float4 *>(Wn + (int64_t)j * C + c4 * 4);
+                acc.x += tv * wv.x; acc.y += tv * wv.y; acc.z += tv * wv.z; acc.w += tv * wv.w;
+            }
+        xn[i4] = acc;
+    }
+}
+
+extern "C" int rick_thin_bwdx_f32(const float *t, const float *W, int64_t w_bstride, float *x, int N, int64_t P, int C,
+                                  int J, void *stream) {
+    if (!x || !W || !t || N <= 0 || P <= 0 || C <= 0 || C % 4 || J < 1 || J > THIN_MAXJ || N > 65535) return RICK_EINVAL;
+    int64_t nb = cdiv64(P * (C / 4), 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(thin_bwdx_kernel, dim3((unsigned)nb, N), dim3(256), 0, (hipStream_t)stream, t, W, w_bstride, x, P, C, J);
+    RICK_LAUNCH_STATUS();
+}
+
+// G[n,j,c] = sum_p t[n,j,p] * x[n,p,c];  partials [blk][n][j][c]
+#define THINW_ROWS 256
+extern "C" int rick_thin_wgrad_blocks(int64_t P) {
+    int64_t nb = cdiv64(P, THINW_ROWS);
+    if (nb > 256) nb = 256;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(const float *__restrict__ t, const float *__restrict__ x,
+                                                         float *__restrict__ partials, int64_t P, int C, int J) {
+    extern __shared__ float lds[];   // [256]
+    const int n = blockIdx.y, N = gridDim.y, nb = gridDim.x;
+    const int64_t ppb = cdiv64(P, nb);
+    const int64_t p0 = (int64_t)blockIdx.x * ppb, p1 = p0 + ppb < P ? p0 + ppb : P;
+    const float *xn = x + (int64_t)n * P * C;
+    const float *tn = t + (int64_t)n * J * P;
+    float *pb = partials + ((int64_t)blockIdx.x * N + n) * J * C;
+    for (int cbase = 0; cbase < C; cbase += 256) {
+        const int cg = C - cbase < 256 ? C - cbase : 256;
+        const int rpb = 256 / cg;
+        const int lane_c = threadIdx.x % cg, lane_r = threadIdx.x / cg;
+        float acc[THIN_MAXJ] = {0.f, 0.f, 0.f, 0.f};
+        if (lane_r < rpb)
+            for (int64_t p = p0 + lane_r; p < p1; p += rpb) {
+                const float xv = xn[p * C + cbase + lane_c];
+#pragma unroll
+                for (int j = 0; j < THIN_MAXJ; j++)
+                    if (j < J) acc[j] += tn[(int64_t)j * P + p] * xv;
+            }
+#pragma unroll
+        for (int j = 0; j < THIN_MAXJ; j++) {
+            if (j >= J) break;
+            __syncthreads();
+            lds[threadIdx.x] = lane_r < rpb ? acc[j] : 0.f;
+            __syncthreads();
+            if (threadIdx.x < cg) {
+                float s = 0.f;
+                for (int rr = 0; rr < rpb; rr++) s += lds[rr * cg + threadIdx.x];
+                pb[(int64_t)j * C + cbase + threadIdx.x] = s;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void thin_partial_sum_kernel(const float *__restrict__ partials, float *__restrict__ out,
+                                                               int nb, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; b++) s += partials[(int64_t)b * n + i];
+    out[i] = s;
+}
+
+extern "C" int rick_thin_wgrad_f32(const float *t, const float *x, float *G, int N, int64_t P, int C, int J,
+                                   float *partials, void *stream) {
+    if (!x || !G || !t || !partials || N <= 0 || P <= 0 || C <= 0 || J < 1 || J > THIN_MAXJ || N > 65535) return RICK_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = rick_thin_wgrad_blocks(P);
+    hipLaunchKernelGGL(thin_wgrad_kernel, dim3(nb, N), dim3(256), 256 * sizeof(float), st, t, x, partials, P, C, J);
+    const int64_t n = (int64_t)N * J * C;
+    hipLaunchKernelGGL(thin_partial_sum_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, partials, G, nb, n);
+    RICK_LAUNCH_STATUS();
+}

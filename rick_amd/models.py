@@ -1,0 +1,361 @@
+"""StyleGAN2 Generator / Discriminator on the MI355X engine, with the reference's constructor
+and forward signatures and state_dict keys (gan_training/models/model_probe_tune.py:373-764;
+key list: SURVEY.md §8a row M*), so rosinality checkpoints load and the RICK Fisher / mask code
+can address parameters by the same names.
+
+Differences that do not change results (documented in DESIGN.md):
+  * activations are channels-last; RGB tensors are planar; the image returned by the
+    Generator is made NCHW-contiguous;
+  * modulated convolutions share one weight over the batch (modulation / demodulation folded
+    into the MFMA kernel) instead of B grouped convolutions;
+  * the Discriminator evaluates conv1 / conv2 of each ResBlock once and returns the same 14
+    `feat` tensors (the reference computes them twice, model_probe_tune.py:740-744).
+"""
+import math
+import random
+
+import torch
+from torch import autograd, nn
+from torch.nn import functional as F
+
+from . import op
+from .op import modconv as _mc
+from .op.fused_act import FusedLeakyReLU, fused_leaky_relu, fused_noise_bias_act
+from .op.upfirdn2d import upfirdn2d
+
+CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512}
+
+
+def _channels(res, channel_multiplier):
+    return CHANNELS.get(res, (16384 // res) * channel_multiplier)   # 64:256cm 128:128cm 256:64cm 512:32cm 1024:16cm
+
+
+def make_kernel(k):
+    k = torch.tensor(k, dtype=torch.float32)
+    if k.ndim == 1:
+        k = torch.outer(k, k)
+    return k / k.sum()
+
+
+class PixelNorm(nn.Module):
+    def forward(self, x):
+        return x * torch.rsqrt(x.pow(2).mean(dim=1, keepdim=True) + 1e-8)
+
+
+class _Fir(nn.Module):
+    """FIR holder with one buffer named ``kernel`` (Blur / Upsample / Downsample of the
+    reference, model_probe_tune.py:40-98)."""
+
+    def __init__(self, taps, pad, up=1, down=1, gain=1.0):
+        super().__init__()
+        self.register_buffer('kernel', make_kernel(taps) * gain)
+        self.pad, self.up, self.down = pad, up, down
+
+    def forward(self, x):
+        return upfirdn2d(x, self.kernel, up=self.up, down=self.down, pad=self.pad)
+
+
+def Blur(kernel, pad, upsample_factor=1):
+    return _Fir(kernel, pad, gain=float(upsample_factor ** 2) if upsample_factor > 1 else 1.0)
+
+
+def Upsample(kernel, factor=2):
+    p = len(kernel) - factor
+    return _Fir(kernel, ((p + 1) // 2 + factor - 1, p // 2), up=factor, gain=float(factor ** 2))
+
+
+def Downsample(kernel, factor=2):
+    p = len(kernel) - factor
+    return _Fir(kernel, ((p + 1) // 2, p // 2), down=factor)
+
+
+class EqualLinear(nn.Module):
+    """model_probe_tune.py:139-173.  The GEMM itself is a plain library call (rocBLAS via
+    F.linear); the bias + LeakyReLU tail is the fused HIP op."""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init)) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def forward(self, x):
+        if self.activation:
+            return fused_leaky_relu(F.linear(x, self.weight * self.scale), self.bias * self.lr_mul)
+        return F.linear(x, self.weight * self.scale, bias=self.bias * self.lr_mul)
+
+
+class EqualConv2d(nn.Module):
+    """model_probe_tune.py:101-136 on the MFMA conv kernels (weight scale folded into packing)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_channel, in_channel, kernel_size, kernel_size))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.stride, self.padding = stride, padding
+        self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
+
+    def forward(self, x):
+        O, I, k, _ = self.weight.shape
+        if I <= 4 and k == 1 and self.stride == 1:
+            # image -> features (discriminator input, model_probe_tune.py:679): thin product
+            W = (self.weight.view(O, I) * self.scale).t().unsqueeze(0)          # [1, J=I, C=O]
+            y = op.thin_bwdx(x.contiguous(), W)
+        else:
+            y = op.conv2d(x, self.weight, self.stride, self.padding, wscale=self.scale, key=(self.weight, 'w'))
+        if self.bias is not None:
+            y = y + self.bias.view(1, -1, 1, 1)
+        return y
+
+
+class ModulatedConv2d(nn.Module):
+    """model_probe_tune.py:188-284 (3x3 plain / 3x3 upsample / 1x1 no-demod)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
+                 downsample=False, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        if downsample:
+            raise NotImplementedError('downsample=True is never used by the reference networks')
+        self.eps = 1e-8
+        self.kernel_size, self.in_channel, self.out_channel = kernel_size, in_channel, out_channel
+        self.upsample, self.downsample = upsample, downsample
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self.demodulate = demodulate
+
+    def forward(self, x, style):
+        s = self.modulation(style)                                   # [B, Ci]
+        w = self.weight[0]                                           # [Co, Ci, k, k]
+        if self.kernel_size == 1 and self.out_channel <= 4 and not self.demodulate:
+            Wn = (self.scale * w.view(1, self.out_channel, self.in_channel)) * s.unsqueeze(1)   # [B, 3, Ci]
+            return op.thin_fwd(x, Wn)                                # planar [B, 3, H, W]
+        d = _mc.demod_coeff(w, s, self.scale, self.eps) if self.demodulate else None
+        key = (self.weight, 'mod')
+        if op.second_order_enabled():
+            y = _mc.modulated_conv_composed(x, w, s, None, self.scale, self.upsample, key)
+            if self.upsample:
+                y = self.blur(y)
+            return op.chan_scale(y, d) if d is not None else y
+        y = _mc.modulated_conv_fused(x, w, s, d, self.scale, self.upsample, key)
+        return self.blur(y) if self.upsample else y
+
+
+class NoiseInjection(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+    def forward(self, image, noise=None):      # standalone use; StyledConv fuses it with the activation
+        if noise is None:
+            b, _, h, w = image.shape
+            noise = image.new_empty(b, 1, h, w).normal_()
+        return image + self.weight * noise
+
+
+class ConstantInput(nn.Module):
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+
+    def forward(self, x):
+        return self.input.expand(x.shape[0], -1, -1, -1).contiguous(memory_format=torch.channels_last)
+
+
+class StyledConv(nn.Module):
+    """conv -> noise -> bias+LeakyReLU (model_probe_tune.py:314-348); the last two are one kernel."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, blur_kernel=[1, 3, 3, 1],
+                 demodulate=True):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
+                                    blur_kernel=blur_kernel, demodulate=demodulate)
+        self.noise = NoiseInjection()
+        self.activate = FusedLeakyReLU(out_channel)
+
+    def forward(self, x, style, noise=None):
+        out = self.conv(x, style)
+        if noise is None:
+            b, _, h, w = out.shape
+            noise = torch.empty(b, 1, h, w, device=out.device, dtype=out.dtype).normal_()
+        return fused_noise_bias_act(out, self.activate.bias, noise, self.noise.weight,
+                                    self.activate.negative_slope, self.activate.scale)
+
+
+class ToRGB(nn.Module):
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        if upsample:
+            self.upsample = Upsample(blur_kernel)
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+
+    def forward(self, x, style, skip=None):
+        out = self.conv(x, style) + self.bias
+        if skip is not None:
+            out = out + self.upsample(skip)
+        return out
+
+
+class _FisherMixin:
+    def estimate_fisher(self, loglikelihood):
+        """(grads, {name: grad**2}) for every parameter that requires grad
+        (model_probe_tune.py:481-504, :706-729)."""
+        named = [(n, p) for n, p in self.named_parameters()]
+        grads = autograd.grad(loglikelihood, [p for _, p in named], retain_graph=True, allow_unused=True)
+        est = {}
+        for (n, p), g in zip(named, grads):
+            if p.requires_grad:
+                est[n] = g.detach() ** 2 if g is not None else p.detach().clone().zero_()
+        return grads, est
+
+
+class Generator(nn.Module, _FisherMixin):
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01):
+        super().__init__()
+        self.size, self.style_dim = size, style_dim
+        self.style = nn.Sequential(PixelNorm(), *[EqualLinear(style_dim, style_dim, lr_mul=lr_mlp,
+                                                              activation='fused_lrelu') for _ in range(n_mlp)])
+        self.channels = {r: _channels(r, channel_multiplier) for r in (4, 8, 16, 32, 64, 128, 256, 512, 1024)}
+        self.input = ConstantInput(self.channels[4])
+        self.conv1 = StyledConv(self.channels[4], self.channels[4], 3, style_dim, blur_kernel=blur_kernel)
+        self.to_rgb1 = ToRGB(self.channels[4], style_dim, upsample=False)
+        self.log_size = int(math.log(size, 2))
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        self.convs, self.upsamples, self.to_rgbs = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        self.noises = nn.Module()
+        for layer_idx in range(self.num_layers):
+            res = (layer_idx + 5) // 2
+            self.noises.register_buffer(f'noise_{layer_idx}', torch.randn(1, 1, 2 ** res, 2 ** res))
+        in_channel = self.channels[4]
+        for i in range(3, self.log_size + 1):
+            out_channel = self.channels[2 ** i]
+            self.convs.append(StyledConv(in_channel, out_channel, 3, style_dim, upsample=True, blur_kernel=blur_kernel))
+            self.convs.append(StyledConv(out_channel, out_channel, 3, style_dim, blur_kernel=blur_kernel))
+            self.to_rgbs.append(ToRGB(out_channel, style_dim))
+            in_channel = out_channel
+        self.n_latent = self.log_size * 2 - 2
+
+    def make_noise(self):
+        device = self.input.input.device
+        noises = [torch.randn(1, 1, 4, 4, device=device)]
+        for i in range(3, self.log_size + 1):
+            noises += [torch.randn(1, 1, 2 ** i, 2 ** i, device=device) for _ in range(2)]
+        return noises
+
+    def mean_latent(self, n_latent):
+        z = torch.randn(n_latent, self.style_dim, device=self.input.input.device)
+        return self.style(z).mean(0, keepdim=True)
+
+    def get_latent(self, input):
+        return self.style(input)
+
+    def forward(self, styles, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
+                input_is_latent=False, noise=None, randomize_noise=True, return_feats=False):
+        if not input_is_latent:
+            styles = [self.style(s) for s in styles]
+        if noise is None:
+            noise = ([None] * self.num_layers if randomize_noise
+                     else [getattr(self.noises, f'noise_{i}') for i in range(self.num_layers)])
+        if truncation < 1:
+            styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
+        if len(styles) < 2:
+            inject_index = self.n_latent
+            latent = styles[0].unsqueeze(1).repeat(1, inject_index, 1) if styles[0].ndim < 3 else styles[0]
+        else:
+            if inject_index is None:
+                inject_index = random.randint(1, self.n_latent - 1)
+            latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
+                                styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
+        feats = []
+        out = self.conv1(self.input(latent), latent[:, 0], noise=noise[0])
+        feats.append(out)
+        skip = self.to_rgb1(out, latent[:, 1])
+        i = 1
+        for blk, to_rgb in enumerate(self.to_rgbs):
+            out = self.convs[2 * blk](out, latent[:, i], noise=noise[2 * blk + 1])
+            feats.append(out)
+            out = self.convs[2 * blk + 1](out, latent[:, i + 1], noise=noise[2 * blk + 2])
+            feats.append(out)
+            skip = to_rgb(out, latent[:, i + 2], skip)
+            i += 2
+        image = skip.contiguous()
+        if return_latents:
+            return image, latent
+        if return_feats:
+            return image, feats
+        return image, None
+
+
+class ConvLayer(nn.Sequential):
+    """[Blur] + EqualConv2d + [FusedLeakyReLU] with the reference's child indices
+    (model_probe_tune.py:595-641) — the Fisher code derives bias keys from them."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, downsample=False, blur_kernel=[1, 3, 3, 1], bias=True,
+                 activate=True):
+        layers = []
+        if downsample:
+            p = (len(blur_kernel) - 2) + (kernel_size - 1)
+            layers.append(Blur(blur_kernel, pad=((p + 1) // 2, p // 2)))
+            stride, self.padding = 2, 0
+        else:
+            stride, self.padding = 1, kernel_size // 2
+        layers.append(EqualConv2d(in_channel, out_channel, kernel_size, padding=self.padding, stride=stride,
+                                  bias=bias and not activate))
+        if activate:
+            if not bias:
+                raise NotImplementedError('ScaledLeakyReLU variant is not used by the reference networks')
+            layers.append(FusedLeakyReLU(out_channel))
+        super().__init__(*layers)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_channel, out_channel, blur_kernel=[1, 3, 3, 1], downsample=True):
+        super().__init__()
+        self.conv1 = ConvLayer(in_channel, in_channel, 3)
+        self.conv2 = ConvLayer(in_channel, out_channel, 3, downsample=downsample)
+        self.skip = ConvLayer(in_channel, out_channel, 1, downsample=downsample, activate=False, bias=False)
+
+    def forward(self, x, feat=None):
+        t1 = self.conv1(x)
+        t2 = self.conv2(t1)
+        if feat is not None:
+            feat += [t1, t2]
+        return op.add_scale(t2, self.skip(x), 1 / math.sqrt(2))
+
+
+class Discriminator(nn.Module, _FisherMixin):
+    def __init__(self, size, channel_multiplier=2, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        ch = {r: _channels(r, channel_multiplier) for r in (4, 8, 16, 32, 64, 128, 256, 512, 1024)}
+        convs = [ConvLayer(3, ch[size], 1)]
+        log_size = int(math.log(size, 2))
+        in_channel = ch[size]
+        for i in range(log_size, 2, -1):
+            out_channel = ch[2 ** (i - 1)]
+            convs.append(ResBlock(in_channel, out_channel, blur_kernel))
+            in_channel = out_channel
+        self.convs = nn.Sequential(*convs)
+        self.stddev_group, self.stddev_feat = 25, 1
+        self.final_conv = ConvLayer(in_channel + 1, ch[4], 3)
+        self.final_linear = nn.Sequential(EqualLinear(ch[4] * 4 * 4, ch[4], activation='fused_lrelu'),
+                                          EqualLinear(ch[4], 1))
+
+    def forward(self, inp, ind=None, real=False):
+        feat = []
+        x = self.convs[0](inp)
+        feat.append(x)
+        for blk in list(self.convs)[1:]:
+            x = blk(x, feat)
+        out = op.minibatch_stddev(x, self.stddev_group, self.stddev_feat, second_order=op.second_order_enabled())
+        out = self.final_conv(out)
+        feat.append(out)
+        out = out.contiguous().view(out.shape[0], -1)      # NCHW flatten order, as the checkpoint expects
+        return self.final_linear(out), feat

@@ -1,0 +1,36 @@
+"""Drop-in replacements for the reference's ``op`` package (op/__init__.py:1-2) plus the
+additional HIP ops the MI355X engine is built from."""
+import contextlib
+
+from .fused_act import FusedLeakyReLU, FusedLeakyReLU_kml, fused_leaky_relu, fused_noise_bias_act
+from .upfirdn2d import upfirdn2d
+from .conv import (bump_weights_epoch, conv2d, conv_transpose2d, get_precision, set_precision)
+from .misc import add_scale, chan_scale, hw_dot, minibatch_stddev, thin_bwdx, thin_fwd
+from . import modconv
+
+_second_order = False
+
+
+def second_order_enabled():
+    return _second_order
+
+
+@contextlib.contextmanager
+def second_order(enabled=True):
+    """Inside this context every op builds a graph that can be differentiated again
+    (R1: train_dynamic_update_prune.py:89-96; path length: :104-118).  Outside it the modulated
+    convolutions and minibatch-stddev use fused single-kernel paths whose backward is
+    first-order only (it raises if differentiated twice)."""
+    global _second_order
+    prev = _second_order
+    _second_order = enabled
+    try:
+        yield
+    finally:
+        _second_order = prev
+
+
+__all__ = ['FusedLeakyReLU', 'FusedLeakyReLU_kml', 'fused_leaky_relu', 'fused_noise_bias_act', 'upfirdn2d',
+           'conv2d', 'conv_transpose2d', 'set_precision', 'get_precision', 'bump_weights_epoch',
+           'add_scale', 'chan_scale', 'hw_dot', 'minibatch_stddev', 'thin_fwd', 'thin_bwdx',
+           'second_order', 'second_order_enabled', 'modconv']

@@ -1,0 +1,248 @@
+"""Convolution family on the MFMA implicit-GEMM kernels (rick_amd/csrc/conv.hip).
+
+Replaces the F.conv2d / F.conv_transpose2d calls of the reference model
+(model_probe_tune.py:122,265,274,280) and their autograd.  Three bilinear primitives that
+are closed under differentiation, so R1 / path-length second-order terms need nothing else:
+
+    conv  (x, w)       y[n,o,p]      = sum_{i,k} w[o,i,k] x[n,i,p*s + k - pad]
+    convT (x, w)       y[n,o,q]     += w[o,i,k] x[n,i,p]      with q = p*s + k - pad
+    wgrad (a, b)       gw[o,i,k]     = sum_{n,p} a[n,o,p] b[n,i,p*s + k - pad]
+
+    d conv /dx = convT(g, w^T)     d conv /dw = wgrad(g, x)
+    d convT/dx = conv (g, w^T)     d convT/dw = wgrad(x, g)^T
+    d wgrad/da = conv (b, gg)      d wgrad/db = convT(a, gg^T)
+
+(w^T swaps the two channel axes; no spatial flips are needed because the tap geometry is
+explicit.)  All activations are channels-last; weights are any [O, I, kh, kw] view whose last
+two dims are jointly contiguous.  `precision()` selects bf16x3 (default, fp32-grade) or
+plain bf16 MFMA.
+"""
+import ctypes
+import weakref
+
+import torch
+from torch.autograd import Function
+
+from .._lib import MAX_TAPS, ConvGeom, check, lib, ptr, require_cuda_f32, stream_ptr
+
+_SPLIT = 2          # 2: bf16 hi/lo split, 3 MFMAs per product (fp32-grade); 1: plain bf16
+_weights_epoch = 0  # bumped by optimisers that update parameters through raw pointers
+_pack_cache = weakref.WeakKeyDictionary()
+
+
+def set_precision(name):
+    """'bf16x3' (default; parity-grade) or 'bf16' (single pass, ~3x the MFMA rate, ~2^-9 relative)."""
+    global _SPLIT
+    _SPLIT = {'bf16x3': 2, 'bf16': 1}[name]
+
+
+def get_precision():
+    return 'bf16x3' if _SPLIT == 2 else 'bf16'
+
+
+def bump_weights_epoch():
+    """Invalidate cached packed weights (call after any raw-pointer parameter update)."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def _nhwc(x):
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def _empty_nhwc(n, c, h, w, like):
+    return torch.empty((n, c, h, w), device=like.device, dtype=like.dtype, memory_format=torch.channels_last)
+
+
+def _w_strides(w):
+    """(tensor, s_o, s_i, s_t) with element (o, i, ky*kw+kx) at s_o*o + s_i*i + s_t*(ky*kw+kx)."""
+    kh, kw = w.shape[2], w.shape[3]
+    st = w.stride()
+    if kh * kw > 1 and not (st[2] == kw * st[3]):
+        w = w.contiguous()
+        st = w.stride()
+    s_t = st[3] if kh * kw > 1 else 1
+    return w, st[0], st[1], s_t
+
+
+def _pack(w, scale, key=None):
+    """Pack w[O, I, kh, kw] (any strides) * scale for the igemm A operand.  `key` = (param, tag)
+    enables caching across calls until the parameter changes."""
+    O, I, kh, kw = w.shape
+    if key is not None:
+        ent = _pack_cache.get(key[0])
+        sig = (key[1], key[0]._version, _weights_epoch, _SPLIT, float(scale), tuple(w.shape), w.stride(), w.data_ptr())
+        if ent is not None and sig in ent:
+            return ent[sig]
+    w, s_o, s_i, s_t = _w_strides(w)
+    nbytes = lib.rick_conv_packed_bytes(O, I, kh * kw)
+    buf = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    check(lib.rick_conv_pack_weight(ptr(w), s_o, s_i, s_t, O, I, kh * kw, float(scale), ptr(buf), stream_ptr()),
+          'rick_conv_pack_weight')
+    if key is not None:
+        ent = _pack_cache.setdefault(key[0], {})
+        # keep only entries of the current parameter version
+        for k in [k for k in ent if k[1] != sig[1] or k[2] != sig[2]]:
+            del ent[k]
+        ent[sig] = buf
+    return buf
+
+
+def _geom(N, IH, IW, Ci, OH, OW, Co, GH, GW, is_, os_, oy0, ox0, taps, nslices, alpha=1.0):
+    g = ConvGeom()
+    g.N, g.IH, g.IW, g.Ci, g.OH, g.OW, g.Co = N, IH, IW, Ci, OH, OW, Co
+    g.GH, g.GW, g.is_, g.os, g.oy0, g.ox0 = GH, GW, is_, os_, oy0, ox0
+    if len(taps) > MAX_TAPS:
+        raise RuntimeError(f'conv: at most {MAX_TAPS} taps per launch')
+    g.ntaps, g.nslices = len(taps), nslices
+    for t, (dy, dx, wt) in enumerate(taps):
+        g.dy[t], g.dx[t], g.wt[t] = dy, dx, wt
+    g.split, g.alpha = _SPLIT, alpha
+    return g
+
+
+def conv_out_size(i, k, s, p):
+    return (i + 2 * p - k) // s + 1
+
+
+# ------------------------------------------------------------------------------ raw launches
+def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0):
+    x = _nhwc(x)
+    N, I, IH, IW = x.shape
+    OH, OW = conv_out_size(IH, kh, s, p), conv_out_size(IW, kw, s, p)
+    y = _empty_nhwc(N, O, OH, OW, x)
+    taps = [(ky - p, kx - p, ky * kw + kx) for ky in range(kh) for kx in range(kw)]
+    g = _geom(N, IH, IW, I, OH, OW, O, OH, OW, s, 1, 0, 0, taps, kh * kw, alpha)
+    check(lib.rick_conv_igemm_f32(ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), ctypes.byref(g), stream_ptr()),
+          'rick_conv_igemm_f32')
+    return y
+
+
+def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alpha=1.0):
+    """y[q] += w[k] x[pos], q = pos*s + k - p, one launch per output parity class."""
+    x = _nhwc(x)
+    N, I, IH, IW = x.shape
+    OH, OW = out_hw
+    classes = []
+    for py in range(s):
+        for px in range(s):
+            taps = [((py + p - ky) // s, (px + p - kx) // s, ky * kw + kx)
+                    for ky in range(kh) for kx in range(kw)
+                    if (py + p - ky) % s == 0 and (px + p - kx) % s == 0]
+            GH, GW = (OH - py + s - 1) // s, (OW - px + s - 1) // s
+            if GH > 0 and GW > 0:
+                classes.append((py, px, GH, GW, taps))
+    full = all(len(c[4]) > 0 for c in classes)
+    y = _empty_nhwc(N, O, OH, OW, x)
+    if not full:
+        y.zero_()
+    for py, px, GH, GW, taps in classes:
+        if not taps:
+            continue
+        g = _geom(N, IH, IW, I, OH, OW, O, GH, GW, 1, s, py, px, taps, kh * kw, alpha)
+        check(lib.rick_conv_igemm_f32(ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), ctypes.byref(g),
+                                      stream_ptr()), 'rick_conv_igemm_f32')
+    return y
+
+
+def _wgrad_launch(a, b, kh, kw, s, p, alpha=1.0, ascale=None, bscale=None):
+    """gw[o,i,ky,kx] = alpha * sum a[n,o,pos] b[n,i,pos*s + k - p]  -> contiguous [O, I, kh, kw]."""
+    a, b = _nhwc(a), _nhwc(b)
+    N, O, AH, AW = a.shape
+    _, I, BH, BW = b.shape
+    gw = torch.empty((O, I, kh, kw), device=a.device, dtype=a.dtype)
+    taps = [(ky - p, kx - p, ky * kw + kx) for ky in range(kh) for kx in range(kw)]
+    if len(taps) > 9:
+        raise RuntimeError('wgrad: kernels larger than 3x3 are not supported')
+    g = _geom(N, BH, BW, I, AH, AW, O, AH, AW, s, 1, 0, 0, taps, kh * kw, alpha)
+    nbytes = lib.rick_conv_wgrad_workspace_bytes(ctypes.byref(g))
+    if nbytes < 0:
+        raise RuntimeError('rick_conv_wgrad_workspace_bytes: invalid geometry')
+    ws = torch.empty(max(nbytes, 16), device=a.device, dtype=torch.uint8)
+    check(lib.rick_conv_wgrad_f32(ptr(b), ptr(a), ptr(gw), I * kh * kw, kh * kw, 1, ptr(ascale), ptr(bscale),
+                                  ctypes.byref(g), 0, ptr(ws), stream_ptr()), 'rick_conv_wgrad_f32')
+    return gw
+
+
+# ------------------------------------------------------------------------ autograd primitives
+class _Conv(Function):
+    @staticmethod
+    def forward(ctx, x, w, s, p, wscale, key):
+        O, I, kh, kw = w.shape
+        if x.shape[1] != I:
+            raise RuntimeError(f'conv: input has {x.shape[1]} channels, weight expects {I}')
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (s, p, wscale, key)
+        return _conv_launch(x, _pack(w, wscale, key and (key[0], key[1] + '/conv')), O, kh, kw, s, p)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        s, p, wscale, key = ctx.cfg
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _ConvT.apply(g, w.transpose(0, 1), s, p, wscale, (x.shape[2], x.shape[3]),
+                              key and (key[0], key[1] + '/T'))
+        if ctx.needs_input_grad[1]:
+            gw = _WGrad.apply(g, x, w.shape[2], w.shape[3], s, p, wscale)
+        return gx, gw, None, None, None, None
+
+
+class _ConvT(Function):
+    @staticmethod
+    def forward(ctx, x, w, s, p, wscale, out_hw, key):
+        O, I, kh, kw = w.shape
+        if x.shape[1] != I:
+            raise RuntimeError(f'convT: input has {x.shape[1]} channels, weight expects {I}')
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (s, p, wscale, key)
+        return _convT_launch(x, _pack(w, wscale, key and (key[0], key[1] + '/convT')), O, kh, kw, s, p, out_hw)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        s, p, wscale, key = ctx.cfg
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _Conv.apply(g, w.transpose(0, 1), s, p, wscale, key and (key[0], key[1] + '/T'))
+        if ctx.needs_input_grad[1]:
+            # wgrad(a = x [I ch], b = g [O ch]) -> [I, O, kh, kw]; transpose back to w's [O, I, ..]
+            gw = _WGrad.apply(x, g, w.shape[2], w.shape[3], s, p, wscale).transpose(0, 1)
+        return gx, gw, None, None, None, None, None
+
+
+class _WGrad(Function):
+    @staticmethod
+    def forward(ctx, a, b, kh, kw, s, p, alpha):
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (kh, kw, s, p, alpha)
+        return _wgrad_launch(a, b, kh, kw, s, p, alpha)
+
+    @staticmethod
+    def backward(ctx, gg):
+        a, b = ctx.saved_tensors
+        kh, kw, s, p, alpha = ctx.cfg
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = _Conv.apply(b, gg, s, p, alpha, None)
+            if ga.shape[2:] != a.shape[2:]:
+                ga = ga[:, :, :a.shape[2], :a.shape[3]]
+        if ctx.needs_input_grad[1]:
+            gb = _ConvT.apply(a, gg.transpose(0, 1), s, p, alpha, (b.shape[2], b.shape[3]), None)
+        return ga, gb, None, None, None, None, None
+
+
+def conv2d(x, w, stride=1, padding=0, wscale=1.0, key=None):
+    """y = conv2d(x, w * wscale) (cross-correlation, like F.conv2d).  w: [O, I, kh, kw]."""
+    require_cuda_f32(x, w)
+    return _Conv.apply(x, w, int(stride), int(padding), float(wscale), key)
+
+
+def conv_transpose2d(x, w, stride=2, padding=0, wscale=1.0, key=None):
+    """y = F.conv_transpose2d(x, (w * wscale) given as [O, I, kh, kw]) — note torch stores the
+    transposed-conv weight as [I, O, kh, kw]; pass ``w_torch.transpose(0, 1)``."""
+    require_cuda_f32(x, w)
+    kh, kw = w.shape[2], w.shape[3]
+    oh = (x.shape[2] - 1) * stride - 2 * padding + kh
+    ow = (x.shape[3] - 1) * stride - 2 * padding + kw
+    return _ConvT.apply(x, w, int(stride), int(padding), float(wscale), (oh, ow), key)

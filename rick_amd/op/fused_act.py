@@ -1,0 +1,166 @@
+"""Fused bias + (noise) + LeakyReLU on MI355X — drop-in for the reference's
+``op.fused_leaky_relu`` / ``op.FusedLeakyReLU`` / ``op.FusedLeakyReLU_kml`` (op/fused_act.py:73-107).
+
+    y = scale * leaky_relu(x + bias[c] (+ noise_weight * noise), negative_slope)
+
+The gradient only needs the sign pattern of the OUTPUT (op/fused_act.py:22,28-30), so with
+m = (y > 0 ? 1 : slope) the whole derivative tower is two mutually adjoint linear maps
+    L (v, b, w) = scale * m * (v + b[c] + w * noise)       (rick_bias_act_f32, act=3, grad=1)
+    L*(g)       = (scale*m*g, sum_rows(.), sum(. * noise))  (rick_bias_act_bwd_f32, one pass,
+                                                             wavefront-shuffle reductions)
+and every order of autograd alternates between them.  The optional noise term fuses
+NoiseInjection (model_probe_tune.py:287-298) into the same pass; without it the op is exactly
+the reference's.  Tensors are processed channels-last as [rows, C].
+"""
+import math
+
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from .._lib import check, lib, ptr, require_cuda_f32, stream_ptr
+
+
+def _as_rows(x):
+    """-> (tensor in [rows, C] memory order, rows, C, hw)."""
+    if x.ndim == 2:
+        return x.contiguous(), x.shape[0], x.shape[1], 1
+    if x.ndim == 4:
+        xc = x.contiguous(memory_format=torch.channels_last)
+        hw = x.shape[2] * x.shape[3]
+        return xc, x.shape[0] * hw, x.shape[1], hw
+    raise RuntimeError(f'fused_leaky_relu: expected 2-D or 4-D input, got {x.ndim}-D')
+
+
+def _noise_args(noise, x):
+    if noise is None:
+        return None, 1, 1
+    if noise.ndim != 4 or noise.shape[1] != 1 or noise.shape[2:] != x.shape[2:] or noise.shape[0] not in (1, x.shape[0]):
+        raise RuntimeError(f'noise must be [N or 1, 1, H, W] matching input {tuple(x.shape)}, got {tuple(noise.shape)}')
+    return noise.contiguous(), noise.shape[0], noise.shape[2] * noise.shape[3]
+
+
+def _pointwise(x, bias, ref, grad_mode, slope, scale, noise, nw):
+    xr, rows, c, hw = _as_rows(x)
+    out = torch.empty_like(xr)
+    refr = None
+    if ref is not None:
+        refr, _, _, _ = _as_rows(ref)
+    nz, nb, nhw = _noise_args(noise, x) if noise is not None else (None, 1, 1)
+    check(lib.rick_bias_act_f32(ptr(xr), ptr(bias), ptr(refr), ptr(out), xr.numel(), 1, c, 3, grad_mode,
+                                slope, scale, ptr(nz), ptr(nw), hw * c, c, nb, nhw, stream_ptr()),
+          'rick_bias_act_f32')
+    return out
+
+
+class _ActAdjoint(Function):
+    """L*: g -> (gx, gb, gnw) given the saved output y (and noise)."""
+
+    @staticmethod
+    def forward(ctx, g, y, noise, slope, scale, want_b, want_w):
+        gr, rows, c, hw = _as_rows(g)
+        yr, _, _, _ = _as_rows(y)
+        gx = torch.empty_like(gr)
+        nz, nb, nhw = _noise_args(noise, g) if (noise is not None and want_w) else (None, 1, 1)
+        gb = torch.empty(c, device=g.device, dtype=g.dtype) if want_b else None
+        gw = torch.empty(1, device=g.device, dtype=g.dtype) if nz is not None else None
+        part = None
+        if want_b or nz is not None:
+            nblk = lib.rick_bias_act_bwd_blocks(rows, c)
+            part = torch.empty(nblk * (c + 1), device=g.device, dtype=g.dtype)
+        check(lib.rick_bias_act_bwd_f32(ptr(gr), ptr(yr), ptr(gx), ptr(gb), ptr(gw), ptr(nz), rows, c, hw, nb, nhw,
+                                        slope, scale, ptr(part), stream_ptr()), 'rick_bias_act_bwd_f32')
+        ctx.save_for_backward(y, noise)
+        ctx.cfg = (slope, scale)
+        if gb is None:
+            gb = g.new_zeros(c)
+        if gw is None:
+            gw = g.new_zeros(1)
+        return gx, gb, gw
+
+    @staticmethod
+    def backward(ctx, ggx, ggb, ggw):
+        y, noise = ctx.saved_tensors
+        slope, scale = ctx.cfg
+        out = _ActLinear.apply(ggx, ggb, ggw, y, noise, slope, scale)
+        return out, None, None, None, None, None, None
+
+
+class _ActLinear(Function):
+    """L: (v, b, w) -> scale * m(y) * (v + b[c] + w*noise)."""
+
+    @staticmethod
+    def forward(ctx, v, b, w, y, noise, slope, scale):
+        ctx.save_for_backward(y, noise)
+        ctx.cfg = (slope, scale)
+        ctx.need = (b is not None, w is not None and noise is not None)
+        nz = noise if (w is not None and noise is not None) else None
+        return _pointwise(v, b.contiguous() if b is not None else None, y, 1, slope, scale, nz,
+                          w.contiguous() if nz is not None else None)
+
+    @staticmethod
+    def backward(ctx, g):
+        y, noise = ctx.saved_tensors
+        slope, scale = ctx.cfg
+        gx, gb, gw = _ActAdjoint.apply(g, y, noise, slope, scale, ctx.need[0], ctx.need[1])
+        return gx, (gb if ctx.need[0] else None), (gw if ctx.need[1] else None), None, None, None, None
+
+
+class _Act(Function):
+    @staticmethod
+    def forward(ctx, x, bias, noise, nw, slope, scale):
+        y = _pointwise(x, bias.contiguous() if bias is not None else None, None, 0, slope, scale, noise,
+                       nw.contiguous() if noise is not None else None)
+        ctx.save_for_backward(y, noise)
+        ctx.cfg = (slope, scale)
+        ctx.need = (bias is not None, noise is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, noise = ctx.saved_tensors
+        slope, scale = ctx.cfg
+        gx, gb, gw = _ActAdjoint.apply(g, y, noise, slope, scale, ctx.need[0] and ctx.needs_input_grad[1],
+                                       ctx.need[1] and ctx.needs_input_grad[3])
+        return (gx, gb if ctx.need[0] else None, None, gw if ctx.need[1] else None, None, None)
+
+
+def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
+    """Reference signature (op/fused_act.py:106-107)."""
+    require_cuda_f32(input, bias)
+    return _Act.apply(input, bias, None, None, float(negative_slope), float(scale))
+
+
+def fused_noise_bias_act(input, bias, noise, noise_weight, negative_slope=0.2, scale=2 ** 0.5):
+    """activate(noise_injection(input)) of StyledConv (model_probe_tune.py:343-346) in one pass.
+    noise: [N or 1, 1, H, W]; noise_weight: Parameter[1]."""
+    require_cuda_f32(input, bias, noise, noise_weight)
+    return _Act.apply(input, bias, noise, noise_weight, float(negative_slope), float(scale))
+
+
+class FusedLeakyReLU(nn.Module):
+    """Same constructor and state (``bias``) as the reference module (op/fused_act.py:73-82)."""
+
+    def __init__(self, channel, negative_slope=0.2, scale=2 ** 0.5):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(channel))
+        self.negative_slope = negative_slope
+        self.scale = scale
+
+    def forward(self, input):
+        return fused_leaky_relu(input, self.bias, self.negative_slope, self.scale)
+
+
+class FusedLeakyReLU_kml(nn.Module):
+    """op/fused_act.py:85-103 (extra ``b_vector``; unused by the training script)."""
+
+    def __init__(self, channel, negative_slope=0.2, scale=2 ** 0.5):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(channel))
+        self.b_vector = nn.Parameter(torch.zeros(channel))
+        self.negative_slope = negative_slope
+        self.scale = scale
+
+    def forward(self, input):
+        bias = self.bias + self.b_vector if self.b_vector.requires_grad else self.bias
+        return fused_leaky_relu(input, bias, self.negative_slope, self.scale)

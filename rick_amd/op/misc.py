@@ -1,0 +1,252 @@
+"""HBM-bound helper ops of the hot path (rick_amd/csrc/elementwise.hip, thin.hip), each wired
+into autograd as a family closed under differentiation (needed by R1 / path-length terms).
+
+    chan_scale(x, s)   x[n,c,h,w] * s[n,c]           (style modulation / demodulation,
+    hw_dot(a, b)       sum_hw a*b -> [n,c]             model_probe_tune.py:246-251)
+    add_scale(a, b, k) (a + b) * k                    (ResBlock merge, model_probe_tune.py:658)
+    thin_fwd / thin_bwdx / thin_wgrad                 (3-channel 1x1 products: ToRGB :351-370,
+                                                       discriminator input conv :679)
+    minibatch_stddev                                  (model_probe_tune.py:748-756)
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .._lib import check, lib, ptr, require_cuda_f32, stream_ptr
+
+
+def _nhwc(x):
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+# ------------------------------------------------------------------ chan_scale / hw_dot
+def _chan_scale_raw(x, s):
+    x = _nhwc(x)
+    s = s.contiguous()
+    n, c, h, w = x.shape
+    if s.shape != (n, c):
+        raise RuntimeError(f'chan_scale: scale must be [{n},{c}], got {tuple(s.shape)}')
+    y = torch.empty_like(x)
+    check(lib.rick_chan_scale_f32(ptr(x), ptr(s), ptr(y), n, h * w, c, stream_ptr()), 'rick_chan_scale_f32')
+    return y
+
+
+def _hw_dot_raw(a, b):
+    a, b = _nhwc(a), _nhwc(b)
+    n, c, h, w = a.shape
+    d = torch.empty((n, c), device=a.device, dtype=a.dtype)
+    nb = lib.rick_hw_dot_blocks(h * w)
+    part = torch.empty(nb * n * c, device=a.device, dtype=a.dtype)
+    check(lib.rick_hw_dot_f32(ptr(a), ptr(b), ptr(d), n, h * w, c, ptr(part), stream_ptr()), 'rick_hw_dot_f32')
+    return d
+
+
+class _ChanScale(Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.save_for_backward(x, s)
+        return _chan_scale_raw(x, s)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        gx = _ChanScale.apply(g, s) if ctx.needs_input_grad[0] else None
+        gs = _HwDot.apply(g, x) if ctx.needs_input_grad[1] else None
+        return gx, gs
+
+
+class _HwDot(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return _hw_dot_raw(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = _ChanScale.apply(b, g) if ctx.needs_input_grad[0] else None
+        gb = _ChanScale.apply(a, g) if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
+def chan_scale(x, s):
+    require_cuda_f32(x, s)
+    return _ChanScale.apply(x, s)
+
+
+def hw_dot(a, b):
+    require_cuda_f32(a, b)
+    return _HwDot.apply(a, b)
+
+
+# --------------------------------------------------------------------------- add_scale
+class _AddScale(Function):
+    @staticmethod
+    def forward(ctx, a, b, k):
+        ctx.k = k
+        a = _nhwc(a) if a.ndim == 4 else a.contiguous()
+        if b is not None:
+            b = (_nhwc(b) if b.ndim == 4 else b.contiguous())
+            if b.shape != a.shape:
+                raise RuntimeError('add_scale: shape mismatch')
+        y = torch.empty_like(a)
+        check(lib.rick_add_scale_f32(ptr(a), ptr(b), ptr(y), a.numel(), k, stream_ptr()), 'rick_add_scale_f32')
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = _AddScale.apply(g, None, ctx.k)
+        return gs, (gs if ctx.needs_input_grad[1] else None), None
+
+
+def add_scale(a, b, k):
+    require_cuda_f32(a, b)
+    return _AddScale.apply(a, b, float(k))
+
+
+# ------------------------------------------------------------------------- thin products
+def _thin_shapes(x, J):
+    n, c, h, w = x.shape
+    if c % 4:
+        raise RuntimeError('thin ops need C % 4 == 0')
+    if not 1 <= J <= 4:
+        raise RuntimeError('thin ops support 1..4 thin channels')
+    return n, c, h, w
+
+
+def _wb(W, n):
+    """W: [N or 1, J, C] -> (contiguous tensor, batch stride)."""
+    W = W.contiguous()
+    if W.shape[0] not in (1, n):
+        raise RuntimeError('thin ops: W batch must be 1 or N')
+    return W, (0 if W.shape[0] == 1 else W.shape[1] * W.shape[2])
+
+
+class _ThinFwd(Function):
+    """t[n,j,h,w] = sum_c x[n,c,h,w] W[n,j,c]   (x channels-last, t planar)."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        x = _nhwc(x)
+        n, c, h, w = _thin_shapes(x, W.shape[1])
+        Wc, bs = _wb(W, n)
+        t = torch.empty((n, W.shape[1], h, w), device=x.device, dtype=x.dtype)
+        check(lib.rick_thin_fwd_f32(ptr(x), ptr(Wc), bs, None, ptr(t), n, h * w, c, W.shape[1], stream_ptr()),
+              'rick_thin_fwd_f32')
+        ctx.save_for_backward(x, W)
+        return t
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        gx = _ThinBwdX.apply(g, W) if ctx.needs_input_grad[0] else None
+        gW = None
+        if ctx.needs_input_grad[1]:
+            gW = _ThinWgrad.apply(g, x)
+            if W.shape[0] == 1:
+                gW = gW.sum(0, keepdim=True)
+        return gx, gW
+
+
+class _ThinBwdX(Function):
+    """x[n,c,h,w] = sum_j t[n,j,h,w] W[n,j,c]   (t planar, x channels-last)."""
+
+    @staticmethod
+    def forward(ctx, t, W):
+        t = t.contiguous()
+        n, J, h, w = t.shape
+        c = W.shape[2]
+        Wc, bs = _wb(W, n)
+        x = torch.empty((n, c, h, w), device=t.device, dtype=t.dtype, memory_format=torch.channels_last)
+        _thin_shapes(x, J)
+        check(lib.rick_thin_bwdx_f32(ptr(t), ptr(Wc), bs, ptr(x), n, h * w, c, J, stream_ptr()), 'rick_thin_bwdx_f32')
+        ctx.save_for_backward(t, W)
+        return x
+
+    @staticmethod
+    def backward(ctx, gg):
+        t, W = ctx.saved_tensors
+        gt = _ThinFwd.apply(gg, W) if ctx.needs_input_grad[0] else None
+        gW = None
+        if ctx.needs_input_grad[1]:
+            gW = _ThinWgrad.apply(t, gg)
+            if W.shape[0] == 1:
+                gW = gW.sum(0, keepdim=True)
+        return gt, gW
+
+
+class _ThinWgrad(Function):
+    """G[n,j,c] = sum_hw t[n,j,h,w] x[n,c,h,w]."""
+
+    @staticmethod
+    def forward(ctx, t, x):
+        t = t.contiguous()
+        x = _nhwc(x)
+        n, c, h, w = _thin_shapes(x, t.shape[1])
+        J = t.shape[1]
+        G = torch.empty((n, J, c), device=x.device, dtype=x.dtype)
+        nb = lib.rick_thin_wgrad_blocks(h * w)
+        part = torch.empty(nb * n * J * c, device=x.device, dtype=x.dtype)
+        check(lib.rick_thin_wgrad_f32(ptr(t), ptr(x), ptr(G), n, h * w, c, J, ptr(part), stream_ptr()),
+              'rick_thin_wgrad_f32')
+        ctx.save_for_backward(t, x)
+        return G
+
+    @staticmethod
+    def backward(ctx, gG):
+        t, x = ctx.saved_tensors
+        gt = _ThinFwd.apply(x, gG) if ctx.needs_input_grad[0] else None
+        gx = _ThinBwdX.apply(t, gG) if ctx.needs_input_grad[1] else None
+        return gt, gx
+
+
+def thin_fwd(x, W):
+    require_cuda_f32(x, W)
+    return _ThinFwd.apply(x, W)
+
+
+def thin_bwdx(t, W):
+    require_cuda_f32(t, W)
+    return _ThinBwdX.apply(t, W)
+
+
+# ------------------------------------------------------------------- minibatch stddev
+class _MbStd(Function):
+    """First-order HIP path (group == batch).  Second-order callers use the composite below."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _nhwc(x)
+        b, c, h, w = x.shape
+        out = torch.empty((b, c + 1, h, w), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+        stat = torch.empty(1, device=x.device, dtype=x.dtype)
+        check(lib.rick_mbstd_fwd_f32(ptr(x), ptr(out), ptr(stat), b, h * w, c, stream_ptr()), 'rick_mbstd_fwd_f32')
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _nhwc(g)
+        b, c, h, w = x.shape
+        gx = torch.empty_like(x)
+        check(lib.rick_mbstd_bwd_f32(ptr(x), ptr(g), ptr(gx), b, h * w, c, stream_ptr()), 'rick_mbstd_bwd_f32')
+        return gx
+
+
+def minibatch_stddev(x, stddev_group=25, stddev_feat=1, second_order=False):
+    """cat([x, stddev channel]) as in model_probe_tune.py:748-756.  The HIP kernel covers the
+    training configuration (group == batch <= 25, stddev_feat == 1); other group shapes and
+    double-differentiable calls (R1) use the same formula composed from device tensor ops on
+    this [B,512,4,4] tensor (8 K elements per sample)."""
+    require_cuda_f32(x)
+    b, c, h, w = x.shape
+    group = min(b, stddev_group)
+    if group == b and stddev_feat == 1 and not second_order:
+        return _MbStd.apply(x)
+    s = x.reshape(group, -1, stddev_feat, c // stddev_feat, h, w)
+    s = torch.sqrt(s.var(0, unbiased=False) + 1e-8)
+    s = s.mean([2, 3, 4], keepdim=True).squeeze(2)
+    s = s.repeat(group, 1, h, w)
+    return torch.cat([x, s], 1)

@@ -1,0 +1,87 @@
+"""Modulated convolution (StyleGAN2 weight modulation / demodulation,
+model_probe_tune.py:188-284) without per-sample weights.
+
+The reference builds W'[b,o,i,k] = scale*W[o,i,k]*s[b,i]*d[b,o] and runs a grouped conv with
+B groups.  Algebraically  y[b,o] = d[b,o] * sum_{i,k} scale*W[o,i,k] * (s[b,i] x[b,i]),
+with d = rsqrt(sum_{i,k} (scale*W*s)^2 + 1e-8) = rsqrt(s^2 @ Wsq^T + 1e-8): one shared-weight
+convolution over the whole batch (GEMM M = B*H*W) with the modulation folded into the operand
+load (iscale) and the demodulation into the epilogue (oscale) of the MFMA kernel.
+
+Two implementations with identical values:
+  * `modulated_conv_fused`   one kernel per direction, first-order backward only
+  * `modulated_conv_composed` chan_scale -> conv -> chan_scale from the closed primitive
+                              family, differentiable to any order (used under op.second_order()).
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .conv import _conv_launch, _convT_launch, _pack, _wgrad_launch, conv2d, conv_transpose2d
+from .misc import _chan_scale_raw, _hw_dot_raw, chan_scale
+
+
+def demod_coeff(w, s, wscale, eps=1e-8):
+    """d[b,o] = rsqrt(sum_{i,k} (wscale*w[o,i,k]*s[b,i])^2 + eps)  (model_probe_tune.py:250).
+    Small tensors ([O,I] and [B,I]); plain device tensor algebra, differentiable to any order."""
+    wsq = (w * wscale).pow(2).sum([2, 3])          # [O, I]
+    return torch.rsqrt(s.pow(2) @ wsq.t() + eps)   # [B, O]
+
+
+def modulated_conv_composed(x, w, s, d, wscale, upsample, key=None):
+    xs = chan_scale(x, s)
+    if upsample:
+        y = conv_transpose2d(xs, w, stride=2, padding=0, wscale=wscale, key=key)
+    else:
+        y = conv2d(xs, w, stride=1, padding=w.shape[2] // 2, wscale=wscale, key=key)
+    return chan_scale(y, d) if d is not None else y
+
+
+class _ModConvFused(Function):
+    @staticmethod
+    def forward(ctx, x, w, s, d, wscale, upsample, key):
+        O, I, kh, kw = w.shape
+        s = s.contiguous()
+        d = d.contiguous() if d is not None else None
+        wp = _pack(w, wscale, key and (key[0], key[1] + ('/convT' if upsample else '/conv')))
+        if upsample:
+            oh, ow = (x.shape[2] - 1) * 2 + kh, (x.shape[3] - 1) * 2 + kw
+            y = _convT_launch(x, wp, O, kh, kw, 2, 0, (oh, ow), iscale=s, oscale=d)
+        else:
+            y = _conv_launch(x, wp, O, kh, kw, 1, kh // 2, iscale=s, oscale=d)
+        ctx.save_for_backward(x, w, s, d, y)
+        ctx.cfg = (wscale, upsample, key)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, w, s, d, y = ctx.saved_tensors
+        wscale, upsample, key = ctx.cfg
+        O, I, kh, kw = w.shape
+        g = g.contiguous(memory_format=torch.channels_last)
+        gx = gs = gw = gd = None
+        wT = w.transpose(0, 1)
+        wpT = _pack(wT, wscale, key and (key[0], key[1] + '/T'))
+        # unscaled data gradient: gx' = W^T (g * d)
+        if upsample:
+            gxu = _conv_launch(g, wpT, I, kh, kw, 2, 0, iscale=d)
+        else:
+            gxu = _convT_launch(g, wpT, I, kh, kw, 1, kh // 2, (x.shape[2], x.shape[3]), iscale=d)
+        if ctx.needs_input_grad[2]:
+            gs = _hw_dot_raw(gxu, x)
+        if ctx.needs_input_grad[0]:
+            gx = _chan_scale_raw(gxu, s)
+        if ctx.needs_input_grad[1]:
+            if upsample:   # convT: gw[o,i,k] = sum x[pos,i] g[pos*2+k, o]  (a = x, b = g), transposed back
+                gw = _wgrad_launch(x, g, kh, kw, 2, 0, wscale, ascale=s, bscale=d).transpose(0, 1)
+            else:
+                gw = _wgrad_launch(g, x, kh, kw, 1, kh // 2, wscale, ascale=d, bscale=s)
+        if d is not None and ctx.needs_input_grad[3]:
+            gd = _hw_dot_raw(g, y) / d          # y = d * y'  ->  sum g*y' = (sum g*y) / d,  d > 0
+        return gx, gw, gs, gd, None, None, None
+
+
+def modulated_conv_fused(x, w, s, d, wscale, upsample, key=None):
+    return _ModConvFused.apply(x, w, s, d, float(wscale), bool(upsample), key)

@@ -1,0 +1,74 @@
+"""upfirdn2d on MI355X — drop-in for the reference's ``op.upfirdn2d``
+(op/upfirdn2d.py:145-156): ``upfirdn2d(input[N,C,H,W], kernel[kh,kw], up=1, down=1, pad=(p0,p1))``.
+
+The operator is linear in ``input`` and its adjoint is again an upfirdn2d (flipped FIR, up and
+down exchanged, the gradient pads of op/upfirdn2d.py:111-114), so ONE autograd node type,
+closed under differentiation, gives gradients of every order; the reference reaches the same
+result with a Function / Backward-Function pair (op/upfirdn2d.py:19-142).  Every launch is
+``rick_upfirdn2d_f32`` (rick_amd/csrc/upfirdn2d.hip).
+
+Layout: inputs with C % 64 == 0 (or C < 64 and C % 4 == 0) run channels-last through the NHWC
+kernel (major = N, minor = C); anything else (e.g. the 3-channel RGB skip) runs planar
+(major = N*C, minor = 1).  The result is returned in the layout that ran.
+"""
+import torch
+from torch.autograd import Function
+
+from .._lib import check, lib, ptr, require_cuda_f32, stream_ptr
+
+
+def _fir(x, taps, up_xy, down_xy, pad4):
+    """One kernel launch.  pad4 = (x0, x1, y0, y1).  Output extent per axis:
+    (in*up + pad0 + pad1 - k)//down + 1 (op/upfirdn2d.py:103-104)."""
+    n, c, h, w = x.shape
+    kh, kw = taps.shape
+    oh = (h * up_xy[1] + pad4[2] + pad4[3] - kh) // down_xy[1] + 1
+    ow = (w * up_xy[0] + pad4[0] + pad4[1] - kw) // down_xy[0] + 1
+    if oh <= 0 or ow <= 0:
+        raise RuntimeError(f'upfirdn2d: empty output ({oh}x{ow})')
+    if c % 64 == 0 or (c < 64 and c % 4 == 0):
+        x = x.contiguous(memory_format=torch.channels_last)
+        y = torch.empty((n, c, oh, ow), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+        major, minor = n, c
+    else:
+        x = x.contiguous()
+        y = torch.empty((n, c, oh, ow), device=x.device, dtype=x.dtype)
+        major, minor = n * c, 1
+    check(lib.rick_upfirdn2d_f32(ptr(x), ptr(taps), ptr(y), major, h, w, minor, kh, kw,
+                                 up_xy[0], up_xy[1], down_xy[0], down_xy[1],
+                                 pad4[0], pad4[1], pad4[2], pad4[3], stream_ptr()),
+          'rick_upfirdn2d_f32')
+    return y
+
+
+class _UpFirDn(Function):
+    """y = upfirdn2d(x; taps, up, down, pad).  backward(g) = _UpFirDn(g; flip(taps), down, up, adj_pad)."""
+
+    @staticmethod
+    def forward(ctx, x, taps, up_xy, down_xy, pad4):
+        y = _fir(x, taps, up_xy, down_xy, pad4)
+        kh, kw = taps.shape
+        h, w = x.shape[2], x.shape[3]
+        oh, ow = y.shape[2], y.shape[3]
+        # pads of the adjoint operator (same expressions as op/upfirdn2d.py:111-114)
+        adj = (kw - pad4[0] - 1, w * up_xy[0] - ow * down_xy[0] + pad4[0] - up_xy[0] + 1,
+               kh - pad4[2] - 1, h * up_xy[1] - oh * down_xy[1] + pad4[2] - up_xy[1] + 1)
+        ctx.save_for_backward(taps)
+        ctx.adjoint = (down_xy, up_xy, adj)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (taps,) = ctx.saved_tensors
+        a_up, a_down, a_pad = ctx.adjoint
+        gx = _UpFirDn.apply(g, torch.flip(taps, [0, 1]).contiguous(), a_up, a_down, a_pad)
+        return gx, None, None, None, None
+
+
+def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
+    """Same signature and semantics as the reference op (op/upfirdn2d.py:145-156): one
+    up / down / pad pair for both axes.  CPU tensors raise (there is no native fallback)."""
+    require_cuda_f32(input, kernel)
+    if input.ndim != 4 or kernel.ndim != 2:
+        raise RuntimeError('upfirdn2d expects input [N,C,H,W] and kernel [kh,kw]')
+    return _UpFirDn.apply(input, kernel.contiguous(), (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))

@@ -1,0 +1,341 @@
+"""GPU parity tests of the HIP ops (through the C ABI) against the CPU oracle and the
+reference-derived golden vectors.  Run with `-m gpu` on an MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from rick_amd.synth import synth_state_dict, synth_tensor
+from tests.cases import UPFIRDN_CASES, upfirdn_kernel
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+# ---------------------------------------------------------------------------- upfirdn2d
+@pytest.mark.parametrize('case', UPFIRDN_CASES, ids=[c[0] for c in UPFIRDN_CASES])
+def test_upfirdn2d_planar_bitexact(case, golden):
+    """Planar path vs the scalar C oracle: bit-exact (same index math, same fmaf order)."""
+    from oracle import c_ref
+    from rick_amd.op import upfirdn2d
+    tag, up, down, p0, p1, n, c, h, w, ks = case
+    g = golden('ops')
+    k = upfirdn_kernel(ks, up)
+    x = synth_tensor(f'upfirdn/{tag}/x', (n, c, h, w))
+    xd = x.to(DEV).requires_grad_(True)
+    y = upfirdn2d(xd, k.to(DEV), up=up, down=down, pad=(p0, p1))
+    yc = c_ref.upfirdn2d_c(x.numpy(), k.numpy(), (up, up), (down, down), (p0, p1, p0, p1))
+    assert np.array_equal(y.detach().cpu().numpy(), yc), 'forward not bit-exact vs C oracle'
+    assert rel_err(y, g[f'{tag}/y']) < 2e-6
+    gy = synth_tensor(f'upfirdn/{tag}/gy', y.shape).to(DEV).requires_grad_(True)
+    (gx,) = torch.autograd.grad(y, xd, gy, create_graph=True)
+    assert rel_err(gx, g[f'{tag}/gx']) < 2e-6
+    ggx = synth_tensor(f'upfirdn/{tag}/ggx', x.shape).to(DEV)
+    (ggy,) = torch.autograd.grad(gx, gy, ggx)
+    assert rel_err(ggy, g[f'{tag}/ggy']) < 2e-6
+
+
+@pytest.mark.parametrize('cfg', [(1, 1, 1, 1, 2, 64, 17, 17), (1, 1, 2, 2, 2, 128, 16, 16), (1, 1, 1, 1, 1, 8, 9, 12),
+                                 (1, 2, 1, 1, 2, 64, 16, 16), (2, 1, 2, 1, 1, 16, 8, 8), (1, 1, 1, 1, 3, 512, 9, 9),
+                                 (1, 1, 2, 2, 1, 128, 256, 256)])
+def test_upfirdn2d_nhwc_bitexact(cfg):
+    from oracle import c_ref
+    from rick_amd.op import upfirdn2d
+    up, down, p0, p1, n, c, h, w = cfg
+    k = upfirdn_kernel(4, up)
+    x = synth_tensor(f'ufd_nhwc/{cfg}', (n, c, h, w))
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = upfirdn2d(xd, k.to(DEV), up=up, down=down, pad=(p0, p1))
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    yc = c_ref.upfirdn2d_c(x.numpy(), k.numpy(), (up, up), (down, down), (p0, p1, p0, p1))
+    assert np.array_equal(y.detach().cpu().numpy(), yc)
+    gy = synth_tensor(f'ufd_nhwc/gy/{cfg}', y.shape)
+    (gx,) = torch.autograd.grad(y, xd, gy.to(DEV))
+    from oracle.ops_ref import upfirdn2d_ref
+    xr = x.double().requires_grad_(True)
+    (gxr,) = torch.autograd.grad(upfirdn2d_ref(xr, k.double(), up, down, (p0, p1)), xr, gy.double())
+    assert rel_err(gx, gxr) < 2e-6
+
+
+def test_upfirdn2d_rejects_cpu():
+    from rick_amd.op import upfirdn2d
+    with pytest.raises(RuntimeError):
+        upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(4, 4) / 16)
+
+
+# ------------------------------------------------------------------------- fused act
+@pytest.mark.parametrize('tag,shape', [('act2d', (3, 8)), ('act4d', (2, 5, 6, 6))])
+def test_fused_leaky_relu_golden(tag, shape, golden):
+    from rick_amd.op import fused_leaky_relu
+    g = golden('ops')
+    x = synth_tensor(f'act/{tag}/x', shape).to(DEV).requires_grad_(True)
+    b = synth_tensor(f'act/{tag}/b', (shape[1],)).to(DEV).requires_grad_(True)
+    y = fused_leaky_relu(x, b)
+    assert rel_err(y, g[f'{tag}/y']) < 1e-6
+    gy = synth_tensor(f'act/{tag}/gy', shape).to(DEV).requires_grad_(True)
+    gx, gb = torch.autograd.grad(y, (x, b), gy, create_graph=True)
+    assert rel_err(gx, g[f'{tag}/gx']) < 1e-6
+    assert rel_err(gb, g[f'{tag}/gb']) < 1e-5
+    ggx = synth_tensor(f'act/{tag}/ggx', shape).to(DEV)
+    ggb = synth_tensor(f'act/{tag}/ggb', (shape[1],)).to(DEV)
+    (ggy,) = torch.autograd.grad((gx, gb), gy, (ggx, ggb))
+    assert rel_err(ggy, g[f'{tag}/ggy']) < 1e-6
+
+
+@pytest.mark.parametrize('shape,nb', [((2, 64, 8, 8), 1), ((3, 128, 16, 16), 3), ((2, 512, 4, 4), 1), ((4, 12, 5, 5), 4)])
+def test_noise_bias_act_vs_oracle(shape, nb):
+    from oracle.ops_ref import fused_leaky_relu_ref
+    from rick_amd.op import fused_noise_bias_act
+    x = synth_tensor(f'nba/x/{shape}', shape)
+    b = synth_tensor(f'nba/b/{shape}', (shape[1],))
+    nz = synth_tensor(f'nba/n/{shape}', (nb, 1, shape[2], shape[3]))
+    nw = synth_tensor(f'nba/w/{shape}', (1,))
+    gy = synth_tensor(f'nba/gy/{shape}', shape)
+    ref_in = [t.double().requires_grad_(True) for t in (x, b, nw)]
+    yr = fused_leaky_relu_ref(ref_in[0] + ref_in[2] * nz.double(), ref_in[1])
+    gr = torch.autograd.grad(yr, ref_in, gy.double(), create_graph=True)
+    pl = sum((t ** 2).sum() for t in gr)
+    ggr = torch.autograd.grad(pl, ref_in[0])
+    dev_in = [t.to(DEV).requires_grad_(True) for t in (x, b, nw)]
+    y = fused_noise_bias_act(dev_in[0], dev_in[1], nz.to(DEV), dev_in[2])
+    assert rel_err(y, yr) < 1e-6
+    gd = torch.autograd.grad(y, dev_in, gy.to(DEV), create_graph=True)
+    for a, r in zip(gd, gr):
+        assert rel_err(a, r) < 2e-5
+    pld = sum((t ** 2).sum() for t in gd)
+    (ggd,) = torch.autograd.grad(pld, dev_in[0])
+    assert rel_err(ggd, ggr[0]) < 2e-5
+
+
+# ------------------------------------------------------------------------------ conv
+CONV_CASES = [
+    # tag, N, Ci, Co, H, W, k, stride, pad
+    ('s1_small', 2, 32, 128, 8, 8, 3, 1, 1),
+    ('s1_odd_ch', 3, 16, 24, 8, 8, 3, 1, 1),
+    ('s1_16', 2, 64, 64, 16, 16, 3, 1, 1),
+    ('s1_rect', 1, 32, 32, 12, 20, 3, 1, 1),
+    ('s1_4x4', 4, 64, 128, 4, 4, 3, 1, 1),
+    ('s1_513', 2, 513, 128, 4, 4, 3, 1, 1),
+    ('s1_big', 1, 128, 128, 64, 64, 3, 1, 1),
+    ('s2_blur', 2, 32, 64, 17, 17, 3, 2, 0),
+    ('s2_33', 1, 64, 128, 33, 33, 3, 2, 0),
+    ('k1_s2', 2, 64, 32, 15, 15, 1, 2, 0),
+    ('k1_s1', 2, 32, 64, 8, 8, 1, 1, 0),
+    ('co256', 1, 32, 256, 8, 8, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_vs_fp64(case):
+    """conv, its data/weight gradients and one second-order term vs torch CPU fp64.
+    bf16x3 split: fp32-grade, tolerance 2e-5 relative to the output max."""
+    from rick_amd import op
+    tag, N, Ci, Co, H, W, k, s, p = case
+    x = synth_tensor(f'conv/{tag}/x', (N, Ci, H, W))
+    w = synth_tensor(f'conv/{tag}/w', (Co, Ci, k, k))
+    wscale = 1 / math.sqrt(Ci * k * k)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr * wscale, stride=s, padding=p)
+    gy = synth_tensor(f'conv/{tag}/gy', yr.shape)
+    gxr, gwr = torch.autograd.grad(yr, (xr, wr), gy.double(), create_graph=True)
+    plr = gxr.pow(2).sum() + gwr.pow(2).sum()
+    ggr = torch.autograd.grad(plr, (xr, wr))
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = op.conv2d(xd, wd, s, p, wscale=wscale)
+    assert y.shape == yr.shape
+    assert rel_err(y, yr) < 2e-5, 'fprop'
+    gx, gw = torch.autograd.grad(y, (xd, wd), gy.to(DEV), create_graph=True)
+    assert rel_err(gx, gxr) < 2e-5, 'dgrad'
+    assert rel_err(gw, gwr) < 2e-5, 'wgrad'
+    pl = gx.pow(2).sum() + gw.pow(2).sum()
+    gg = torch.autograd.grad(pl, (xd, wd))
+    assert rel_err(gg[0], ggr[0]) < 5e-5, 'second-order d/dx'
+    assert rel_err(gg[1], ggr[1]) < 5e-5, 'second-order d/dw'
+
+
+@pytest.mark.parametrize('case', [('t_4', 2, 32, 64, 4, 4), ('t_8', 3, 64, 32, 8, 8), ('t_16', 1, 128, 128, 16, 16),
+                                  ('t_5', 2, 16, 24, 5, 7)], ids=lambda c: c[0])
+def test_conv_transpose2d_vs_fp64(case):
+    from rick_amd import op
+    tag, N, Ci, Co, H, W = case
+    x = synth_tensor(f'convT/{tag}/x', (N, Ci, H, W))
+    w = synth_tensor(f'convT/{tag}/w', (Co, Ci, 3, 3))
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr.transpose(0, 1) * 0.1, stride=2, padding=0)
+    gy = synth_tensor(f'convT/{tag}/gy', yr.shape)
+    gxr, gwr = torch.autograd.grad(yr, (xr, wr), gy.double(), create_graph=True)
+    ggr = torch.autograd.grad(gxr.pow(2).sum() + gwr.pow(2).sum(), (xr, wr))
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = op.conv_transpose2d(xd, wd, 2, 0, wscale=0.1)
+    assert y.shape == yr.shape
+    assert rel_err(y, yr) < 2e-5
+    gx, gw = torch.autograd.grad(y, (xd, wd), gy.to(DEV), create_graph=True)
+    assert rel_err(gx, gxr) < 2e-5
+    assert rel_err(gw, gwr) < 2e-5
+    gg = torch.autograd.grad(gx.pow(2).sum() + gw.pow(2).sum(), (xd, wd))
+    assert rel_err(gg[0], ggr[0]) < 5e-5
+    assert rel_err(gg[1], ggr[1]) < 5e-5
+
+
+def test_conv_bf16_single_pass_is_coarser():
+    """split=1 (plain bf16 MFMA) is a speed option, not the parity path: ~1e-3..1e-2 error."""
+    from rick_amd import op
+    x = synth_tensor('convp/x', (2, 64, 16, 16))
+    w = synth_tensor('convp/w', (64, 64, 3, 3))
+    yr = F.conv2d(x.double(), w.double() / 24, padding=1)
+    op.set_precision('bf16')
+    try:
+        y1 = op.conv2d(x.to(DEV), w.to(DEV), 1, 1, wscale=1 / 24)
+    finally:
+        op.set_precision('bf16x3')
+    y3 = op.conv2d(x.to(DEV), w.to(DEV), 1, 1, wscale=1 / 24)
+    e1, e3 = rel_err(y1, yr), rel_err(y3, yr)
+    assert e3 < 2e-5 < e1 < 3e-2
+
+
+# --------------------------------------------------------------------------- mod conv
+@pytest.mark.parametrize('tag', ['plain', 'up', 'rgb'])
+@pytest.mark.parametrize('mode', ['fused', 'second_order'])
+def test_modulated_conv_golden(tag, mode, golden):
+    """ModulatedConv2d module vs the reference module's outputs (tests/golden/layers.npz)."""
+    from rick_amd import op
+    from rick_amd.models import ModulatedConv2d
+    g = golden('layers')
+    B, CI, CO, R, SD = 3, 16, 24, 8, 32
+    co = 3 if tag == 'rgb' else CO
+    kw = dict(kernel_size=1, demodulate=False) if tag == 'rgb' else dict(kernel_size=3, upsample=(tag == 'up'))
+    m = ModulatedConv2d(CI, co, style_dim=SD, **kw)
+    sd = synth_state_dict({k: v.shape for k, v in m.state_dict().items()})
+    m.load_state_dict(sd, strict=False)
+    m = m.to(DEV)
+    x = synth_tensor(f'modconv/{tag}/x', (B, CI, R, R)).to(DEV).requires_grad_(True)
+    s = synth_tensor(f'modconv/{tag}/s', (B, SD)).to(DEV).requires_grad_(True)
+    gy = synth_tensor(f'modconv/{tag}/gy', g[f'{tag}/y'].shape).to(DEV)
+    params = [m.weight, m.modulation.weight, m.modulation.bias]
+    with op.second_order(mode == 'second_order'):
+        y = m(x, s)
+        assert rel_err(y, g[f'{tag}/y']) < 3e-5
+        grads = torch.autograd.grad(y, [x, s] + params, gy, create_graph=(mode == 'second_order'))
+        for n, gr in zip(('gx', 'gs', 'gw', 'gmw', 'gmb'), grads):
+            assert rel_err(gr, g[f'{tag}/{n}']) < 5e-5, n
+        if mode == 'second_order':
+            pl = grads[1].pow(2).sum()
+            assert rel_err(pl, g[f'{tag}/pl']) < 1e-4
+            gg = torch.autograd.grad(pl, [x, m.weight, s], allow_unused=True)
+            for n, gr, t in zip(('pl_gx', 'pl_gw', 'pl_gs'), gg, (x, m.weight, s)):
+                gr = torch.zeros_like(t) if gr is None else gr
+                ref = g[f'{tag}/{n}']
+                if np.abs(ref).max() == 0:
+                    assert float(gr.abs().max()) < 1e-6
+                else:
+                    assert rel_err(gr, ref) < 2e-4, n
+
+
+# ------------------------------------------------------------------------ small ops
+def test_thin_ops_vs_einsum():
+    from rick_amd import op
+    N, C, H, W, J = 3, 64, 9, 7, 3
+    x = synth_tensor('thin/x', (N, C, H, W))
+    Wm = synth_tensor('thin/W', (N, J, C))
+    t = synth_tensor('thin/t', (N, J, H, W))
+    xd, Wd, td = (a.to(DEV).requires_grad_(True) for a in (x, Wm, t))
+    y = op.thin_fwd(xd, Wd)
+    yr = torch.einsum('nchw,njc->njhw', x.double(), Wm.double())
+    assert rel_err(y, yr) < 1e-5
+    gx, gW = torch.autograd.grad(y, (xd, Wd), td, create_graph=True)
+    assert rel_err(gx, torch.einsum('njhw,njc->nchw', t.double(), Wm.double())) < 1e-5
+    assert rel_err(gW, torch.einsum('njhw,nchw->njc', t.double(), x.double())) < 1e-5
+    (ggt,) = torch.autograd.grad(gx.pow(2).sum(), td)
+    gxr = torch.einsum('njhw,njc->nchw', t.double(), Wm.double())
+    assert rel_err(ggt, 2 * torch.einsum('nchw,njc->njhw', gxr, Wm.double())) < 2e-5
+    # shared W (batch 1): discriminator input conv
+    W1 = synth_tensor('thin/W1', (1, J, C)).to(DEV).requires_grad_(True)
+    z = op.thin_bwdx(td, W1)
+    assert rel_err(z, torch.einsum('njhw,jc->nchw', t.double(), W1[0].double().cpu())) < 1e-5
+    (gW1,) = torch.autograd.grad(z, W1, xd.detach())
+    assert rel_err(gW1[0], torch.einsum('njhw,nchw->jc', t.double(), x.double())) < 1e-5
+
+
+def test_chan_scale_hw_dot_add_scale():
+    from rick_amd import op
+    x = synth_tensor('cs/x', (3, 64, 5, 7))
+    s = synth_tensor('cs/s', (3, 64))
+    xd, sd = x.to(DEV).requires_grad_(True), s.to(DEV).requires_grad_(True)
+    y = op.chan_scale(xd, sd)
+    assert rel_err(y, x * s[:, :, None, None]) < 1e-6
+    g = synth_tensor('cs/g', x.shape).to(DEV)
+    gx, gs = torch.autograd.grad(y, (xd, sd), g, create_graph=True)
+    assert rel_err(gs, (g.cpu() * x).sum((2, 3))) < 1e-5
+    (gg,) = torch.autograd.grad(gs.pow(2).sum(), xd)
+    assert rel_err(gg, 2 * (g.cpu() * x).sum((2, 3))[:, :, None, None] * g.cpu()) < 1e-5
+    a, b = synth_tensor('as/a', (2, 32, 6, 6)), synth_tensor('as/b', (2, 32, 6, 6))
+    z = op.add_scale(a.to(DEV), b.to(DEV), 0.7071)
+    assert rel_err(z, (a + b) * 0.7071) < 1e-6
+
+
+@pytest.mark.parametrize('B', [1, 2, 4])
+def test_minibatch_stddev(B):
+    from oracle.ops_ref import minibatch_stddev_ref
+    from rick_amd import op
+    x = synth_tensor(f'mbstd/{B}', (B, 512, 4, 4))
+    xr = x.double().requires_grad_(True)
+    yr = minibatch_stddev_ref(xr)
+    g = synth_tensor(f'mbstd/g/{B}', yr.shape)
+    (gr,) = torch.autograd.grad(yr, xr, g.double())
+    for so in (False, True):
+        xd = x.to(DEV).requires_grad_(True)
+        y = op.minibatch_stddev(xd, second_order=so)
+        assert rel_err(y, yr) < 1e-5
+        (gd,) = torch.autograd.grad(y, xd, g.to(DEV))
+        assert rel_err(gd, gr) < 1e-4 if B > 1 else True
+
+
+def test_fisher_and_optimizer_kernels():
+    from oracle.train_ref import adam_step_ref
+    from rick_amd import _lib
+    lib, ptr, sp = _lib.lib, _lib.ptr, _lib.stream_ptr
+    n = 100003
+    g = synth_tensor('opt/g', (n,))
+    acc = synth_tensor('opt/acc', (n,)).abs()
+    accd, gd = acc.to(DEV), g.to(DEV)
+    _lib.check(lib.rick_sq_accumulate_f32(ptr(accd), ptr(gd), n, sp()), 'sq')
+    assert rel_err(accd, acc.double() + g.double() ** 2) < 1e-6
+    # per-filter mean of a [1, Co, Ci, 3, 3] tensor over (0,2,3,4)  (train_dynamic_update_prune.py:282)
+    f = synth_tensor('opt/f', (1, 24, 16, 3, 3)).abs()
+    fd, out = f.to(DEV), torch.empty(24, device=DEV)
+    _lib.check(lib.rick_filter_reduce_f32(ptr(fd), ptr(out), 1, 0, 24, 16 * 9, 16 * 9, 1.0 / (16 * 9), sp()), 'fr')
+    assert rel_err(out, f.double().mean((0, 2, 3, 4))) < 1e-6
+    # modulation weight [Ci, style] mean over dim 1
+    f2 = synth_tensor('opt/f2', (16, 512)).abs()
+    out2 = torch.empty(16, device=DEV)
+    _lib.check(lib.rick_filter_reduce_f32(ptr(f2.to(DEV)), ptr(out2), 1, 0, 16, 512, 512, 1.0 / 512, sp()), 'fr2')
+    assert rel_err(out2, f2.double().mean(1)) < 1e-6
+    # masked Adam, 3 steps, beta1 = 0 as configured by the reference (train...:913-931)
+    p = synth_tensor('opt/p', (n,))
+    mask = (torch.arange(n) % 7 == 0).to(torch.uint8) + 2 * (torch.arange(n) % 11 == 0).to(torch.uint8)
+    pd, md, vd, maskd = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), mask.to(DEV)
+    pr, mr, vr = p.double(), torch.zeros(n).double(), torch.zeros(n).double()
+    lr, b1, b2 = 0.002 * 0.8, 0.0, 0.99 ** 0.8
+    for step in range(1, 4):
+        gs = synth_tensor(f'opt/g{step}', (n,))
+        gdd = gs.to(DEV)
+        _lib.check(lib.rick_masked_adam_f32(ptr(pd), ptr(gdd), ptr(md), ptr(vd), ptr(maskd), n, lr, b1, b2, 1e-8,
+                                            1 - b1 ** step, 1 - b2 ** step, sp()), 'adam')
+        gm = gs.double().clone()
+        gm[mask > 0] = 0
+        pr[(mask & 2) > 0] = 0
+        pr, mr, vr = adam_step_ref(pr, gm, mr, vr, step, lr, b1, b2)
+    assert rel_err(pd, pr) < 1e-5
+    e = synth_tensor('opt/e', (n,))
+    ed = e.to(DEV)
+    _lib.check(lib.rick_ema_f32(ptr(ed), ptr(pd), n, 0.997784, sp()), 'ema')
+    assert rel_err(ed, e.double() * 0.997784 + pd.double().cpu() * (1 - 0.997784)) < 1e-6
