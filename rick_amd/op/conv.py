@@ -18,7 +18,6 @@ two dims are jointly contiguous.  `precision()` selects bf16x3 (default, fp32-gr
 plain bf16 MFMA.
 """
 import ctypes
-import weakref
 
 import torch
 from torch.autograd import Function
@@ -27,7 +26,6 @@ from .._lib import MAX_TAPS, ConvGeom, check, lib, ptr, require_cuda_f32, stream
 
 _SPLIT = 2          # 2: bf16 hi/lo split, 3 MFMAs per product (fp32-grade); 1: plain bf16
 _weights_epoch = 0  # bumped by optimisers that update parameters through raw pointers
-_pack_cache = weakref.WeakKeyDictionary()
 
 
 def set_precision(name):
@@ -70,7 +68,7 @@ def _pack(w, scale, key=None):
     enables caching across calls until the parameter changes."""
     O, I, kh, kw = w.shape
     if key is not None:
-        ent = _pack_cache.get(key[0])
+        ent = getattr(key[0], '_rick_packed', None)
         sig = (key[1], key[0]._version, _weights_epoch, _SPLIT, float(scale), tuple(w.shape), w.stride(), w.data_ptr())
         if ent is not None and sig in ent:
             return ent[sig]
@@ -80,7 +78,9 @@ def _pack(w, scale, key=None):
     check(lib.rick_conv_pack_weight(ptr(w), s_o, s_i, s_t, O, I, kh * kw, float(scale), ptr(buf), stream_ptr()),
           'rick_conv_pack_weight')
     if key is not None:
-        ent = _pack_cache.setdefault(key[0], {})
+        if ent is None:
+            ent = {}
+            key[0]._rick_packed = ent      # lives and dies with the parameter object
         # keep only entries of the current parameter version
         for k in [k for k in ent if k[1] != sig[1] or k[2] != sig[2]]:
             del ent[k]

@@ -1,0 +1,470 @@
+"""Host side of the RICK adaptation loop on the MI355X engine: losses and gradient penalties,
+the Fisher-information sweep with on-device grad^2 accumulation and per-filter reduction, the
+freeze / fine-tune / prune decisions and masks, the masked flat Adam + EMA, and the per-iteration
+control flow of ``train()`` (train_dynamic_update_prune.py:159-699).
+
+Work the reference performs and then discards is skipped (SURVEY.md §8a footnote): the D step
+runs on ``fake.detach()``, the G step does not compute D weight gradients, and parameters that
+no optimiser owns do not get gradients.  Results are unchanged.
+"""
+import math
+import random
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import autograd
+
+from . import op
+from ._lib import check, lib, ptr, stream_ptr
+
+
+# --------------------------------------------------------------------------- losses
+def d_logistic_loss(real_pred, fake_pred):
+    """train_dynamic_update_prune.py:82-86"""
+    return F.softplus(-real_pred).mean() + F.softplus(fake_pred).mean()
+
+
+def g_nonsaturating_loss(fake_pred):
+    """train_dynamic_update_prune.py:99-101"""
+    return F.softplus(-fake_pred).mean()
+
+
+def d_r1_loss(real_pred, real_img):
+    """train_dynamic_update_prune.py:89-96 (needs op.second_order())."""
+    (grad_real,) = autograd.grad(outputs=real_pred.sum(), inputs=real_img, create_graph=True)
+    return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
+
+
+def g_path_regularize(fake_img, latents, mean_path_length, decay=0.01, noise=None):
+    """train_dynamic_update_prune.py:104-118 (needs op.second_order()).  `noise` overrides the
+    randn_like draw so parity tests can share it with the oracle."""
+    if noise is None:
+        noise = torch.randn_like(fake_img)
+    noise = noise / math.sqrt(fake_img.shape[2] * fake_img.shape[3])
+    (grad,) = autograd.grad(outputs=(fake_img * noise).sum(), inputs=latents, create_graph=True)
+    path_lengths = torch.sqrt(grad.pow(2).sum(2).mean(1))
+    path_mean = mean_path_length + decay * (path_lengths.mean() - mean_path_length)
+    path_penalty = (path_lengths - path_mean).pow(2).mean()
+    return path_penalty, path_mean.detach(), path_lengths
+
+
+def make_noise(batch, latent_dim, n_noise, device):
+    if n_noise == 1:
+        return torch.randn(batch, latent_dim, device=device)
+    return torch.randn(n_noise, batch, latent_dim, device=device).unbind(0)
+
+
+def mixing_noise(batch, latent_dim, prob, device):
+    """train_dynamic_update_prune.py:130-135"""
+    if prob > 0 and random.random() < prob:
+        return make_noise(batch, latent_dim, 2, device)
+    return [make_noise(batch, latent_dim, 1, device)]
+
+
+def requires_grad(model, flag=True, only=None):
+    for name, p in model.named_parameters():
+        if only is None or only(name):
+            p.requires_grad = flag
+
+
+# ------------------------------------------------------------------ flat params / Adam / EMA
+class FlatParams:
+    """Re-homes a list of parameters into ONE flat fp32 buffer (each parameter becomes a view)
+    with a matching flat gradient buffer (``p.grad`` are views too).  One kernel then covers the
+    mask + Adam update of a whole network, one memset zeroes the gradients and one RCCL
+    all-reduce (optionally in buckets) averages them."""
+
+    def __init__(self, named_params):
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        sizes = [p.numel() for p in self.params]
+        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        self.total = int(self.offsets[-1])
+        dev = self.params[0].device
+        self.flat = torch.empty(self.total, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(self.total, device=dev, dtype=torch.float32)
+        for p, o, n in zip(self.params, self.offsets, sizes):
+            self.flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + n].view(p.shape)
+            p.grad = self.grad[o:o + n].view(p.shape)
+        self.index = {n: i for i, n in enumerate(self.names)}
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def segment(self, name):
+        i = self.index[name]
+        return int(self.offsets[i]), int(self.offsets[i + 1])
+
+
+class MaskedFlatAdam:
+    """torch.optim.Adam(lr, betas, eps=1e-8) over a FlatParams, with RICK's freeze / prune masks
+    applied in the same kernel (train_dynamic_update_prune.py:427-438, 522-540).  Parameters
+    whose ``requires_grad`` is False at step time are skipped exactly like torch skips
+    ``grad is None`` (per-parameter step counts, used by the warm-up stage :202-211)."""
+
+    def __init__(self, flat, lr, betas, eps=1e-8):
+        self.fp, self.lr, self.betas, self.eps = flat, lr, betas, eps
+        self.m = torch.zeros_like(flat.flat)
+        self.v = torch.zeros_like(flat.flat)
+        self.steps = [0] * len(flat.params)
+        self.mask = None            # uint8 flat: bit0 freeze, bit1 prune
+
+    def set_mask(self, mask):
+        self.mask = mask
+
+    def step(self):
+        fp = self.fp
+        active = [p.requires_grad for p in fp.params]
+        i, n = 0, len(fp.params)
+        while i < n:
+            if not active[i]:
+                i += 1
+                continue
+            j = i
+            self.steps[i] += 1
+            while j + 1 < n and active[j + 1] and self.steps[j + 1] + 1 == self.steps[i]:
+                j += 1
+                self.steps[j] += 1
+            lo, hi = int(fp.offsets[i]), int(fp.offsets[j + 1])
+            t = self.steps[i]
+            b1, b2 = self.betas
+            mk = None if self.mask is None else self.mask[lo:hi]
+            check(lib.rick_masked_adam_f32(ptr(fp.flat[lo:hi]), ptr(fp.grad[lo:hi]), ptr(self.m[lo:hi]),
+                                           ptr(self.v[lo:hi]), ptr(mk), hi - lo, self.lr, b1, b2, self.eps,
+                                           1.0 - b1 ** t, 1.0 - b2 ** t, stream_ptr()), 'rick_masked_adam_f32')
+            i = j + 1
+        op.bump_weights_epoch()
+
+
+def ema_accumulate(ema_params, params, decay):
+    """accumulate() of the reference (train_dynamic_update_prune.py:68-73) over matched lists."""
+    for e, p in zip(ema_params, params):
+        check(lib.rick_ema_f32(ptr(e.data), ptr(p.data), e.numel(), decay, stream_ptr()), 'rick_ema_f32')
+    op.bump_weights_epoch()
+
+
+# ------------------------------------------------------------------------ Fisher sweep
+class FisherAccumulator:
+    """Device-side replacement for the per-sample ``.cpu().numpy()`` accumulation of grad^2
+    (train_dynamic_update_prune.py:252-263): acc += g^2 in one fused kernel per tensor."""
+
+    def __init__(self, named_params):
+        self.names = [n for n, _ in named_params]
+        self.acc = {n: torch.zeros_like(p, memory_format=torch.contiguous_format) for n, p in named_params}
+
+    def add(self, grads):
+        for n, g in zip(self.names, grads):
+            if g is None:
+                continue
+            g = g.contiguous()
+            check(lib.rick_sq_accumulate_f32(ptr(self.acc[n]), ptr(g), g.numel(), stream_ptr()),
+                  'rick_sq_accumulate_f32')
+
+    def scale_(self, s):
+        for v in self.acc.values():
+            v.mul_(s)
+
+
+def filter_mean(t, filter_dim):
+    """Mean over every dim except `filter_dim` with one wavefront per filter
+    (rick_filter_reduce_f32).  Supports filter_dim 0 ([F, ...]) and 1 of a [1, F, ...] tensor."""
+    t = t.contiguous()
+    if filter_dim == 1:
+        if t.shape[0] != 1:
+            raise RuntimeError('filter_mean: dim-1 filters need a leading dim of 1')
+        t = t[0]
+    nf = t.shape[0]
+    inner = t.numel() // nf
+    out = torch.empty(nf, device=t.device, dtype=t.dtype)
+    check(lib.rick_filter_reduce_f32(ptr(t), ptr(out), 1, 0, nf, inner, inner, 1.0 / inner, stream_ptr()),
+          'rick_filter_reduce_f32')
+    return out
+
+
+def g_filter_fim(fisher, n_blocks=12):
+    """Per-filter FIM of the generator (train_dynamic_update_prune.py:279-299): dicts of device vectors."""
+    conv, fc = {}, {}
+    for k in range(n_blocks):
+        conv[f'convs.{k}.conv.weight'] = filter_mean(fisher[f'convs.{k}.conv.weight'], 1)
+        wk = f'convs.{k}.conv.modulation.weight'
+        fc[wk] = (filter_mean(fisher[wk], 0) + fisher[f'convs.{k}.conv.modulation.bias']) / 2
+    return conv, fc
+
+
+def d_filter_fim(fisher, blocks=range(1, 7)):
+    """Per-filter FIM of the discriminator (train_dynamic_update_prune.py:334-353)."""
+    out = {}
+    for b in blocks:
+        for li in range(2):
+            wk, bk = f'convs.{b}.conv{li + 1}.{li}.weight', f'convs.{b}.conv{li + 1}.{li + 1}.bias'
+            out[wk] = (filter_mean(fisher[wk], 0) + fisher[bk]) / 2
+            if li == 1:
+                sk = f'convs.{b}.skip.{li}.weight'
+                out[sk] = filter_mean(fisher[sk], 0)
+    return out
+
+
+def _split(fim, cut, prune, skip_rule=False):
+    if skip_rule:   # train_dynamic_update_prune.py:382-384
+        return np.where(fim > cut)[0], np.where((fim >= prune) & (fim <= cut))[0], np.where(fim < prune)[0]
+    return np.where(fim > cut)[0], np.where((fim > prune) & (fim <= cut))[0], np.where(fim <= prune)[0]
+
+
+def decide_g(conv, fc, fisher_quantile, prune_quantile):
+    """freeze / ft / prune index sets of the generator from per-filter FIM vectors (host numpy,
+    a few thousand floats; np.percentile in PERCENT units — train_dynamic_update_prune.py:285-330)."""
+    conv = {k: np.asarray(v, dtype=np.float32) for k, v in conv.items()}
+    fc = {k: np.asarray(v, dtype=np.float32) for k, v in fc.items()}
+    allc = np.concatenate([[]] + list(conv.values()), axis=None)
+    allf = np.concatenate([[]] + list(fc.values()), axis=None)
+    cut_c, pr_c = np.percentile(allc, q=fisher_quantile), np.percentile(allc, q=prune_quantile)
+    cut_f, pr_f = np.percentile(allf, q=fisher_quantile), np.percentile(allf, q=prune_quantile)
+    freeze, ft, prune = {}, {}, {}
+    for k, v in conv.items():
+        freeze[k], ft[k], prune[k] = _split(v, cut_c, pr_c)
+    for k, v in fc.items():
+        for kk in (k, k.replace('weight', 'bias')):
+            freeze[kk], ft[kk], prune[kk] = _split(v, cut_f, pr_f)
+    return freeze, ft, prune
+
+
+def decide_d(fim, fisher_quantile, prune_quantile):
+    """train_dynamic_update_prune.py:352-384"""
+    fim = {k: np.asarray(v, dtype=np.float32) for k, v in fim.items()}
+    allv = np.concatenate([[]] + list(fim.values()), axis=None)
+    cut, pr = np.percentile(allv, q=fisher_quantile), np.percentile(allv, q=prune_quantile)
+    freeze, ft, prune = {}, {}, {}
+    for k, v in fim.items():
+        if 'skip' in k:
+            freeze[k], ft[k], prune[k] = _split(v, cut, pr, skip_rule=True)
+        else:
+            bk = k.replace(f'{k[-8]}.weight', f'{int(k[-8]) + 1}.bias')
+            for kk in (k, bk):
+                freeze[kk], ft[kk], prune[kk] = _split(v, cut, pr)
+    return freeze, ft, prune
+
+
+def zero_idx_merge(old, new):
+    """train_dynamic_update_prune.py:138-144"""
+    return {k: np.unique(np.concatenate((old[k], new[k]))) for k in old}
+
+
+def build_mask(flat, freeze_idx, zero_idx):
+    """Flat uint8 mask for MaskedFlatAdam from per-key filter index sets: bit0 = freeze
+    (grad := 0), bit1 = zero/prune (param := 0, grad := 0).  5-D generator conv weights are
+    indexed on dim 1, everything else on dim 0 (train_dynamic_update_prune.py:524-537, 429-435)."""
+    mask = torch.zeros(flat.total, dtype=torch.uint8)
+    for bit, table in ((1, freeze_idx), (2, zero_idx)):
+        for name, idx in table.items():
+            if name not in flat.index or len(idx) == 0:
+                continue
+            lo, hi = flat.segment(name)
+            p = flat.params[flat.index[name]]
+            view = mask[lo:hi].view(p.shape)
+            ii = torch.as_tensor(np.asarray(idx), dtype=torch.long)
+            if p.ndim == 5:
+                view[:, ii] |= bit
+            else:
+                view[ii] |= bit
+    return mask.to(flat.flat.device)
+
+
+# --------------------------------------------------------------------------- trainer
+@dataclass
+class TrainConfig:
+    """The live flags of the reference CLI (train_dynamic_update_prune.py:703-758) with its defaults."""
+    size: int = 256
+    batch: int = 4
+    latent: int = 512
+    n_mlp: int = 8
+    channel_multiplier: int = 2
+    r1: float = 10.0
+    path_regularize: float = 2.0
+    path_batch_shrink: int = 2
+    d_reg_every: int = 16
+    g_reg_every: int = 4
+    mixing: float = 0.9
+    lr: float = 0.002
+    num_fisher_img: int = 5
+    fisher_freq: int = 50
+    fisher_quantile: float = 40.0
+    prune_quantile: float = 0.1
+    warmup_iter: int = 250
+    ema_decay: float = 0.5 ** (32 / (10 * 1000))     # train_dynamic_update_prune.py:180
+
+
+def g_optim_filter(name):
+    return 'convs' in name                              # train_dynamic_update_prune.py:909-911
+
+
+def d_optim_filter(name):
+    return ('convs' in name and 'convs.0' not in name) or 'final' in name   # :922-926
+
+
+class RickTrainer:
+    """One process / one GPU worth of the adaptation loop.  `dp` (rick_amd.dist.DataParallelGrads
+    or None) averages flat gradients over ranks with RCCL before each optimiser step."""
+
+    def __init__(self, cfg, generator, discriminator, g_ema, d_ema, dp=None):
+        self.cfg, self.g, self.d, self.g_ema, self.d_ema, self.dp = cfg, generator, discriminator, g_ema, d_ema, dp
+        self.device = next(generator.parameters()).device
+        g_named = [(n, p) for n, p in generator.named_parameters() if g_optim_filter(n)]
+        d_named = [(n, p) for n, p in discriminator.named_parameters() if d_optim_filter(n)]
+        self.g_flat, self.d_flat = FlatParams(g_named), FlatParams(d_named)
+        g_ratio = cfg.g_reg_every / (cfg.g_reg_every + 1)
+        d_ratio = cfg.d_reg_every / (cfg.d_reg_every + 1)
+        self.g_optim = MaskedFlatAdam(self.g_flat, cfg.lr * g_ratio, (0 ** g_ratio, 0.99 ** g_ratio))
+        self.d_optim = MaskedFlatAdam(self.d_flat, cfg.lr * d_ratio, (0 ** d_ratio, 0.99 ** d_ratio))
+        # parameters no optimiser owns never need gradients in the train steps
+        for n, p in generator.named_parameters():
+            p.requires_grad = g_optim_filter(n)
+        self._d_all = dict(discriminator.named_parameters())
+        self.mean_path_length = 0
+        self.idx_freeze_g = self.idx_freeze_d = None
+        self.zero_idx_g = self.zero_idx_d = None
+        self.losses = {}
+        if dp is not None:
+            dp.attach(self.g_flat, self.d_flat)
+
+    # ---- gradient flags of the discriminator for the current stage (:202-211)
+    def _set_d_stage(self, i):
+        warm = i < self.cfg.warmup_iter
+        for n, p in self._d_all.items():
+            p.requires_grad = (('final' in n) if warm else True) and d_optim_filter(n)
+
+    def _d_frozen(self):
+        class _Ctx:
+            def __init__(s, params):
+                s.params, s.flags = params, None
+
+            def __enter__(s):
+                s.flags = [p.requires_grad for p in s.params]
+                for p in s.params:
+                    p.requires_grad = False
+
+            def __exit__(s, *a):
+                for p, f in zip(s.params, s.flags):
+                    p.requires_grad = f
+        return _Ctx(list(self._d_all.values()))
+
+    def _reduce(self, flat):
+        if self.dp is not None:
+            self.dp.all_reduce(flat)
+
+    # ---- steps (each returns the loss tensor; no host sync)
+    def d_step(self, real_img, noise, i=10 ** 9, g_noise=None):
+        self._set_d_stage(i)
+        with torch.no_grad():
+            fake_img, _ = self.g(noise, noise=g_noise)
+        fake_pred, _ = self.d(fake_img)
+        real_pred, _ = self.d(real_img)
+        d_loss = d_logistic_loss(real_pred, fake_pred)
+        self.d_flat.zero_grad()
+        d_loss.backward()
+        self._reduce(self.d_flat)
+        self.d_optim.step()
+        self.losses.update(d=d_loss.detach(), real_score=real_pred.detach().mean(), fake_score=fake_pred.detach().mean())
+        return d_loss
+
+    def r1_step(self, real_img, i=10 ** 9):
+        cfg = self.cfg
+        self._set_d_stage(i)
+        real_img = real_img.detach().requires_grad_(True)
+        with op.second_order():
+            real_pred, _ = self.d(real_img)
+            real_pred = real_pred.view(real_img.size(0), -1).mean(dim=1).unsqueeze(1)
+            r1_loss = d_r1_loss(real_pred, real_img)
+            self.d_flat.zero_grad()
+            (cfg.r1 / 2 * r1_loss * cfg.d_reg_every + 0 * real_pred[0]).backward()
+        self._reduce(self.d_flat)
+        self.d_optim.step()
+        self.losses['r1'] = r1_loss.detach()
+        return r1_loss
+
+    def g_step(self, noise, g_noise=None):
+        fake_img, _ = self.g(noise, noise=g_noise)
+        with self._d_frozen():
+            fake_pred, _ = self.d(fake_img)
+            g_loss = g_nonsaturating_loss(fake_pred)
+            self.g_flat.zero_grad()
+            g_loss.backward()
+        self._reduce(self.g_flat)
+        self.g_optim.step()
+        self.losses['g'] = g_loss.detach()
+        return g_loss
+
+    def plr_step(self, noise, pl_noise=None, g_noise=None):
+        cfg = self.cfg
+        with op.second_order():
+            fake_img, latents = self.g(noise, return_latents=True, noise=g_noise)
+            path_loss, self.mean_path_length, path_lengths = g_path_regularize(
+                fake_img, latents, self.mean_path_length, noise=pl_noise)
+            self.g_flat.zero_grad()
+            weighted = cfg.path_regularize * cfg.g_reg_every * path_loss
+            if cfg.path_batch_shrink:
+                weighted = weighted + 0 * fake_img[0, 0, 0, 0]
+            weighted.backward()
+        self._reduce(self.g_flat)
+        self.g_optim.step()
+        self.losses.update(path=path_loss.detach(), path_length=path_lengths.detach().mean())
+        return path_loss
+
+    def ema_step(self):
+        """accumulate(g_ema, g), accumulate(d_ema, d) (:697-698) over ALL named parameters."""
+        dec = self.cfg.ema_decay
+        ema_accumulate([p for _, p in self.g_ema.named_parameters()], [p for _, p in self.g.named_parameters()], dec)
+        ema_accumulate([p for _, p in self.d_ema.named_parameters()], [p for _, p in self.d.named_parameters()], dec)
+
+    # ---- Fisher sweep (:214-393)
+    def fisher_sweep(self, latents, reals, first, fixed_noise=False):
+        """latents: list of [1,512] tensors for THIS rank's samples; reals: matching [1,3,H,W]."""
+        cfg = self.cfg
+        requires_grad(self.g_ema, True)
+        requires_grad(self.d_ema, True)
+        g_named, d_named = list(self.g_ema.named_parameters()), list(self.d_ema.named_parameters())
+        acc_g, acc_d = FisherAccumulator(g_named), FisherAccumulator(d_named)
+        for z, real in zip(latents, reals):
+            fake, _ = self.g_ema([z.view(1, -1)], randomize_noise=not fixed_noise)
+            fake_pred, _ = self.d_ema(fake)
+            real_pred, _ = self.d_ema(real.view(1, 3, cfg.size, cfg.size))
+            g_loss = g_nonsaturating_loss(fake_pred)
+            d_loss = d_logistic_loss(real_pred, fake_pred)
+            acc_g.add(autograd.grad(g_loss, [p for _, p in g_named], retain_graph=True, allow_unused=True))
+            acc_d.add(autograd.grad(d_loss, [p for _, p in d_named], allow_unused=True))
+        scale = 1.0 / (cfg.num_fisher_img * cfg.batch)                 # :266-269
+        acc_g.scale_(scale)
+        acc_d.scale_(scale)
+        conv, fc = g_filter_fim(acc_g.acc)
+        dfim = d_filter_fim(acc_d.acc)
+        if self.dp is not None:                                        # samples are sharded over ranks
+            self.dp.all_reduce_vectors(list(conv.values()) + list(fc.values()) + list(dfim.values()))
+        to_np = lambda d: {k: v.detach().cpu().numpy() for k, v in d.items()}   # noqa: E731
+        self.fim = (to_np(conv), to_np(fc), to_np(dfim))
+        self.idx_freeze_g, _, prune_g = decide_g(self.fim[0], self.fim[1], cfg.fisher_quantile, cfg.prune_quantile)
+        self.idx_freeze_d, _, prune_d = decide_d(self.fim[2], cfg.fisher_quantile, cfg.prune_quantile)
+        if first:
+            self.zero_idx_g, self.zero_idx_d = prune_g, prune_d
+        else:
+            self.zero_idx_g = zero_idx_merge(self.zero_idx_g, prune_g)
+            self.zero_idx_d = zero_idx_merge(self.zero_idx_d, prune_d)
+        self.g_optim.set_mask(build_mask(self.g_flat, self.idx_freeze_g, self.zero_idx_g))
+        self.d_optim.set_mask(build_mask(self.d_flat, self.idx_freeze_d, self.zero_idx_d))
+        return acc_g, acc_d
+
+    # ---- one iteration in the reference's order (:395-589, 697-698)
+    def iteration(self, i, real_img, fisher_inputs=None):
+        cfg = self.cfg
+        if fisher_inputs is not None and i - cfg.warmup_iter >= 0 and (i - cfg.warmup_iter) % cfg.fisher_freq == 0:
+            self.fisher_sweep(*fisher_inputs, first=(i == cfg.warmup_iter))
+        self.d_step(real_img, mixing_noise(cfg.batch, cfg.latent, cfg.mixing, self.device), i)
+        if i % cfg.d_reg_every == 0:
+            self.r1_step(real_img, i)
+        if i >= cfg.warmup_iter:
+            self.g_step(mixing_noise(cfg.batch, cfg.latent, cfg.mixing, self.device))
+            if i % cfg.g_reg_every == 0:
+                pb = max(1, cfg.batch // cfg.path_batch_shrink)
+                self.plr_step(mixing_noise(pb, cfg.latent, cfg.mixing, self.device))
+        self.ema_step()
