@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: G+D train-step images/sec @256 px (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one iteration of the RICK adaptation loop in steady state (i >= warmup_iter,
+train_dynamic_update_prune.py:395-589,697-698): D step, [R1 every 16], G step, [path length
+every 4], EMA — with the freeze/prune masks of a Fisher sweep active — on the configuration the
+metric is quoted on (BASELINE configs[1]: FFHQ-256 architecture, batch 4 per GPU).  Weights are
+random-init (torch.manual_seed(1); the FFHQ checkpoint is a download), reals are seeded U(-1,1)
+batches already resident in HBM.  value = global batch * K / max-over-ranks wall time.
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel (conv_igemm_kernel, bf16x3 MFMA): algorithmic FLOPs / time,
+                timed per launch with HIP events on the launch stream in an instrumented repeat of
+                the same steps (the timed region itself carries no events)
+  cpu_baseline  the CPU oracle (port of the reference's CPU formulation) timed on this box's host
+                cores on a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(size=256):
+    """One non-reg iteration (D step fwd+bwd, G step fwd+bwd) of the CPU oracle at batch 1."""
+    from oracle.model_ref import discriminator_ref, generator_ref
+    from oracle.train_ref import d_logistic_loss_ref, g_nonsaturating_loss_ref
+    from rick_amd.synth import synth_latents, synth_reals, synth_state_dict
+    from tests.shapes import discriminator_shapes, generator_shapes
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sg = synth_state_dict(generator_shapes(size))
+    sd = synth_state_dict(discriminator_shapes(size))
+    pg = [v.requires_grad_(True) for k, v in sg.items() if not k.startswith('noises.')]
+    pd = [v.requires_grad_(True) for k, v in sd.items()]
+    z, real = synth_latents(1, seed=11), synth_reals(1, size=size, seed=11)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        fake, _ = generator_ref(sg, [z], size=size)
+    fp, _ = discriminator_ref(sd, fake, size=size)
+    rp, _ = discriminator_ref(sd, real, size=size)
+    torch.autograd.grad(d_logistic_loss_ref(rp, fp), pd)
+    fake, _ = generator_ref(sg, [z], size=size)
+    fp, _ = discriminator_ref(sd, fake, size=size)
+    torch.autograd.grad(g_nonsaturating_loss_ref(fp), pg, allow_unused=True)
+    dt = time.perf_counter() - t0
+    return {'value': 1.0 / dt, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'1 non-reg iteration (D step + G step, fwd+bwd, no optimiser) at batch 1, {size}px, '
+                      f'fp32 oneDNN, {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=32)
+    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--batch', type=int, default=4, help='per-GPU batch (BASELINE configs[1])')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--fisher-img', type=int, default=2, help='samples of the (untimed) Fisher sweep that sets the masks')
+    args = ap.parse_args()
+
+    from rick_amd import op
+    from rick_amd.dist import DataParallelGrads, init_from_env
+    from rick_amd.models import Discriminator, Generator
+    from rick_amd.op.conv import launch_profiler
+    from rick_amd.synth import synth_latents, synth_reals
+    from rick_amd.train import RickTrainer, TrainConfig
+    import torch.distributed as dist
+
+    rank, local, world = init_from_env()
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    op.set_precision(args.precision)
+
+    torch.manual_seed(1)                                   # train_dynamic_update_prune.py:760-762
+    cfg = TrainConfig(size=args.size, batch=args.batch, num_fisher_img=args.fisher_img)
+    g = Generator(cfg.size, cfg.latent, cfg.n_mlp, cfg.channel_multiplier).to(dev)
+    d = Discriminator(cfg.size, cfg.channel_multiplier).to(dev)
+    g_ema = Generator(cfg.size, cfg.latent, cfg.n_mlp, cfg.channel_multiplier).to(dev)
+    d_ema = Discriminator(cfg.size, cfg.channel_multiplier).to(dev)
+    g_ema.load_state_dict(g.state_dict())
+    d_ema.load_state_dict(d.state_dict())
+    dp = DataParallelGrads() if world > 1 else None
+    if dp is not None:
+        dp.broadcast_params([g, d, g_ema, d_ema])
+    tr = RickTrainer(cfg, g, d, g_ema, d_ema, dp=dp)
+    torch.manual_seed(1234 + rank)                         # per-rank latents / noise
+
+    reals = [synth_reals(cfg.batch, cfg.size, seed=100 * rank + j).to(dev) for j in range(4)]
+    # steady state: a Fisher sweep has run, masks are active (untimed; it recurs every fisher_freq iterations)
+    mine = [j for j in range(cfg.num_fisher_img) if j % world == rank]
+    tr.fisher_sweep([synth_latents(1, seed=500 + j).to(dev) for j in mine],
+                    [synth_reals(1, cfg.size, seed=600 + j).to(dev) for j in mine], first=True)
+
+    i0 = cfg.warmup_iter + 1
+
+    def run(n, start):
+        for k in range(n):
+            tr.iteration(start + k, reals[k % len(reals)])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup, i0)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps, i0 + args.warmup)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    out = {
+        'metric': 'G+D train-step images/sec @256px', 'value': cfg.batch * world * args.steps / elapsed,
+        'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32 (bf16x3 split MFMA, fp32 accumulate)' if args.precision == 'bf16x3' else 'bf16',
+        'data': 'synthetic',
+        'config': {'workload': f'FFHQ-256 StyleGAN2 G+D RICK iteration (D step, R1/16, G step, PLR/4, EMA, masks on), '
+                               f'batch {cfg.batch}/GPU, {cfg.size}px, channel_multiplier 2, random-init weights',
+                   'global_batch': cfg.batch * world, 'parallelism': f'dp{world}',
+                   'first_iteration': i0 + args.warmup},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # instrumented repeat of 4 non-reg + reg iterations: HIP events around every conv-family launch
+        with launch_profiler() as prof:
+            run(16, i0 + args.warmup + args.steps)
+            torch.cuda.synchronize()
+        agg = {}
+        for kind, flops, e0, e1 in prof:
+            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        ig = agg.get('igemm', [0.0, 1.0, 1])
+        ach = ig[0] / ig[1] / 1e12
+        mult = 3.0 if args.precision == 'bf16x3' else 1.0
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel', 'achieved': ach,
+                           'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 'traffic': None,
+                           'mfma_issued_frac': mult * ach / MFMA_BF16_DENSE_PEAK_TFLOPS,
+                           'launches': ig[2], 'avg_launch_us': 1e6 * ig[1] / max(ig[2], 1),
+                           'algorithmic_gflop_per_launch': ig[0] / max(ig[2], 1) / 1e9,
+                           'note': 'achieved = algorithmic FLOPs (2*N*OH*OW*Co*Ci*taps) / event-timed duration over '
+                                   '16 instrumented iterations; bf16x3 issues 3 MFMA FLOPs per algorithmic FLOP'}
+        if 'wgrad' in agg:
+            wg = agg['wgrad']
+            out['roofline']['wgrad_kernel'] = {'achieved': wg[0] / wg[1] / 1e12, 'launches': wg[2],
+                                               'avg_launch_us': 1e6 * wg[1] / max(wg[2], 1)}
+        conv_s = sum(a[1] for a in agg.values()) / 16
+        out['roofline']['conv_family_ms_per_step'] = 1e3 * conv_s
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(cfg.size)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

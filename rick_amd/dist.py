@@ -1,0 +1,128 @@
+"""Process-per-GPU data parallelism for the RICK loop over RCCL / xGMI.
+
+The reference's only live parallelism is single-process ``nn.DataParallel`` on D
+(train_dynamic_update_prune.py:941-944): per-call parameter broadcast, scatter, gather of 14
+feature maps, reduce-add of gradients.  Here every rank owns a full replica and a micro-batch;
+the only data-path exchange is the gradient average before each optimiser step:
+
+  * gradients of one network live in ONE flat buffer (rick_amd.train.FlatParams), cut into
+    contiguous buckets (default 32 MiB: large enough that a ring over 7 xGMI links runs at link
+    rate, small enough that the first bucket leaves while backward is still producing the rest);
+  * a post-accumulate-grad hook per parameter counts down its bucket; when a bucket is complete
+    its ``all_reduce`` is issued asynchronously (torch.distributed 'nccl' == RCCL on ROCm; it
+    runs on the backend's own stream), so communication overlaps the rest of backward;
+  * ``all_reduce(flat)`` (called right before the optimiser step) issues whatever is left and
+    waits.  Semantics: mean over ranks == the reference's loss ``.mean()`` over the global batch;
+    minibatch-stddev stays per rank, as under DataParallel's per-device chunks.
+
+Fisher sweep: samples are sharded over ranks, grad^2 is reduced per filter locally (linear), and
+only the per-filter vectors (~20 KB) are summed across ranks (``all_reduce_vectors``).
+Works with the 'gloo' backend on CPU tensors too (used by the world_size-2 tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's environment; returns (rank, local_rank, world)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class DataParallelGrads:
+    def __init__(self, bucket_bytes=32 << 20, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self._state = {}       # id(flat) -> dict(buckets, pending, works, hooks)
+
+    # ------------------------------------------------------------------ bucket bookkeeping
+    def attach(self, *flats):
+        for flat in flats:
+            buckets, cur_lo, cur_members = [], None, []
+            # parameters are laid out in forward order; gradients arrive roughly in reverse, so
+            # buckets are cut from the END of the buffer towards the front
+            for i in reversed(range(len(flat.params))):
+                lo, hi = int(flat.offsets[i]), int(flat.offsets[i + 1])
+                if cur_lo is None:
+                    cur_hi = hi
+                cur_lo = lo
+                cur_members.append(i)
+                if cur_hi - cur_lo >= self.bucket_elems or i == 0:
+                    buckets.append({'lo': cur_lo, 'hi': cur_hi, 'members': list(cur_members)})
+                    cur_lo, cur_members = None, []
+            st = {'buckets': buckets, 'owner': {}, 'pending': [], 'works': [], 'launched': [], 'flat': flat}
+            for b, bk in enumerate(buckets):
+                for i in bk['members']:
+                    st['owner'][i] = b
+            self._state[id(flat)] = st
+            self._arm(st)
+            if self.world > 1:
+                for i, p in enumerate(flat.params):
+                    p.register_post_accumulate_grad_hook(self._make_hook(st, i))
+
+    def _arm(self, st):
+        st['pending'] = [sum(1 for i in bk['members'] if st['flat'].params[i].requires_grad) for bk in st['buckets']]
+        st['launched'] = [False] * len(st['buckets'])
+        st['works'] = []
+
+    def _launch(self, st, b):
+        bk = st['buckets'][b]
+        view = st['flat'].grad[bk['lo']:bk['hi']]
+        st['works'].append((dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True), view))
+        st['launched'][b] = True
+
+    def _make_hook(self, st, i):
+        def hook(_param):
+            b = st['owner'][i]
+            st['pending'][b] -= 1
+            if st['pending'][b] == 0 and not st['launched'][b]:
+                self._launch(st, b)
+        return hook
+
+    # --------------------------------------------------------------------------- public
+    def all_reduce(self, flat):
+        """Average flat.grad over ranks (finishes the buckets the hooks already started)."""
+        if self.world == 1:
+            return
+        st = self._state[id(flat)]
+        for b in range(len(st['buckets'])):
+            if not st['launched'][b]:
+                self._launch(st, b)
+        inv = 1.0 / self.world
+        for work, view in st['works']:
+            work.wait()
+            view.mul_(inv)
+        self._arm(st)
+
+    def all_reduce_vectors(self, vectors):
+        """Sum small vectors (per-filter Fisher) over ranks in one collective."""
+        if self.world == 1:
+            return
+        flat = torch.cat([v.reshape(-1) for v in vectors])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for v in vectors:
+            n = v.numel()
+            v.copy_(flat[off:off + n].view_as(v))
+            off += n
+
+    def broadcast_params(self, modules, src=0):
+        """Make replicas identical at start-up (one-off)."""
+        if self.world == 1:
+            return
+        for m in modules:
+            for t in list(m.parameters()) + list(m.buffers()):
+                dist.broadcast(t.data, src=src, group=self.group)

@@ -28,6 +28,34 @@ _SPLIT = 2          # 2: bf16 hi/lo split, 3 MFMAs per product (fp32-grade); 1: 
 _weights_epoch = 0  # bumped by optimisers that update parameters through raw pointers
 
 
+_prof = None         # list of (kind, algorithmic_flops, start_event, end_event) while profiling
+
+
+class launch_profiler:
+    """Context manager used by bench.py: brackets every conv-family launch with HIP events on
+    the launch stream (torch's current stream) and records its algorithmic FLOPs."""
+
+    def __enter__(self):
+        global _prof
+        _prof = []
+        return _prof
+
+    def __exit__(self, *a):
+        global _prof
+        _prof = None
+
+
+def _launch(kind, flops, fn, *args):
+    if _prof is None:
+        return fn(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    _prof.append((kind, flops, e0, e1))
+    return rc
+
+
 def set_precision(name):
     """'bf16x3' (default; parity-grade) or 'bf16' (single pass, ~3x the MFMA rate, ~2^-9 relative)."""
     global _SPLIT
@@ -113,8 +141,8 @@ def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0):
     y = _empty_nhwc(N, O, OH, OW, x)
     taps = [(ky - p, kx - p, ky * kw + kx) for ky in range(kh) for kx in range(kw)]
     g = _geom(N, IH, IW, I, OH, OW, O, OH, OW, s, 1, 0, 0, taps, kh * kw, alpha)
-    check(lib.rick_conv_igemm_f32(ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), ctypes.byref(g), stream_ptr()),
-          'rick_conv_igemm_f32')
+    check(_launch('igemm', 2.0 * N * OH * OW * O * I * kh * kw, lib.rick_conv_igemm_f32, ptr(x), ptr(wp), ptr(y),
+                  ptr(iscale), ptr(oscale), ctypes.byref(g), stream_ptr()), 'rick_conv_igemm_f32')
     return y
 
 
@@ -140,8 +168,8 @@ def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alph
         if not taps:
             continue
         g = _geom(N, IH, IW, I, OH, OW, O, GH, GW, 1, s, py, px, taps, kh * kw, alpha)
-        check(lib.rick_conv_igemm_f32(ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), ctypes.byref(g),
-                                      stream_ptr()), 'rick_conv_igemm_f32')
+        check(_launch('igemm', 2.0 * N * GH * GW * O * I * len(taps), lib.rick_conv_igemm_f32, ptr(x), ptr(wp), ptr(y),
+                      ptr(iscale), ptr(oscale), ctypes.byref(g), stream_ptr()), 'rick_conv_igemm_f32')
     return y
 
 
@@ -159,8 +187,9 @@ def _wgrad_launch(a, b, kh, kw, s, p, alpha=1.0, ascale=None, bscale=None):
     if nbytes < 0:
         raise RuntimeError('rick_conv_wgrad_workspace_bytes: invalid geometry')
     ws = torch.empty(max(nbytes, 16), device=a.device, dtype=torch.uint8)
-    check(lib.rick_conv_wgrad_f32(ptr(b), ptr(a), ptr(gw), I * kh * kw, kh * kw, 1, ptr(ascale), ptr(bscale),
-                                  ctypes.byref(g), 0, ptr(ws), stream_ptr()), 'rick_conv_wgrad_f32')
+    check(_launch('wgrad', 2.0 * N * AH * AW * O * I * kh * kw, lib.rick_conv_wgrad_f32, ptr(b), ptr(a), ptr(gw),
+                  I * kh * kw, kh * kw, 1, ptr(ascale), ptr(bscale), ctypes.byref(g), 0, ptr(ws), stream_ptr()),
+          'rick_conv_wgrad_f32')
     return gw
 
 

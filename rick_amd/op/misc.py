@@ -127,13 +127,13 @@ class _ThinFwd(Function):
 
     @staticmethod
     def forward(ctx, x, W):
+        ctx.save_for_backward(x, W)          # the ORIGINAL inputs, so higher-order graphs reach them
         x = _nhwc(x)
         n, c, h, w = _thin_shapes(x, W.shape[1])
         Wc, bs = _wb(W, n)
         t = torch.empty((n, W.shape[1], h, w), device=x.device, dtype=x.dtype)
         check(lib.rick_thin_fwd_f32(ptr(x), ptr(Wc), bs, None, ptr(t), n, h * w, c, W.shape[1], stream_ptr()),
               'rick_thin_fwd_f32')
-        ctx.save_for_backward(x, W)
         return t
 
     @staticmethod
@@ -153,6 +153,7 @@ class _ThinBwdX(Function):
 
     @staticmethod
     def forward(ctx, t, W):
+        ctx.save_for_backward(t, W)
         t = t.contiguous()
         n, J, h, w = t.shape
         c = W.shape[2]
@@ -160,7 +161,6 @@ class _ThinBwdX(Function):
         x = torch.empty((n, c, h, w), device=t.device, dtype=t.dtype, memory_format=torch.channels_last)
         _thin_shapes(x, J)
         check(lib.rick_thin_bwdx_f32(ptr(t), ptr(Wc), bs, ptr(x), n, h * w, c, J, stream_ptr()), 'rick_thin_bwdx_f32')
-        ctx.save_for_backward(t, W)
         return x
 
     @staticmethod
@@ -180,6 +180,7 @@ class _ThinWgrad(Function):
 
     @staticmethod
     def forward(ctx, t, x):
+        ctx.save_for_backward(t, x)
         t = t.contiguous()
         x = _nhwc(x)
         n, c, h, w = _thin_shapes(x, t.shape[1])
@@ -189,7 +190,6 @@ class _ThinWgrad(Function):
         part = torch.empty(nb * n * J * c, device=x.device, dtype=x.dtype)
         check(lib.rick_thin_wgrad_f32(ptr(t), ptr(x), ptr(G), n, h * w, c, J, ptr(part), stream_ptr()),
               'rick_thin_wgrad_f32')
-        ctx.save_for_backward(t, x)
         return G
 
     @staticmethod

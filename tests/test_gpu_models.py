@@ -38,15 +38,18 @@ def grad2(named, grads):
 
 
 def check_grad2(got, gold, prefix, tol):
+    # per-key sum(g^2); keys whose gradient is >1000x smaller (in norm) than the largest one are
+    # dominated by fp32 rounding of the big terms, hence the absolute floor of 1e-6 * max
     worst = 0.0
+    top = max(float(gold[f'{prefix}/{k}']) for k in got)
     for k, v in got.items():
         ref = float(gold[f'{prefix}/{k}'])
         if ref == 0.0:
-            assert v < 1e-20, (k, v)
+            assert v <= 1e-12 * top, (k, v)
             continue
         e = abs(v - ref) / ref
         worst = max(worst, e)
-        assert e < tol, f'{prefix}/{k}: {v} vs {ref} (rel {e:.2e})'
+        assert abs(v - ref) < tol * ref + 1e-6 * top, f'{prefix}/{k}: {v} vs {ref} (rel {e:.2e})'
     return worst
 
 
@@ -164,24 +167,28 @@ def test_trainer_steps_match_oracle():
     zero_g = {'convs.1.conv.modulation.weight': np.array([4]), 'convs.1.conv.modulation.bias': np.array([4])}
     tr.g_optim.set_mask(build_mask(tr.g_flat, freeze_g, zero_g))
 
-    def ref_adam(params, grads, keys, lr, b2, freeze, zero, fivedim_keys=()):
-        out = {}
+    def masked(p, gr, k, freeze, zero):
+        p, gr = p.clone(), gr.clone()
+        for tab, kill_p in ((freeze, False), (zero, True)):
+            if k in tab:
+                sl = (slice(None), tab[k]) if p.ndim == 5 else (tab[k],)
+                gr[sl] = 0
+                if kill_p:
+                    p[sl] = 0
+        return p, gr
+
+    def check_step(flat, before, ref_grads, keys, lr, b2, freeze, zero, named_after):
+        """(a) device gradients == oracle gradients (after masking); (b) the fused mask+Adam kernel
+        applied to the device gradients == restated torch.optim.Adam (first step, beta1 = 0).  Adam's
+        first step is sign-like (lr * g / (|g| + eps)), so (b) is checked on the device's own
+        gradients rather than through the oracle's."""
         for k in keys:
-            p, gr = params[k].clone(), grads[k].clone()
-            if k in freeze:
-                if p.ndim == 5:
-                    gr[:, freeze[k]] = 0
-                else:
-                    gr[freeze[k]] = 0
-            if k in zero:
-                if p.ndim == 5:
-                    p[:, zero[k]] = 0
-                    gr[:, zero[k]] = 0
-                else:
-                    p[zero[k]] = 0
-                    gr[zero[k]] = 0
-            out[k], _, _ = adam_step_ref(p, gr, torch.zeros_like(p), torch.zeros_like(p), 1, lr, 0.0, b2)
-        return out
+            lo, hi = flat.segment(k)
+            p0, g_ref = masked(before[k], ref_grads[k], k, freeze, zero)
+            g_dev = flat.grad[lo:hi].view(p0.shape).double().cpu()
+            assert rel(g_dev, g_ref) < 3e-4, ('grad', k)
+            exp, _, _ = adam_step_ref(p0, g_dev, torch.zeros_like(p0), torch.zeros_like(p0), 1, lr, 0.0, b2)
+            assert rel(named_after[k], exp) < 2e-6, ('adam', k)
 
     # ---- D step
     for v in sd.values():
@@ -193,12 +200,11 @@ def test_trainer_steps_match_oracle():
     dl = d_logistic_loss_ref(rp, fp)
     dkeys = [k for k in sd if d_optim_filter(k) and not k.endswith('.kernel')]
     gd = dict(zip(dkeys, torch.autograd.grad(dl, [sd[k] for k in dkeys])))
-    exp = ref_adam({k: sd[k].detach() for k in dkeys}, gd, dkeys, cfg.lr * 16 / 17, 0.99 ** (16 / 17), freeze_d, zero_d)
+    before = {k: sd[k].detach().clone() for k in dkeys}
     d_loss = tr.d_step(real.to(DEV), [z.to(DEV)], g_noise=dev_noises)
     assert rel(d_loss, dl.detach()) < 1e-4
     got = dict(d.named_parameters())
-    for k in dkeys:
-        assert rel(got[k], exp[k]) < 2e-4, k
+    check_step(tr.d_flat, before, gd, dkeys, cfg.lr * 16 / 17, 0.99 ** (16 / 17), freeze_d, zero_d, got)
     assert float(got['convs.2.skip.1.weight'][[0, 3]].abs().max()) == 0.0
 
     # ---- G step (D already updated on both sides: reload oracle D from the device)
@@ -210,12 +216,11 @@ def test_trainer_steps_match_oracle():
     gl = g_nonsaturating_loss_ref(fp)
     gkeys = [k for k in sg if g_optim_filter(k) and not k.endswith('.kernel')]
     gg = dict(zip(gkeys, torch.autograd.grad(gl, [sg[k] for k in gkeys])))
-    exp = ref_adam({k: sg[k].detach() for k in gkeys}, gg, gkeys, cfg.lr * 4 / 5, 0.99 ** (4 / 5), freeze_g, zero_g)
+    before = {k: sg[k].detach().clone() for k in gkeys}
     g_loss = tr.g_step([z.to(DEV)], g_noise=dev_noises)
     assert rel(g_loss, gl.detach()) < 1e-4
     got = dict(g.named_parameters())
-    for k in gkeys:
-        assert rel(got[k], exp[k]) < 2e-4, k
+    check_step(tr.g_flat, before, gg, gkeys, cfg.lr * 4 / 5, 0.99 ** (4 / 5), freeze_g, zero_g, got)
 
     # ---- R1 and path-length values through the trainer (second-order graph), vs oracle
     sd3 = {k: v.detach().double().cpu().requires_grad_(True) for k, v in d.state_dict().items()}

@@ -1,0 +1,181 @@
+"""CPU-only tests of the host-side logic: Fisher decisions vs the oracle restatement and the
+captured reference FIM, mask construction, flat parameter views, and the multi-process
+data-parallel path (gloo, world_size 2)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle.train_ref import d_decisions_ref, g_decisions_ref, zero_idx_merge_ref
+from rick_amd.train import (FlatParams, build_mask, d_optim_filter, decide_d, decide_g, g_optim_filter,
+                            zero_idx_merge)
+from tests.shapes import discriminator_shapes, generator_shapes
+
+
+_FF = {}
+
+
+def fake_fisher(shapes, seed):
+    """Synthetic non-negative 'Fisher' tensors for the keys the decision code reads (cached)."""
+    if seed not in _FF:
+        rs = np.random.RandomState(seed)
+        _FF[seed] = {k: (rs.rand(*s).astype(np.float32) ** 4) for k, s in shapes.items()
+                     if k.startswith('convs.') and not k.endswith('.kernel')}
+    return _FF[seed]
+
+
+@pytest.mark.parametrize('fq,pq', [(40, 0.1), (85, 0.075), (75, 0.1)])
+def test_decisions_match_oracle(fq, pq):
+    """product decide_g / decide_d (fed per-filter vectors) == oracle restatement of
+    train_dynamic_update_prune.py:279-393 (fed full Fisher tensors)."""
+    fg = fake_fisher(generator_shapes(256), 1)
+    fd = fake_fisher(discriminator_shapes(256), 2)
+    conv = {f'convs.{k}.conv.weight': fg[f'convs.{k}.conv.weight'].mean(axis=(0, 2, 3, 4)) for k in range(12)}
+    fc = {f'convs.{k}.conv.modulation.weight': (fg[f'convs.{k}.conv.modulation.weight'].mean(axis=1)
+                                                 + fg[f'convs.{k}.conv.modulation.bias']) / 2 for k in range(12)}
+    got = decide_g(conv, fc, fq, pq)
+    ref = g_decisions_ref(fg, fq, pq)
+    for a, b in zip(got, ref):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    dfim = {}
+    for b in range(1, 7):
+        for li in range(2):
+            wk, bk = f'convs.{b}.conv{li + 1}.{li}.weight', f'convs.{b}.conv{li + 1}.{li + 1}.bias'
+            dfim[wk] = (fd[wk].mean(axis=(1, 2, 3)) + fd[bk]) / 2
+        dfim[f'convs.{b}.skip.1.weight'] = fd[f'convs.{b}.skip.1.weight'].mean(axis=(1, 2, 3))
+    got = decide_d(dfim, fq, pq)
+    ref = d_decisions_ref(fd, fq, pq)
+    for a, b in zip(got, ref):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    # every filter lands in exactly one set; D bias keys exist (character arithmetic of :363)
+    fr, ft, pr = got
+    assert 'convs.3.conv2.2.bias' in fr and 'convs.3.conv1.1.bias' in fr
+    for k in fr:
+        n = len(fr[k]) + len(ft[k]) + len(pr[k])
+        assert n == len(dfim[k if k in dfim else k.replace(f'{int(k[-6])}.bias', f'{int(k[-6]) - 1}.weight')])
+    m = zero_idx_merge(pr, fr)
+    mr = zero_idx_merge_ref(pr, fr)
+    assert all(np.array_equal(m[k], mr[k]) for k in m)
+
+
+def test_decisions_on_reference_fim(golden):
+    """README quantiles on the FIM captured from the reference's estimate_fisher at 256 px."""
+    g = golden('full256')
+    conv = {f'convs.{k}.conv.weight': g[f'fisher/g_conv/{k}'] for k in range(12)}
+    fc = {f'convs.{k}.conv.modulation.weight': g[f'fisher/g_fc/{k}'] for k in range(12)}
+    for fq, pq in ((40, 0.1), (85, 0.075)):
+        fr, ft, pr = decide_g(conv, fc, fq, pq)
+        allc = np.concatenate([conv[k] for k in conv])
+        cut, prl = np.percentile(allc, fq), np.percentile(allc, pq)
+        for k, v in conv.items():
+            assert np.array_equal(fr[k], np.where(v > cut)[0])
+            assert np.array_equal(pr[k], np.where(v <= prl)[0])
+        tot_freeze = sum(len(fr[k]) for k in conv)
+        assert abs(tot_freeze - round(4864 * (100 - fq) / 100)) <= 2
+        assert set(fr) == set(conv) | set(fc) | {k.replace('weight', 'bias') for k in fc}
+
+
+def test_flat_params_and_masks_cpu():
+    from rick_amd.models import Generator
+    g = Generator(16, 512, 8)
+    named = [(n, p) for n, p in g.named_parameters() if g_optim_filter(n)]
+    before = {n: p.detach().clone() for n, p in named}
+    flat = FlatParams(named)
+    assert flat.total == sum(p.numel() for _, p in named)
+    for n, p in named:
+        assert torch.equal(p.detach(), before[n])
+        lo, hi = flat.segment(n)
+        assert p.data_ptr() == flat.flat[lo:hi].data_ptr() and p.grad.data_ptr() == flat.grad[lo:hi].data_ptr()
+    # autograd accumulates into the flat views
+    sum((p * p).sum() for _, p in named).backward()
+    assert torch.allclose(flat.grad, 2 * flat.flat.detach())
+    flat.zero_grad()
+    assert float(flat.grad.abs().max()) == 0
+    freeze = {'convs.0.conv.weight': np.array([1, 3]), 'convs.0.conv.modulation.bias': np.array([0])}
+    zero = {'convs.1.conv.weight': np.array([2]), 'not.a.key': np.array([1])}
+    mask = build_mask(flat, freeze, zero)
+    lo, hi = flat.segment('convs.0.conv.weight')
+    mv = mask[lo:hi].view(1, 512, 512, 3, 3)
+    assert int(mv[:, [1, 3]].min()) == 1 and int(mv[:, [0, 2, 4]].max()) == 0
+    lo, hi = flat.segment('convs.1.conv.weight')
+    assert int(mask[lo:hi].view(1, 512, 512, 3, 3)[:, 2].min()) == 2
+    lo, hi = flat.segment('convs.0.conv.modulation.bias')
+    assert mask[lo:hi].tolist()[:2] == [1, 0]
+    assert d_optim_filter('convs.3.conv1.0.weight') and d_optim_filter('final_linear.1.bias')
+    assert not d_optim_filter('convs.0.0.weight')
+
+
+# ------------------------------------------------------------------- world_size-2 gloo
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from rick_amd.dist import DataParallelGrads, init_from_env
+    init_from_env('gloo')
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(64, 300), torch.nn.Linear(300, 300), torch.nn.Linear(300, 7))
+    named = list(lin.named_parameters())
+    flat = FlatParams(named)
+    dp = DataParallelGrads(bucket_bytes=64 * 1024)
+    dp.broadcast_params([lin])
+    dp.attach(flat)
+    assert len(dp._state[id(flat)]["buckets"]) >= 2
+    xs = torch.randn(8, 64, generator=torch.Generator().manual_seed(5))
+    res = []
+    for it in range(2):                       # two rounds: hooks re-arm
+        flat.zero_grad()
+        x = xs[rank * 4:(rank + 1) * 4]
+        lin(x).pow(2).mean().backward()       # per-rank mean over its micro-batch
+        dp.all_reduce(flat)
+        res.append(flat.grad.clone())
+    # frozen parameter (warm-up stage): its bucket must still complete
+    named[0][1].requires_grad = False
+    dp._arm(dp._state[id(flat)])
+    flat.zero_grad()
+    lin(xs[rank * 4:(rank + 1) * 4]).pow(2).mean().backward()
+    dp.all_reduce(flat)
+    vec = [torch.full((5,), float(rank + 1)), torch.full((3,), 10.0 * (rank + 1))]
+    dp.all_reduce_vectors(vec)
+    q.put((rank, res[0].numpy(), res[1].numpy(), vec[0].numpy(), vec[1].numpy(), flat.grad.clone().numpy()))
+    torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_grads_gloo_world2():
+    """Averaged bucketed all-reduce == single-process gradient of the global-batch mean."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=120) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(64, 300), torch.nn.Linear(300, 300), torch.nn.Linear(300, 7))
+    xs = torch.randn(8, 64, generator=torch.Generator().manual_seed(5))
+    lin(xs).pow(2).mean().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in lin.parameters()]).numpy()
+    for o in outs:
+        assert np.allclose(o[1], ref, rtol=1e-5, atol=1e-7)
+        assert np.allclose(o[2], ref, rtol=1e-5, atol=1e-7)
+        assert np.allclose(o[3], 3.0) and np.allclose(o[4], 30.0)
+        n0 = 64 * 300
+        assert np.allclose(o[5][n0:], ref[n0:], rtol=1e-5, atol=1e-7)     # frozen first weight excluded
+    assert np.array_equal(outs[0][1], outs[1][1])
