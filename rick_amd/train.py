@@ -184,9 +184,11 @@ def filter_mean(t, filter_dim):
     return out
 
 
-def g_filter_fim(fisher, n_blocks=12):
+def g_filter_fim(fisher, n_blocks=None):
     """Per-filter FIM of the generator (train_dynamic_update_prune.py:279-299): dicts of device vectors."""
     conv, fc = {}, {}
+    if n_blocks is None:      # 12 at 256 px, the only size the reference supports (hard-coded range(12), :281)
+        n_blocks = sum(1 for k in fisher if k.startswith('convs.') and k.endswith('.conv.weight'))
     for k in range(n_blocks):
         conv[f'convs.{k}.conv.weight'] = filter_mean(fisher[f'convs.{k}.conv.weight'], 1)
         wk = f'convs.{k}.conv.modulation.weight'
@@ -194,9 +196,11 @@ def g_filter_fim(fisher, n_blocks=12):
     return conv, fc
 
 
-def d_filter_fim(fisher, blocks=range(1, 7)):
+def d_filter_fim(fisher, blocks=None):
     """Per-filter FIM of the discriminator (train_dynamic_update_prune.py:334-353)."""
     out = {}
+    if blocks is None:        # range(1, 7) at 256 px (:336)
+        blocks = range(1, 1 + sum(1 for k in fisher if k.endswith('.skip.1.weight')))
     for b in blocks:
         for li in range(2):
             wk, bk = f'convs.{b}.conv{li + 1}.{li}.weight', f'convs.{b}.conv{li + 1}.{li + 1}.bias'
@@ -397,6 +401,20 @@ class RickTrainer:
         return g_loss
 
     def plr_step(self, noise, pl_noise=None, g_noise=None):
+        cfg = self.cfg
+        # the path-length gradient is taken w.r.t. the latents, which only carry a graph if the mapping
+        # network's parameters require grad (in the reference every parameter does)
+        style_params = list(self.g.style.parameters())
+        for p in style_params:
+            p.requires_grad = True
+        try:
+            return self._plr_step(noise, pl_noise, g_noise)
+        finally:
+            for p in style_params:
+                p.requires_grad = False
+                p.grad = None
+
+    def _plr_step(self, noise, pl_noise, g_noise):
         cfg = self.cfg
         with op.second_order():
             fake_img, latents = self.g(noise, return_latents=True, noise=g_noise)
