@@ -38,7 +38,7 @@ def cpu_baseline(size=256):
     from oracle.train_ref import d_logistic_loss_ref, g_nonsaturating_loss_ref
     from rick_amd.synth import synth_latents, synth_reals, synth_state_dict
     from tests.shapes import discriminator_shapes, generator_shapes
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)      # oneDNN scales poorly past one socket's worth of threads here
     torch.set_num_threads(cores)
     sg = synth_state_dict(generator_shapes(size))
     sd = synth_state_dict(discriminator_shapes(size))

@@ -106,10 +106,15 @@ int64_t rick_conv_packed_bytes(int Co, int Ci, int nslices);
 /* Pack W (element (co, ci, slice s) at w[co*s_co + ci*s_ci + s*s_t]) * scale into the MFMA
  * A-operand LDS image (bf16 hi/lo, swizzled, zero padded to 128 x 32 tiles). */
 int rick_conv_pack_weight(const float *w, int64_t s_co, int64_t s_ci, int64_t s_t,
-                          int Co, int Ci, int nslices, float scale, void *packed, void *stream);
+                          int Co, int Ci, int nslices, float scale, int split, void *packed, void *stream);
+/* Launches with too few output tiles to fill the chip (the 4x4..32x32 512-channel layers) are
+ * split over the channel-chunk dimension; partial sums go through `workspace`
+ * (rick_conv_igemm_workspace_bytes bytes, 0 = not needed, may then be NULL) and a deterministic
+ * second-stage kernel applies alpha / oscale. */
+int64_t rick_conv_igemm_workspace_bytes(const rick_conv_geom *g);
 int rick_conv_igemm_f32(const float *x, const void *packed_w, float *out,
                         const float *iscale, const float *oscale,
-                        const rick_conv_geom *g, void *stream);
+                        const rick_conv_geom *g, void *workspace, void *stream);
 
 /* Weight gradient for the same geometry:
  *   gw[(co, ci, t)] = alpha * sum_{n, pos} (ascale[n,co] * gy[n, outpix(pos), co]) *

@@ -43,15 +43,31 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
 }
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16_rne(float a, float b) {   // v_cvt_pk_bf16_f32
+    bf16x2_t r = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+    return *reinterpret_cast<unsigned *>(&r);
+}
+
+// x = hi + lo with hi = x truncated to bf16 (exactly representable, so lo = x - hi is exact in
+// fp32) and lo rounded to nearest bf16: |x - hi - lo| <= 2^-17 |x|, unbiased.  10 VALU ops per 4
+// elements (v_and, v_perm, v_pk_add, v_cvt_pk).  SPLIT == 1 (plain bf16): hi is rounded to nearest.
+template <int SPLIT>
 __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
-    const unsigned short h0 = f32_to_bf16_rne(v.x), h1 = f32_to_bf16_rne(v.y), h2 = f32_to_bf16_rne(v.z),
-                         h3 = f32_to_bf16_rne(v.w);
-    hi.x = (unsigned)h0 | ((unsigned)h1 << 16);
-    hi.y = (unsigned)h2 | ((unsigned)h3 << 16);
-    const unsigned short l0 = f32_to_bf16_rne(v.x - bf16_to_f32(h0)), l1 = f32_to_bf16_rne(v.y - bf16_to_f32(h1)),
-                         l2 = f32_to_bf16_rne(v.z - bf16_to_f32(h2)), l3 = f32_to_bf16_rne(v.w - bf16_to_f32(h3));
-    lo.x = (unsigned)l0 | ((unsigned)l1 << 16);
-    lo.y = (unsigned)l2 | ((unsigned)l3 << 16);
+    if (SPLIT == 1) {
+        hi.x = pack_bf16_rne(v.x, v.y);
+        hi.y = pack_bf16_rne(v.z, v.w);
+        lo.x = lo.y = 0;
+        return;
+    }
+    const unsigned ux = __float_as_uint(v.x), uy = __float_as_uint(v.y), uz = __float_as_uint(v.z),
+                   uw = __float_as_uint(v.w);
+    hi.x = __builtin_amdgcn_perm(uy, ux, 0x07060302);
+    hi.y = __builtin_amdgcn_perm(uw, uz, 0x07060302);
+    lo.x = pack_bf16_rne(v.x - __uint_as_float(ux & 0xffff0000u), v.y - __uint_as_float(uy & 0xffff0000u));
+    lo.y = pack_bf16_rne(v.z - __uint_as_float(uz & 0xffff0000u), v.w - __uint_as_float(uw & 0xffff0000u));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -64,7 +80,7 @@ extern "C" int64_t rick_conv_packed_bytes(int Co, int Ci, int nslices) {
 
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, int64_t s_co, int64_t s_ci,
                                                           int64_t s_t, int Co, int Ci, int nslices, float scale,
-                                                          unsigned short *__restrict__ packed, int64_t total) {
+                                                          unsigned short *__restrict__ packed, int64_t total, int split) {
     const int nchunks = (Ci + CV_CK - 1) / CV_CK;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int k = (int)(i & 31);
@@ -77,8 +93,14 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
         const int co = cot * CV_BM + r, ci = chunk * CV_CK + k;
         float v = 0.f;
         if (co < Co && ci < Ci) v = w[co * s_co + ci * s_ci + slice * s_t] * scale;
-        const unsigned short h = f32_to_bf16_rne(v);
-        const unsigned short l = f32_to_bf16_rne(v - bf16_to_f32(h));
+        unsigned short h, l;
+        if (split == 1) {
+            h = f32_to_bf16_rne(v);
+            l = 0;
+        } else {
+            h = (unsigned short)(__float_as_uint(v) >> 16);
+            l = f32_to_bf16_rne(v - bf16_to_f32(h));
+        }
         const int64_t base = (i >> 12) * (CV_WSTEP_BYTES / 2);
         const int off = r * 32 + cv_swz(k >> 3, r) * 8 + (k & 7);
         packed[base + off] = h;
@@ -87,13 +109,13 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
 }
 
 extern "C" int rick_conv_pack_weight(const float *w, int64_t s_co, int64_t s_ci, int64_t s_t, int Co, int Ci,
-                                     int nslices, float scale, void *packed, void *stream) {
-    if (!w || !packed || Co <= 0 || Ci <= 0 || nslices <= 0) return RICK_EINVAL;
+                                     int nslices, float scale, int split, void *packed, void *stream) {
+    if (!w || !packed || Co <= 0 || Ci <= 0 || nslices <= 0 || (split != 1 && split != 2)) return RICK_EINVAL;
     const int64_t total = (int64_t)cdiv(Co, CV_BM) * cdiv(Ci, CV_CK) * nslices * CV_BM * CV_CK;
     int64_t nb = cdiv64(total, 256);
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, s_co, s_ci, s_t, Co,
-                       Ci, nslices, scale, (unsigned short *)packed, total);
+                       Ci, nslices, scale, (unsigned short *)packed, total, split);
     RICK_LAUNCH_STATUS();
 }
 
@@ -105,6 +127,7 @@ struct ConvTiling {
     int dymin, dxmin;
     int PH, PW, NPP;            // patch extents (input pixels), NPP = nb*PH*PW
     int nchunks, ncot;
+    int nsplit, cps;            // igemm split-K over channel chunks: splits, chunks per split
 };
 
 static int ilog2_ceil(int v) {
@@ -142,7 +165,20 @@ static int make_tiling(const rick_conv_geom *g, int tile_positions, ConvTiling *
     t->NPP = t->nb * t->PH * t->PW;
     t->nchunks = cdiv(g->Ci, CV_CK);
     t->ncot = cdiv(g->Co, CV_BM);
+    t->nsplit = 1;
+    t->cps = t->nchunks;
     return 0;
+}
+
+// Split-K plan for launches with too few blocks to fill 256 CUs (the 4x4..32x32, 512-channel layers:
+// K = 4608 is long while there are only 4..128 output tiles).
+static void igemm_plan_split(ConvTiling *t) {
+    const int base = t->ntx * t->nty * t->ntn * t->ncot;
+    if (base >= 384 || t->nchunks < 2) return;
+    int want = cdiv(768, base);
+    if (want > t->nchunks) want = t->nchunks;
+    t->cps = cdiv(t->nchunks, want);
+    t->nsplit = cdiv(t->nchunks, t->cps);
 }
 
 // XCD-aware bijective remap of the linear block id: blocks that share an XCD (id % 8) get a
@@ -187,7 +223,7 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ x, const f
             }
         }
         uint2 hi, lo;
-        split4(v, hi, lo);
+        split4<SPLIT>(v, hi, lo);
         const int off = pix * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
         *reinterpret_cast<uint2 *>(ph + off) = hi;
         if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + off) = lo;
@@ -198,8 +234,8 @@ template <int SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restrict__ x,
                                                             const unsigned char *__restrict__ wpk,
                                                             float *__restrict__ out, const float *__restrict__ iscale,
-                                                            const float *__restrict__ oscale, const rick_conv_geom g,
-                                                            const ConvTiling t) {
+                                                            const float *__restrict__ oscale, float *__restrict__ ws,
+                                                            const rick_conv_geom g, const ConvTiling t) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *wbuf = smem;                               // [2][16 KB]
     unsigned char *ph = smem + 2 * CV_WSTEP_BYTES;            // [NPP][64 B]
@@ -208,8 +244,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
     const int nwg = gridDim.x;
     const int lid = xcd_remap(blockIdx.x, nwg);
     const int npos_tiles = t.ntx * t.nty * t.ntn;
-    const int cot = lid / npos_tiles;
-    int pt = lid - cot * npos_tiles;
+    int pt = lid % npos_tiles;
+    const int split = (lid / npos_tiles) % t.nsplit;
+    const int cot = lid / (npos_tiles * t.nsplit);
+    const int c_begin = split * t.cps;
+    const int c_end = c_begin + t.cps < t.nchunks ? c_begin + t.cps : t.nchunks;
     const int tx_i = pt % t.ntx;
     pt /= t.ntx;
     const int ty_i = pt % t.nty;
@@ -245,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 
-    const int nks = t.nchunks * g.ntaps;
+    const int nks = (c_end - c_begin) * g.ntaps;
     // packed-weight base of this co-tile; k-step (chunk c, tap tt) lives at block (c*nslices + wt[tt])
     const unsigned char *wbase = wpk + (int64_t)cot * t.nchunks * g.nslices * CV_WSTEP_BYTES;
     constexpr int WCOPY = (SPLIT == 2 ? CV_WSTEP_BYTES : CV_WTILE_BYTES) / (256 * 16);   // uint4 per thread: 4 or 2
@@ -270,15 +309,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
         }                                                               \
     } while (0)
     // ---- prologue: patch(0), W(0)
-    stage_patch<SPLIT>(x, iscale, ph, pl, g, t, n0, iy0, ix0, 0);
+    stage_patch<SPLIT>(x, iscale, ph, pl, g, t, n0, iy0, ix0, c_begin);
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(wbase + (int64_t)g.wt[0] * CV_WSTEP_BYTES);
+        const uint4 *src = reinterpret_cast<const uint4 *>(
+            wbase + ((int64_t)c_begin * g.nslices + g.wt[0]) * CV_WSTEP_BYTES);
         CV_WLOAD(src);
         CV_WSTORE(wbuf);
     }
     __syncthreads();
 
-    int chunk = 0, tap = 0;
+    int chunk = c_begin, tap = 0;
     for (int ks = 0; ks < nks; ks++) {
         // prefetch W(ks+1) into registers
         int nchunk = chunk, ntap = tap + 1;
@@ -338,6 +378,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
         const int px = pos & tw_mask, py = (pos >> t.tw_log2) & th_mask, nbi = pos >> (t.tw_log2 + t.th_log2);
         const int n = n0 + nbi, gy = gy0 + py, gx = gx0 + px;
         if (n >= g.N || gy >= g.GH || gx >= g.GW) continue;
+        if (t.nsplit > 1) {   // raw partial sums -> workspace [split][n, gy, gx][Co]; scaled in the reduce kernel
+            float *wrow = ws + (((int64_t)split * g.N + n) * g.GH * g.GW + (int64_t)gy * g.GW + gx) * g.Co;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int co = cot * CV_BM + wm * 64 + i * 16 + kg * 4;
+                if (co >= g.Co) continue;
+                if (covec) {
+                    *reinterpret_cast<float4 *>(wrow + co) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                } else {
+                    wrow[co] = acc[i][j][0];
+                    if (co + 1 < g.Co) wrow[co + 1] = acc[i][j][1];
+                    if (co + 2 < g.Co) wrow[co + 2] = acc[i][j][2];
+                    if (co + 3 < g.Co) wrow[co + 3] = acc[i][j][3];
+                }
+            }
+            continue;
+        }
         const int64_t opix = ((int64_t)n * g.OH + gy * g.os + g.oy0) * g.OW + gx * g.os + g.ox0;
         float *orow = out + opix * g.Co;
 #pragma unroll
@@ -364,6 +421,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
     }
 }
 
+// out[n, pix(gy,gx), co] = alpha * oscale[n,co] * sum_s ws[s][n,gy,gx][co]
+__global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
+                                                                  const float *__restrict__ oscale, rick_conv_geom g,
+                                                                  int nsplit) {
+    const int64_t per = (int64_t)g.N * g.GH * g.GW * g.Co;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+        const int co = (int)(i % g.Co);
+        int64_t pos = i / g.Co;
+        const int gx = (int)(pos % g.GW);
+        pos /= g.GW;
+        const int gy = (int)(pos % g.GH);
+        const int n = (int)(pos / g.GH);
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; sp++) s += ws[sp * per + i];
+        s *= g.alpha;
+        if (oscale) s *= oscale[(int64_t)n * g.Co + co];
+        out[(((int64_t)n * g.OH + gy * g.os + g.oy0) * g.OW + gx * g.os + g.ox0) * g.Co + co] = s;
+    }
+}
+
 static int check_geom(const rick_conv_geom *g) {
     if (!g || g->N <= 0 || g->IH <= 0 || g->IW <= 0 || g->Ci <= 0 || g->OH <= 0 || g->OW <= 0 || g->Co <= 0 ||
         g->GH <= 0 || g->GW <= 0 || g->is <= 0 || g->os <= 0 || g->ntaps < 1 || g->ntaps > RICK_MAX_TAPS ||
@@ -375,17 +452,28 @@ static int check_geom(const rick_conv_geom *g) {
     return 0;
 }
 
+extern "C" int64_t rick_conv_igemm_workspace_bytes(const rick_conv_geom *g) {
+    if (check_geom(g)) return -1;
+    ConvTiling t;
+    if (make_tiling(g, CV_BN, &t)) return -1;
+    igemm_plan_split(&t);
+    return t.nsplit > 1 ? (int64_t)t.nsplit * g->N * g->GH * g->GW * g->Co * 4 : 0;
+}
+
 extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *out, const float *iscale,
-                                   const float *oscale, const rick_conv_geom *g, void *stream) {
+                                   const float *oscale, const rick_conv_geom *g, void *workspace, void *stream) {
     if (!x || !packed_w || !out || check_geom(g)) return RICK_EINVAL;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed_w) % 16) return RICK_EINVAL;
     ConvTiling t;
     if (make_tiling(g, CV_BN, &t)) return RICK_EINVAL;
+    igemm_plan_split(&t);
+    if (t.nsplit > 1 && (!workspace || ((uintptr_t)workspace % 16))) return RICK_EINVAL;
     const size_t lds = 2 * CV_WSTEP_BYTES + 2 * (size_t)((t.NPP * 64 + 15) & ~15);
     if (lds > 160 * 1024) return RICK_EINVAL;
-    const int64_t nwg = (int64_t)t.ntx * t.nty * t.ntn * t.ncot;
+    const int64_t nwg = (int64_t)t.ntx * t.nty * t.ntn * t.ncot * t.nsplit;
     if (nwg > 0x7fffffff) return RICK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    float *ws = (float *)workspace;
     if (g->split == 2) {
         static bool attr2 = false;
         if (!attr2) {
@@ -393,7 +481,7 @@ extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *
             attr2 = true;
         }
         hipLaunchKernelGGL(conv_igemm_kernel<2>, dim3((unsigned)nwg), dim3(256), lds, st, x,
-                           (const unsigned char *)packed_w, out, iscale, oscale, *g, t);
+                           (const unsigned char *)packed_w, out, iscale, oscale, ws, *g, t);
     } else {
         static bool attr1 = false;
         if (!attr1) {
@@ -401,7 +489,13 @@ extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *
             attr1 = true;
         }
         hipLaunchKernelGGL(conv_igemm_kernel<1>, dim3((unsigned)nwg), dim3(256), lds, st, x,
-                           (const unsigned char *)packed_w, out, iscale, oscale, *g, t);
+                           (const unsigned char *)packed_w, out, iscale, oscale, ws, *g, t);
+    }
+    if (t.nsplit > 1) {
+        const int64_t per = (int64_t)g->N * g->GH * g->GW * g->Co;
+        int64_t nb = cdiv64(per, 256);
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, t.nsplit);
     }
     RICK_LAUNCH_STATUS();
 }
@@ -416,6 +510,7 @@ extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *
 //   x  patch : same image as the igemm kernel ([pixel][32 ci], cv_swz slots)
 #define WG_TILE 64
 #define WG_GY_BYTES (WG_TILE * CV_BM * 2)   // 16 KB (one of hi / lo)
+#define WG_PMAX 12                          // patch float4 per thread held in registers (NPP <= 384 pixels)
 
 typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
 
@@ -473,7 +568,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 #pragma unroll
         for (int tt = 0; tt < NT; tt++) acc[i][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = tile_begin; tile < tile_end; tile++) {
+    // Software pipeline: the fp32 gy tile (8 float4 / thread) and input patch (<= WG_PMAX float4 / thread)
+    // of tile t+1 are fetched into registers while the MFMAs of tile t run; conversion to bf16 hi/lo and
+    // the LDS writes happen after the barrier that retires tile t.
+    float4 gq[8];
+    float4 pq[WG_PMAX];
+    const int p_items = t.NPP * 8;
+    const int phw = t.PH * t.PW;
+    const bool xvec = (g.Ci & 3) == 0, gvec = (g.Co & 3) == 0;
+
+    auto load_tile = [&](int tile) {
         int pt = tile;
         const int tx_i = pt % t.ntx;
         pt /= t.ntx;
@@ -481,9 +585,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         const int tn_i = pt / t.nty;
         const int gx0 = tx_i << t.tw_log2, gy0 = ty_i << t.th_log2, n0 = tn_i * t.nb;
         const int iy0 = gy0 * g.is + t.dymin, ix0 = gx0 * g.is + t.dxmin;
-        __syncthreads();   // previous tile fully consumed
-        // ---- stage gy tile: 64 positions x 128 co
-        for (int it = threadIdx.x; it < WG_TILE * 32; it += 256) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int it = threadIdx.x + k * 256;
             const int r = it >> 5, c4 = it & 31;
             const int px = r & tw_mask, py = (r >> t.tw_log2) & th_mask, nbi = r >> (t.tw_log2 + t.th_log2);
             const int n = n0 + nbi, yy = gy0 + py, xx = gx0 + px;
@@ -492,7 +596,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             if (n < g.N && yy < g.GH && xx < g.GW && co < g.Co) {
                 const int64_t opix = ((int64_t)n * g.OH + yy * g.os + g.oy0) * g.OW + xx * g.os + g.ox0;
                 const float *src = gy + opix * g.Co + co;
-                if ((g.Co & 3) == 0) {
+                if (gvec) {
                     v = *reinterpret_cast<const float4 *>(src);
                 } else {
                     v.x = src[0];
@@ -508,14 +612,72 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                     if (co + 3 < g.Co) v.w *= sp[3];
                 }
             }
+            gq[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < WG_PMAX; k++) {
+            const int it = threadIdx.x + k * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < p_items) {
+                const int pix = it >> 3, c4 = it & 7;
+                const int nbi = pix / phw;
+                const int rem = pix - nbi * phw;
+                const int py = rem / t.PW, px = rem - py * t.PW;
+                const int n = n0 + nbi, iy = iy0 + py, ix = ix0 + px;
+                const int ci = chunk * CV_CK + c4 * 4;
+                if (n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW && ci < g.Ci) {
+                    const float *src = x + (((int64_t)n * g.IH + iy) * g.IW + ix) * g.Ci + ci;
+                    if (xvec) {
+                        v = *reinterpret_cast<const float4 *>(src);
+                    } else {
+                        v.x = src[0];
+                        if (ci + 1 < g.Ci) v.y = src[1];
+                        if (ci + 2 < g.Ci) v.z = src[2];
+                        if (ci + 3 < g.Ci) v.w = src[3];
+                    }
+                    if (bscale) {
+                        const float *sp = bscale + (int64_t)n * g.Ci + ci;
+                        v.x *= sp[0];
+                        if (ci + 1 < g.Ci) v.y *= sp[1];
+                        if (ci + 2 < g.Ci) v.z *= sp[2];
+                        if (ci + 3 < g.Ci) v.w *= sp[3];
+                    }
+                }
+            }
+            pq[k] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int it = threadIdx.x + k * 256;
+            const int r = it >> 5, c4 = it & 31;
             uint2 hi, lo;
-            split4(v, hi, lo);
+            split4<SPLIT>(gq[k], hi, lo);
             const int off = r * 256 + ((c4 * 8) ^ (wg_key(r) * 32));
             *reinterpret_cast<uint2 *>(gh + off) = hi;
             if (SPLIT == 2) *reinterpret_cast<uint2 *>(gl + off) = lo;
         }
-        stage_patch<SPLIT>(x, bscale, ph, pl, g, t, n0, iy0, ix0, chunk);
+#pragma unroll
+        for (int k = 0; k < WG_PMAX; k++) {
+            const int it = threadIdx.x + k * 256;
+            if (it < p_items) {
+                const int pix = it >> 3, c4 = it & 7;
+                uint2 hi, lo;
+                split4<SPLIT>(pq[k], hi, lo);
+                const int off = pix * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
+                *reinterpret_cast<uint2 *>(ph + off) = hi;
+                if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + off) = lo;
+            }
+        }
+    };
+
+    if (tile_begin < tile_end) load_tile(tile_begin);
+    for (int tile = tile_begin; tile < tile_end; tile++) {
+        __syncthreads();   // previous tile fully consumed
+        store_tile();
         __syncthreads();
+        if (tile + 1 < tile_end) load_tile(tile + 1);
         // ---- two 32-deep k-steps
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
@@ -633,7 +795,7 @@ extern "C" int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw, i
     int nsplit, tps;
     wgrad_plan(g, &t, &nsplit, &tps);
     const size_t lds = 2 * WG_GY_BYTES + 2 * (size_t)((t.NPP * 64 + 15) & ~15);
-    if (lds > 160 * 1024) return RICK_EINVAL;
+    if (lds > 160 * 1024 || t.NPP * 8 > WG_PMAX * 256) return RICK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
     if (g->ntaps == 1) launch_wgrad<1>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);

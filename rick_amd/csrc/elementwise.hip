@@ -170,14 +170,24 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restri
     }
 }
 
-// out[c] = sum_b partials[b*(stride) + c]
+// out[c] = sum_b partials[b*stride + col0 + c].  Block = 32 columns x 8 partial-row groups; the 8
+// group sums are combined through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void partial_colsum_kernel(const float *__restrict__ partials, float *__restrict__ out,
                                                              int nb, int stride, int ncols, int col0) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= ncols) return;
+    __shared__ float red[256];
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int b = 0; b < nb; b++) s += partials[(int64_t)b * stride + col0 + c];
-    out[c] = s;
+    if (c < ncols)
+        for (int b = grp; b < nb; b += 8) s += partials[(int64_t)b * stride + col0 + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && c < ncols) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; g++) t += red[g * 32 + cl];
+        out[c] = t;
+    }
 }
 
 extern "C" int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx, float *gb, float *gnw,
@@ -198,7 +208,7 @@ extern "C" int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx
     else
         hipLaunchKernelGGL(bias_act_bwd_kernel<false>, dim3(nb), dim3(256), lds, st, g, ref, gx, nz, partials, rows, C,
                            rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0);
-    if (gb) hipLaunchKernelGGL(partial_colsum_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partials, gb, nb, C + 1, C, 0);
+    if (gb) hipLaunchKernelGGL(partial_colsum_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, partials, gb, nb, C + 1, C, 0);
     if (gnw) hipLaunchKernelGGL(partial_colsum_kernel, dim3(1), dim3(256), 0, st, partials, gnw, nb, C + 1, 1, C);
     RICK_LAUNCH_STATUS();
 }
@@ -278,7 +288,7 @@ extern "C" int rick_hw_dot_f32(const float *a, const float *b, float *d, int N, 
     hipStream_t st = (hipStream_t)stream;
     const int nb = rick_hw_dot_blocks(P);
     hipLaunchKernelGGL(hw_dot_kernel, dim3(nb, N), dim3(256), 256 * sizeof(float), st, a, b, partials, P, C);
-    hipLaunchKernelGGL(partial_colsum_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, st, partials, d, nb, N * C, N * C, 0);
+    hipLaunchKernelGGL(partial_colsum_kernel, dim3(cdiv(N * C, 32)), dim3(256), 0, st, partials, d, nb, N * C, N * C, 0);
     RICK_LAUNCH_STATUS();
 }
 

@@ -103,7 +103,7 @@ def _pack(w, scale, key=None):
     w, s_o, s_i, s_t = _w_strides(w)
     nbytes = lib.rick_conv_packed_bytes(O, I, kh * kw)
     buf = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
-    check(lib.rick_conv_pack_weight(ptr(w), s_o, s_i, s_t, O, I, kh * kw, float(scale), ptr(buf), stream_ptr()),
+    check(lib.rick_conv_pack_weight(ptr(w), s_o, s_i, s_t, O, I, kh * kw, float(scale), _SPLIT, ptr(buf), stream_ptr()),
           'rick_conv_pack_weight')
     if key is not None:
         if ent is None:
@@ -129,6 +129,14 @@ def _geom(N, IH, IW, Ci, OH, OW, Co, GH, GW, is_, os_, oy0, ox0, taps, nslices, 
     return g
 
 
+def _igemm_ws(g, like):
+    """Split-K workspace for launches with few output tiles (None when the kernel does not need one)."""
+    nbytes = lib.rick_conv_igemm_workspace_bytes(ctypes.byref(g))
+    if nbytes < 0:
+        raise RuntimeError('rick_conv_igemm_workspace_bytes: invalid geometry')
+    return torch.empty(nbytes, device=like.device, dtype=torch.uint8) if nbytes else None
+
+
 def conv_out_size(i, k, s, p):
     return (i + 2 * p - k) // s + 1
 
@@ -142,7 +150,7 @@ def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0):
     taps = [(ky - p, kx - p, ky * kw + kx) for ky in range(kh) for kx in range(kw)]
     g = _geom(N, IH, IW, I, OH, OW, O, OH, OW, s, 1, 0, 0, taps, kh * kw, alpha)
     check(_launch('igemm', 2.0 * N * OH * OW * O * I * kh * kw, lib.rick_conv_igemm_f32, ptr(x), ptr(wp), ptr(y),
-                  ptr(iscale), ptr(oscale), ctypes.byref(g), stream_ptr()), 'rick_conv_igemm_f32')
+                  ptr(iscale), ptr(oscale), ctypes.byref(g), ptr(_igemm_ws(g, x)), stream_ptr()), 'rick_conv_igemm_f32')
     return y
 
 
@@ -169,7 +177,8 @@ def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alph
             continue
         g = _geom(N, IH, IW, I, OH, OW, O, GH, GW, 1, s, py, px, taps, kh * kw, alpha)
         check(_launch('igemm', 2.0 * N * GH * GW * O * I * len(taps), lib.rick_conv_igemm_f32, ptr(x), ptr(wp), ptr(y),
-                      ptr(iscale), ptr(oscale), ctypes.byref(g), stream_ptr()), 'rick_conv_igemm_f32')
+                      ptr(iscale), ptr(oscale), ctypes.byref(g), ptr(_igemm_ws(g, x)), stream_ptr()),
+              'rick_conv_igemm_f32')
     return y
 
 
