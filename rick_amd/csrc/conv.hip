@@ -23,6 +23,7 @@
 // the row: slot = kg ^ (((row>>2)&1)<<1)  -> conflict-free for 16 consecutive rows at any
 // offset (checked by simulation against the gfx950 ds_read_b128 lane groups).
 #include "common.h"
+#include <stdlib.h>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
@@ -128,6 +129,7 @@ struct ConvTiling {
     int PH, PW, NPP;            // patch extents (input pixels), NPP = nb*PH*PW
     int nchunks, ncot;
     int nsplit, cps;            // igemm split-K over channel chunks: splits, chunks per split
+    int debug;                  // ablation switches for tools/bench_conv.py (RICK_CONV_DEBUG); 0 in production
 };
 
 static int ilog2_ceil(int v) {
@@ -167,6 +169,8 @@ static int make_tiling(const rick_conv_geom *g, int tile_positions, ConvTiling *
     t->ncot = cdiv(g->Co, CV_BM);
     t->nsplit = 1;
     t->cps = t->nchunks;
+    const char *dbg = getenv("RICK_CONV_DEBUG");
+    t->debug = dbg ? atoi(dbg) : 0;
     return 0;
 }
 
@@ -188,49 +192,41 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-// Stage the fp32 input patch of one 32-channel chunk into LDS as bf16 hi (+ lo).
-template <int SPLIT>
-__device__ __forceinline__ void stage_patch(const float *__restrict__ x, const float *__restrict__ iscale,
-                                            unsigned char *ph, unsigned char *pl, const rick_conv_geom &g,
-                                            const ConvTiling &t, int n0, int iy0, int ix0, int chunk) {
-    const int items = t.NPP * 8;
+// Patch pixel -> (image-in-tile, row, col) table, built once per block so the staging loops need no
+// integer divisions: entry = nbi << 20 | py << 10 | px.
+__device__ __forceinline__ void build_patch_table(unsigned *ptab, const ConvTiling &t) {
     const int phw = t.PH * t.PW;
-    const bool vec = (g.Ci & 3) == 0;
-    for (int it = threadIdx.x; it < items; it += 256) {
-        const int pix = it >> 3, c4 = it & 7;
+    for (int pix = threadIdx.x; pix < t.NPP; pix += 256) {
         const int nbi = pix / phw;
         const int rem = pix - nbi * phw;
         const int py = rem / t.PW, px = rem - py * t.PW;
-        const int n = n0 + nbi, iy = iy0 + py, ix = ix0 + px;
-        const int ci = chunk * CV_CK + c4 * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW && ci < g.Ci) {
-            const float *src = x + (((int64_t)n * g.IH + iy) * g.IW + ix) * g.Ci + ci;
-            if (vec) {
-                v = *reinterpret_cast<const float4 *>(src);
-            } else {
-                v.x = src[0];
-                if (ci + 1 < g.Ci) v.y = src[1];
-                if (ci + 2 < g.Ci) v.z = src[2];
-                if (ci + 3 < g.Ci) v.w = src[3];
-            }
-            if (iscale) {
-                const float *sp = iscale + (int64_t)n * g.Ci + ci;
-                v.x *= sp[0];
-                if (ci + 1 < g.Ci) v.y *= sp[1];
-                if (ci + 2 < g.Ci) v.z *= sp[2];
-                if (ci + 3 < g.Ci) v.w *= sp[3];
-            }
-        }
-        uint2 hi, lo;
-        split4<SPLIT>(v, hi, lo);
-        const int off = pix * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
-        *reinterpret_cast<uint2 *>(ph + off) = hi;
-        if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + off) = lo;
+        ptab[pix] = ((unsigned)nbi << 20) | ((unsigned)py << 10) | (unsigned)px;
     }
 }
 
-template <int SPLIT>
+// 16-byte load of 4 consecutive channels.  VEC (channel count % 4 == 0): one float4 load from an address
+// that is always safe (callers substitute the tensor base for out-of-range items) — no branch, so the
+// compiler has no reason to wait vmcnt(0) per element.  !VEC: guarded scalar loads (odd channel counts).
+template <bool VEC>
+__device__ __forceinline__ float4 load4(const float *p, bool ok, int c, int C) {
+    if (VEC) return *reinterpret_cast<const float4 *>(p);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+        v.x = p[0];
+        if (c + 1 < C) v.y = p[1];
+        if (c + 2 < C) v.z = p[2];
+        if (c + 3 < C) v.w = p[3];
+    }
+    return v;
+}
+
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+
+// ==========================================================================================
+// Forward / data-gradient kernel.
+#define IG_PMAX 10   // patch float4 per thread prefetched in registers (covers NPP <= 320 pixels)
+
+template <int SPLIT, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restrict__ x,
                                                             const unsigned char *__restrict__ wpk,
                                                             float *__restrict__ out, const float *__restrict__ iscale,
@@ -240,6 +236,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
     unsigned char *wbuf = smem;                               // [2][16 KB]
     unsigned char *ph = smem + 2 * CV_WSTEP_BYTES;            // [NPP][64 B]
     unsigned char *pl = ph + ((t.NPP * 64 + 15) & ~15);
+    unsigned *ptab = reinterpret_cast<unsigned *>(pl + ((t.NPP * 64 + 15) & ~15));   // [NPP]
+    build_patch_table(ptab, t);
+    __syncthreads();
 
     const int nwg = gridDim.x;
     const int lid = xcd_remap(blockIdx.x, nwg);
@@ -260,14 +259,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, kg = lane >> 4;
 
-    // per-lane LDS byte offsets of the A rows (weights)
     int a_off[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int row = wm * 64 + i * 16 + l15;
         a_off[i] = row * 64 + cv_swz(kg, row) * 16;
     }
-    // per-lane patch pixel index of the 4 position columns
     int pb[4];
     const int tw_mask = (1 << t.tw_log2) - 1, th_mask = (1 << t.th_log2) - 1;
 #pragma unroll
@@ -277,18 +274,84 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
         pb[j] = (nbi * t.PH + py * g.is) * t.PW + px * g.is;
     }
 
+    // ---- patch staging state.  The tile is fixed for the block, so validity, source offset (relative to
+    // the tile-origin pointer) and LDS offset of each of this thread's patch items are computed once.
+    const int p_items = t.NPP * 8;
+    const int c4 = threadIdx.x & 7;                      // 256 % 8 == 0: same channel quad for all items
+    const float *xt = x + (((int64_t)n0 * g.IH + iy0) * g.IW + ix0) * g.Ci + c4 * 4;
+    int p_rel[IG_PMAX], p_lds[IG_PMAX], p_sc[IG_PMAX];
+    unsigned p_ok = 0;
+    float4 pq[IG_PMAX];
+#pragma unroll
+    for (int k = 0; k < IG_PMAX; k++) {
+        const int pix = (threadIdx.x >> 3) + 32 * k;
+        p_rel[k] = 0;
+        p_sc[k] = 0;
+        p_lds[k] = pix * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
+        if (pix < t.NPP) {
+            const unsigned e = ptab[pix];
+            const int nbi = (int)(e >> 20), py = (int)((e >> 10) & 1023), px = (int)(e & 1023);
+            const int n = n0 + nbi, iy = iy0 + py, ix = ix0 + px;
+            if (n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
+                p_ok |= 1u << k;
+                p_rel[k] = ((nbi * g.IH + py) * g.IW + px) * g.Ci;
+                p_sc[k] = n * g.Ci + c4 * 4;
+            }
+        }
+    }
+    unsigned cur_ok = 0;      // validity of the items currently held in pq (p_ok restricted by ci < Ci)
+    int cur_ci = 0;
+    auto issue_patch = [&](int chunk) {   // raw loads only; consumers live in commit_patch
+        const int ci = chunk * CV_CK + c4 * 4;
+        cur_ci = ci;
+        cur_ok = ci < g.Ci ? p_ok : 0u;
+#pragma unroll
+        for (int k = 0; k < IG_PMAX; k++) {
+            const bool ok = (cur_ok >> k) & 1u;
+            pq[k] = load4<VEC>(ok ? xt + p_rel[k] + chunk * CV_CK : x, ok, ci, g.Ci);
+        }
+    };
+    auto commit_patch = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < IG_PMAX; k++) {
+            const bool ok = (cur_ok >> k) & 1u;
+            float4 v = pq[k];
+            if (iscale) v = mul4(v, load4<VEC>(ok ? iscale + p_sc[k] + chunk * CV_CK : iscale, ok, cur_ci, g.Ci));
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 hi, lo;
+            split4<SPLIT>(v, hi, lo);
+            if ((threadIdx.x >> 3) + 32 * k < t.NPP) {
+                *reinterpret_cast<uint2 *>(ph + p_lds[k]) = hi;
+                if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds[k]) = lo;
+            }
+        }
+        // patches larger than IG_PMAX*32 pixels (stride-2 geometry): remaining items, synchronously
+        for (int it = threadIdx.x + 256 * IG_PMAX; it < p_items; it += 256) {
+            const int pix = it >> 3;
+            const unsigned e = ptab[pix];
+            const int n = n0 + (int)(e >> 20), iy = iy0 + (int)((e >> 10) & 1023), ix = ix0 + (int)(e & 1023);
+            const int ci = chunk * CV_CK + c4 * 4;
+            const bool ok = n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW && ci < g.Ci;
+            float4 v = load4<VEC>(ok ? x + (((int64_t)n * g.IH + iy) * g.IW + ix) * g.Ci + ci : x, ok, ci, g.Ci);
+            if (iscale) v = mul4(v, load4<VEC>(ok ? iscale + (int64_t)n * g.Ci + ci : iscale, ok, ci, g.Ci));
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 hi, lo;
+            split4<SPLIT>(v, hi, lo);
+            const int off = pix * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
+            *reinterpret_cast<uint2 *>(ph + off) = hi;
+            if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + off) = lo;
+        }
+    };
+
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-
     const int nks = (c_end - c_begin) * g.ntaps;
-    // packed-weight base of this co-tile; k-step (chunk c, tap tt) lives at block (c*nslices + wt[tt])
     const unsigned char *wbase = wpk + (int64_t)cot * t.nchunks * g.nslices * CV_WSTEP_BYTES;
     constexpr int WCOPY = (SPLIT == 2 ? CV_WSTEP_BYTES : CV_WTILE_BYTES) / (256 * 16);   // uint4 per thread: 4 or 2
-
     uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;   // named (not an array): stays in VGPRs
 #define CV_WLOAD(src)                                                   \
     do {                                                                \
@@ -308,28 +371,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
             reinterpret_cast<uint4 *>(dst)[768 + threadIdx.x] = w3;     \
         }                                                               \
     } while (0)
-    // ---- prologue: patch(0), W(0)
-    stage_patch<SPLIT>(x, iscale, ph, pl, g, t, n0, iy0, ix0, c_begin);
+
+    // ---- prologue: patch(c_begin), W(0)
+    issue_patch(c_begin);
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(
             wbase + ((int64_t)c_begin * g.nslices + g.wt[0]) * CV_WSTEP_BYTES);
         CV_WLOAD(src);
         CV_WSTORE(wbuf);
     }
+    commit_patch(c_begin);
     __syncthreads();
 
     int chunk = c_begin, tap = 0;
     for (int ks = 0; ks < nks; ks++) {
-        // prefetch W(ks+1) into registers
         int nchunk = chunk, ntap = tap + 1;
         if (ntap == g.ntaps) { ntap = 0; nchunk++; }
         const bool more = ks + 1 < nks;
-        if (more) {
+        if (more) {   // weights of k-step ks+1 -> registers
             const uint4 *src = reinterpret_cast<const uint4 *>(
                 wbase + ((int64_t)nchunk * g.nslices + g.wt[ntap]) * CV_WSTEP_BYTES);
             CV_WLOAD(src);
         }
-        // ---- compute k-step ks
+        if (tap == 0 && chunk + 1 < c_end) issue_patch(chunk + 1);   // next chunk's patch -> registers
+        __builtin_amdgcn_sched_barrier(0);   // prefetches are issued before the MFMAs, consumed after
         {
             const unsigned char *wb = wbuf + (ks & 1) * CV_WSTEP_BYTES;
             const int toff = (g.dy[tap] - t.dymin) * t.PW + (g.dx[tap] - t.dxmin);
@@ -358,9 +423,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
                 }
         }
         if (more) {
-            if (ntap == 0) {   // next k-step starts a new channel chunk: restage the patch
+            if (ntap == 0) {   // next k-step starts a new channel chunk: all waves are done with the patch
                 __syncthreads();
-                stage_patch<SPLIT>(x, iscale, ph, pl, g, t, n0, iy0, ix0, nchunk);
+                commit_patch(nchunk);
             }
             unsigned char *wd = wbuf + ((ks + 1) & 1) * CV_WSTEP_BYTES;
             CV_WSTORE(wd);
@@ -370,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
         tap = ntap;
     }
 
-    // ---- epilogue: out[n, pix, co] = alpha * oscale[n,co] * acc
+    // ---- epilogue
     const bool covec = (g.Co & 3) == 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -449,6 +514,9 @@ static int check_geom(const rick_conv_geom *g) {
     for (int i = 0; i < g->ntaps; i++)
         if (g->wt[i] < 0 || g->wt[i] >= g->nslices) return RICK_EINVAL;
     if ((g->GH - 1) * g->os + g->oy0 >= g->OH || (g->GW - 1) * g->os + g->ox0 >= g->OW) return RICK_EINVAL;
+    // 32-bit element offsets are used inside a tile
+    if ((int64_t)g->N * g->IH * g->IW * g->Ci >= (1LL << 31) || (int64_t)g->N * g->OH * g->OW * g->Co >= (1LL << 31))
+        return RICK_EINVAL;
     return 0;
 }
 
@@ -460,36 +528,37 @@ extern "C" int64_t rick_conv_igemm_workspace_bytes(const rick_conv_geom *g) {
     return t.nsplit > 1 ? (int64_t)t.nsplit * g->N * g->GH * g->GW * g->Co * 4 : 0;
 }
 
+template <int SPLIT, bool VEC>
+static void launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
+                         const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
+                         const ConvTiling &t) {
+    (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<SPLIT, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    hipLaunchKernelGGL((conv_igemm_kernel<SPLIT, VEC>), dim3(nwg), dim3(256), lds, st, x, wp, out, iscale, oscale, ws, *g, t);
+}
+
 extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *out, const float *iscale,
                                    const float *oscale, const rick_conv_geom *g, void *workspace, void *stream) {
     if (!x || !packed_w || !out || check_geom(g)) return RICK_EINVAL;
-    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed_w) % 16) return RICK_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed_w | (uintptr_t)(iscale ? iscale : x)) % 16) return RICK_EINVAL;
     ConvTiling t;
     if (make_tiling(g, CV_BN, &t)) return RICK_EINVAL;
     igemm_plan_split(&t);
     if (t.nsplit > 1 && (!workspace || ((uintptr_t)workspace % 16))) return RICK_EINVAL;
-    const size_t lds = 2 * CV_WSTEP_BYTES + 2 * (size_t)((t.NPP * 64 + 15) & ~15);
-    if (lds > 160 * 1024) return RICK_EINVAL;
+    const size_t lds = 2 * CV_WSTEP_BYTES + 2 * (size_t)((t.NPP * 64 + 15) & ~15) + (size_t)t.NPP * 4;
+    if (lds > 160 * 1024 || t.PH > 1023 || t.PW > 1023) return RICK_EINVAL;
     const int64_t nwg = (int64_t)t.ntx * t.nty * t.ntn * t.ncot * t.nsplit;
     if (nwg > 0x7fffffff) return RICK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
+    const unsigned char *wp = (const unsigned char *)packed_w;
+    const bool vec = (g->Ci & 3) == 0;
     if (g->split == 2) {
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr2 = true;
-        }
-        hipLaunchKernelGGL(conv_igemm_kernel<2>, dim3((unsigned)nwg), dim3(256), lds, st, x,
-                           (const unsigned char *)packed_w, out, iscale, oscale, ws, *g, t);
+        if (vec) launch_igemm<2, true>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
+        else launch_igemm<2, false>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
     } else {
-        static bool attr1 = false;
-        if (!attr1) {
-            (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr1 = true;
-        }
-        hipLaunchKernelGGL(conv_igemm_kernel<1>, dim3((unsigned)nwg), dim3(256), lds, st, x,
-                           (const unsigned char *)packed_w, out, iscale, oscale, ws, *g, t);
+        if (vec) launch_igemm<1, true>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
+        else launch_igemm<1, false>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
     }
     if (t.nsplit > 1) {
         const int64_t per = (int64_t)g->N * g->GH * g->GW * g->Co;
@@ -510,7 +579,6 @@ extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *
 //   x  patch : same image as the igemm kernel ([pixel][32 ci], cv_swz slots)
 #define WG_TILE 64
 #define WG_GY_BYTES (WG_TILE * CV_BM * 2)   // 16 KB (one of hi / lo)
-#define WG_PMAX 12                          // patch float4 per thread held in registers (NPP <= 384 pixels)
 
 typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
 
@@ -522,7 +590,7 @@ __device__ __forceinline__ bf16x8 tr_read2(const unsigned char *base, int off0, 
 
 __device__ __forceinline__ int wg_key(int r) { return (((r >> 3) & 1) << 2) + (r & 3); }
 
-template <int NT, int SPLIT>
+template <int NT, int SPLIT, bool VEC, int PMAX>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                          float *__restrict__ ws, const float *__restrict__ ascale,
                                                          const float *__restrict__ bscale, const rick_conv_geom g,
@@ -532,11 +600,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     unsigned char *gl = smem + WG_GY_BYTES;            // gy lo
     unsigned char *ph = smem + 2 * WG_GY_BYTES;
     unsigned char *pl = ph + ((t.NPP * 64 + 15) & ~15);
+    unsigned *ptab = reinterpret_cast<unsigned *>(pl + ((t.NPP * 64 + 15) & ~15));
+    build_patch_table(ptab, t);
+    __syncthreads();
 
-    const int lid = blockIdx.x;
-    const int chunk = lid % t.nchunks;
-    const int cot = (lid / t.nchunks) % t.ncot;
-    const int split = lid / (t.nchunks * t.ncot);
+    // XCD-aware mapping: blocks with equal blockIdx % 8 share an XCD (and its L2).  Every XCD owns its own
+    // slices of the position range; all (co-tile, chunk) blocks of a slice run there, so a gy tile is fetched
+    // into ONE L2 and re-used by the nchunks blocks that need it.  (Placement only affects speed.)
+    int split, cc;
+    if ((nsplit & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, spx = nsplit >> 3;
+        split = xcd + 8 * (j % spx);
+        cc = j / spx;
+    } else {
+        split = blockIdx.x / (t.nchunks * t.ncot);
+        cc = blockIdx.x % (t.nchunks * t.ncot);
+    }
+    const int chunk = cc % t.nchunks;
+    const int cot = cc / t.nchunks;
     const int ntiles = t.ntx * t.nty * t.ntn;
     const int tile_begin = split * tiles_per_split;
     const int tile_end = tile_begin + tiles_per_split < ntiles ? tile_begin + tiles_per_split : ntiles;
@@ -546,10 +627,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     const int G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
     const int tw_mask = (1 << t.tw_log2) - 1, th_mask = (1 << t.th_log2) - 1;
 
-    // A (gy^T) row byte offsets for the 4 (kk, h) row groups this lane addresses, column part per co tile
-    int a_row[2][2];     // [kk][h] -> r*256, with key
-    int a_key[2][2];
-    int pbase[2][2];     // patch pixel of position r
+    int a_row[2][2], a_key[2][2], pbase[2][2];
 #pragma unroll
     for (int kk = 0; kk < 2; kk++)
 #pragma unroll
@@ -568,15 +646,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 #pragma unroll
         for (int tt = 0; tt < NT; tt++) acc[i][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // Software pipeline: the fp32 gy tile (8 float4 / thread) and input patch (<= WG_PMAX float4 / thread)
-    // of tile t+1 are fetched into registers while the MFMAs of tile t run; conversion to bf16 hi/lo and
-    // the LDS writes happen after the barrier that retires tile t.
+    // ---- staging state (tile-invariant parts computed once per thread)
     float4 gq[8];
-    float4 pq[WG_PMAX];
-    const int p_items = t.NPP * 8;
-    const int phw = t.PH * t.PW;
-    const bool xvec = (g.Ci & 3) == 0, gvec = (g.Co & 3) == 0;
+    float4 pq[PMAX];
+    int g_rel[8], g_lds[8], p_rel[PMAX], p_lds[PMAX];
+    unsigned g_pyx[8], p_pyx[PMAX];
+    const int gc4 = threadIdx.x & 31, pc4 = threadIdx.x & 7;
+    const int co_base = cot * CV_BM, ci_base = chunk * CV_CK;
+    const int gco = co_base + gc4 * 4, pci = ci_base + pc4 * 4;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int r = (threadIdx.x >> 5) + 8 * k;
+        const int px = r & tw_mask, py = (r >> t.tw_log2) & th_mask, nbi = r >> (t.tw_log2 + t.th_log2);
+        g_rel[k] = ((nbi * g.OH + py * g.os) * g.OW + px * g.os) * g.Co;
+        g_pyx[k] = gco < g.Co ? (((unsigned)nbi << 20) | ((unsigned)py << 10) | (unsigned)px) : 0xffffffffu;
+        g_lds[k] = r * 256 + ((gc4 * 8) ^ (wg_key(r) * 32));
+    }
+#pragma unroll
+    for (int k = 0; k < PMAX; k++) {
+        const int pix = (threadIdx.x >> 3) + 32 * k;
+        p_rel[k] = 0;
+        p_pyx[k] = 0xffffffffu;
+        p_lds[k] = pix * 64 + cv_swz(pc4 >> 1, pix) * 16 + (pc4 & 1) * 8;
+        if (pix < t.NPP) {
+            const unsigned e = ptab[pix];
+            p_rel[k] = (((int)(e >> 20) * g.IH + (int)((e >> 10) & 1023)) * g.IW + (int)(e & 1023)) * g.Ci;
+            if (pci < g.Ci) p_pyx[k] = e;
+        }
+    }
 
+    // load_tile only ISSUES raw 16-byte loads (safe address for out-of-range items) and records a validity
+    // bitmask; every consumer of the loaded registers (scale, zero-select, bf16 split) lives in store_tile,
+    // which runs after the MFMA phase of the previous tile — so the loads stay in flight behind the MFMAs.
+    unsigned okmask = 0;
+    int st_n0 = 0;
     auto load_tile = [&](int tile) {
         int pt = tile;
         const int tx_i = pt % t.ntx;
@@ -585,89 +688,54 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         const int tn_i = pt / t.nty;
         const int gx0 = tx_i << t.tw_log2, gy0 = ty_i << t.th_log2, n0 = tn_i * t.nb;
         const int iy0 = gy0 * g.is + t.dymin, ix0 = gx0 * g.is + t.dxmin;
+        const float *gbase = gy + (((int64_t)n0 * g.OH + gy0 * g.os + g.oy0) * g.OW + gx0 * g.os + g.ox0) * g.Co + gco;
+        const float *xbase = x + (((int64_t)n0 * g.IH + iy0) * g.IW + ix0) * g.Ci + pci;
+        const int nrem = g.N - n0, yrem = g.GH - gy0, xrem = g.GW - gx0;
+        unsigned m = 0;
+        st_n0 = n0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int it = threadIdx.x + k * 256;
-            const int r = it >> 5, c4 = it & 31;
-            const int px = r & tw_mask, py = (r >> t.tw_log2) & th_mask, nbi = r >> (t.tw_log2 + t.th_log2);
-            const int n = n0 + nbi, yy = gy0 + py, xx = gx0 + px;
-            const int co = cot * CV_BM + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < g.N && yy < g.GH && xx < g.GW && co < g.Co) {
-                const int64_t opix = ((int64_t)n * g.OH + yy * g.os + g.oy0) * g.OW + xx * g.os + g.ox0;
-                const float *src = gy + opix * g.Co + co;
-                if (gvec) {
-                    v = *reinterpret_cast<const float4 *>(src);
-                } else {
-                    v.x = src[0];
-                    if (co + 1 < g.Co) v.y = src[1];
-                    if (co + 2 < g.Co) v.z = src[2];
-                    if (co + 3 < g.Co) v.w = src[3];
-                }
-                if (ascale) {
-                    const float *sp = ascale + (int64_t)n * g.Co + co;
-                    v.x *= sp[0];
-                    if (co + 1 < g.Co) v.y *= sp[1];
-                    if (co + 2 < g.Co) v.z *= sp[2];
-                    if (co + 3 < g.Co) v.w *= sp[3];
-                }
-            }
-            gq[k] = v;
+            const unsigned e = g_pyx[k];
+            const int nbi = (int)(e >> 20), py = (int)((e >> 10) & 1023), px = (int)(e & 1023);
+            const bool ok = e != 0xffffffffu && nbi < nrem && py < yrem && px < xrem;
+            m |= (ok ? 1u : 0u) << k;
+            gq[k] = load4<VEC>(ok ? gbase + g_rel[k] : gy, ok, gco, g.Co);
         }
 #pragma unroll
-        for (int k = 0; k < WG_PMAX; k++) {
-            const int it = threadIdx.x + k * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (it < p_items) {
-                const int pix = it >> 3, c4 = it & 7;
-                const int nbi = pix / phw;
-                const int rem = pix - nbi * phw;
-                const int py = rem / t.PW, px = rem - py * t.PW;
-                const int n = n0 + nbi, iy = iy0 + py, ix = ix0 + px;
-                const int ci = chunk * CV_CK + c4 * 4;
-                if (n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW && ci < g.Ci) {
-                    const float *src = x + (((int64_t)n * g.IH + iy) * g.IW + ix) * g.Ci + ci;
-                    if (xvec) {
-                        v = *reinterpret_cast<const float4 *>(src);
-                    } else {
-                        v.x = src[0];
-                        if (ci + 1 < g.Ci) v.y = src[1];
-                        if (ci + 2 < g.Ci) v.z = src[2];
-                        if (ci + 3 < g.Ci) v.w = src[3];
-                    }
-                    if (bscale) {
-                        const float *sp = bscale + (int64_t)n * g.Ci + ci;
-                        v.x *= sp[0];
-                        if (ci + 1 < g.Ci) v.y *= sp[1];
-                        if (ci + 2 < g.Ci) v.z *= sp[2];
-                        if (ci + 3 < g.Ci) v.w *= sp[3];
-                    }
-                }
-            }
-            pq[k] = v;
+        for (int k = 0; k < PMAX; k++) {
+            const unsigned e = p_pyx[k];
+            const int nbi = (int)(e >> 20), iy = iy0 + (int)((e >> 10) & 1023), ix = ix0 + (int)(e & 1023);
+            const bool ok = e != 0xffffffffu && nbi < nrem && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+            m |= (ok ? 1u : 0u) << (8 + k);
+            pq[k] = load4<VEC>(ok ? xbase + p_rel[k] : x, ok, pci, g.Ci);
         }
+        okmask = m;
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int it = threadIdx.x + k * 256;
-            const int r = it >> 5, c4 = it & 31;
+            const bool ok = (okmask >> k) & 1u;
+            float4 v = gq[k];
+            if (ascale)
+                v = mul4(v, load4<VEC>(ok ? ascale + (int64_t)(st_n0 + (int)(g_pyx[k] >> 20)) * g.Co + gco : ascale, ok, gco, g.Co));
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 hi, lo;
-            split4<SPLIT>(gq[k], hi, lo);
-            const int off = r * 256 + ((c4 * 8) ^ (wg_key(r) * 32));
-            *reinterpret_cast<uint2 *>(gh + off) = hi;
-            if (SPLIT == 2) *reinterpret_cast<uint2 *>(gl + off) = lo;
+            split4<SPLIT>(v, hi, lo);
+            *reinterpret_cast<uint2 *>(gh + g_lds[k]) = hi;
+            if (SPLIT == 2) *reinterpret_cast<uint2 *>(gl + g_lds[k]) = lo;
         }
 #pragma unroll
-        for (int k = 0; k < WG_PMAX; k++) {
-            const int it = threadIdx.x + k * 256;
-            if (it < p_items) {
-                const int pix = it >> 3, c4 = it & 7;
-                uint2 hi, lo;
-                split4<SPLIT>(pq[k], hi, lo);
-                const int off = pix * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
-                *reinterpret_cast<uint2 *>(ph + off) = hi;
-                if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + off) = lo;
+        for (int k = 0; k < PMAX; k++) {
+            const bool ok = (okmask >> (8 + k)) & 1u;
+            float4 v = pq[k];
+            if (bscale)
+                v = mul4(v, load4<VEC>(ok ? bscale + (int64_t)(st_n0 + (int)(p_pyx[k] >> 20)) * g.Ci + pci : bscale, ok, pci, g.Ci));
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 hi, lo;
+            split4<SPLIT>(v, hi, lo);
+            if ((threadIdx.x >> 3) + 32 * k < t.NPP) {
+                *reinterpret_cast<uint2 *>(ph + p_lds[k]) = hi;
+                if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds[k]) = lo;
             }
         }
     };
@@ -675,10 +743,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     if (tile_begin < tile_end) load_tile(tile_begin);
     for (int tile = tile_begin; tile < tile_end; tile++) {
         __syncthreads();   // previous tile fully consumed
-        store_tile();
+        if (!(t.debug & 6) || tile == tile_begin) store_tile();
         __syncthreads();
-        if (tile + 1 < tile_end) load_tile(tile + 1);
-        // ---- two 32-deep k-steps
+        if (tile + 1 < tile_end && !(t.debug & 10)) load_tile(tile + 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads ahead of the MFMA phase
+        if (t.debug & 1) continue;
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             bf16x8 ahi[4], alo[4];
@@ -756,11 +825,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 static void wgrad_plan(const rick_conv_geom *g, ConvTiling *t, int *nsplit, int *tps) {
     make_tiling(g, WG_TILE, t);
     const int ntiles = t->ntx * t->nty * t->ntn;
-    int want = 768 / (t->ncot * t->nchunks);
+    int want = 512 / (t->ncot * t->nchunks);   // blocks ~ 2 per CU
     if (want < 1) want = 1;
+    if (want >= 4 && ntiles >= 8) want = (want + 4) / 8 * 8;   // multiple of 8: one set of splits per XCD
     if (want > ntiles) want = ntiles;
     *tps = cdiv(ntiles, want);
     *nsplit = cdiv(ntiles, *tps);
+    if (want % 8 == 0 && *nsplit != want) *nsplit = want;      // keep the multiple of 8 (some splits get fewer tiles)
 }
 
 extern "C" int64_t rick_conv_wgrad_workspace_bytes(const rick_conv_geom *g) {
@@ -771,19 +842,25 @@ extern "C" int64_t rick_conv_wgrad_workspace_bytes(const rick_conv_geom *g) {
     return (int64_t)nsplit * t.ncot * t.nchunks * g->ntaps * CV_BM * CV_CK * 4;
 }
 
+template <int NT, int SPLIT, bool VEC, int PMAX>
+static void launch_wgrad_k(const float *x, const float *gy, float *ws, const float *ascale, const float *bscale,
+                           const rick_conv_geom *g, const ConvTiling &t, int nsplit, int tps, size_t lds, hipStream_t st) {
+    const unsigned nwg = (unsigned)(nsplit * t.ncot * t.nchunks);
+    (void)hipFuncSetAttribute((const void *)conv_wgrad_kernel<NT, SPLIT, VEC, PMAX>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv_wgrad_kernel<NT, SPLIT, VEC, PMAX>), dim3(nwg), dim3(256), lds, st, x, gy, ws, ascale, bscale,
+                       *g, t, nsplit, tps);
+}
+
 template <int NT>
 static void launch_wgrad(const float *x, const float *gy, float *ws, const float *ascale, const float *bscale,
                          const rick_conv_geom *g, const ConvTiling &t, int nsplit, int tps, size_t lds, hipStream_t st) {
-    const unsigned nwg = (unsigned)(nsplit * t.ncot * t.nchunks);
-    if (g->split == 2) {
-        (void)hipFuncSetAttribute((const void *)conv_wgrad_kernel<NT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((conv_wgrad_kernel<NT, 2>), dim3(nwg), dim3(256), lds, st, x, gy, ws, ascale, bscale, *g, t,
-                           nsplit, tps);
-    } else {
-        (void)hipFuncSetAttribute((const void *)conv_wgrad_kernel<NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((conv_wgrad_kernel<NT, 1>), dim3(nwg), dim3(256), lds, st, x, gy, ws, ascale, bscale, *g, t,
-                           nsplit, tps);
-    }
+    const bool vec = ((g->Ci | g->Co) & 3) == 0;
+    const bool small = t.NPP <= 4 * 32;
+    if (g->split == 1 && vec) launch_wgrad_k<NT, 1, true, 12>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (!vec) launch_wgrad_k<NT, 2, false, 12>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (small) launch_wgrad_k<NT, 2, true, 4>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else launch_wgrad_k<NT, 2, true, 12>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
 }
 
 extern "C" int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw, int64_t s_co, int64_t s_ci, int64_t s_t,
@@ -791,15 +868,16 @@ extern "C" int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw, i
                                    void *workspace, void *stream) {
     if (!x || !gy || !gw || !workspace || check_geom(g)) return RICK_EINVAL;
     if (g->ntaps > 9) return RICK_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)gy | (uintptr_t)(ascale ? ascale : x) | (uintptr_t)(bscale ? bscale : x)) % 16) return RICK_EINVAL;
     ConvTiling t;
     int nsplit, tps;
     wgrad_plan(g, &t, &nsplit, &tps);
-    const size_t lds = 2 * WG_GY_BYTES + 2 * (size_t)((t.NPP * 64 + 15) & ~15);
-    if (lds > 160 * 1024 || t.NPP * 8 > WG_PMAX * 256) return RICK_EINVAL;
+    const size_t lds = 2 * WG_GY_BYTES + 2 * (size_t)((t.NPP * 64 + 15) & ~15) + (size_t)t.NPP * 4;
+    if (lds > 160 * 1024 || t.NPP > 12 * 32 || t.PH > 1023 || t.PW > 1023) return RICK_EINVAL;
+    if (g->split == 1 && (((g->Ci | g->Co) & 3) != 0)) return RICK_EINVAL;   // plain-bf16 option: vector path only
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
     if (g->ntaps == 1) launch_wgrad<1>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
-    else if (g->ntaps == 2) launch_wgrad<2>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
     else if (g->ntaps <= 4) launch_wgrad<4>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
     else launch_wgrad<9>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
     const int64_t per_split = (int64_t)t.ncot * t.nchunks * g->ntaps * CV_BM * CV_CK;

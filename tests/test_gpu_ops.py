@@ -152,10 +152,10 @@ def test_conv2d_vs_fp64(case):
     xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
     y = op.conv2d(xd, wd, s, p, wscale=wscale)
     assert y.shape == yr.shape
-    assert rel_err(y, yr) < 2e-5, 'fprop'
+    assert rel_err(y, yr) < 3e-5, 'fprop'
     gx, gw = torch.autograd.grad(y, (xd, wd), gy.to(DEV), create_graph=True)
-    assert rel_err(gx, gxr) < 2e-5, 'dgrad'
-    assert rel_err(gw, gwr) < 2e-5, 'wgrad'
+    assert rel_err(gx, gxr) < 3e-5, 'dgrad'
+    assert rel_err(gw, gwr) < 3e-5, 'wgrad'
     pl = gx.pow(2).sum() + gw.pow(2).sum()
     gg = torch.autograd.grad(pl, (xd, wd))
     assert rel_err(gg[0], ggr[0]) < 5e-5, 'second-order d/dx'

@@ -1,0 +1,55 @@
+"""Micro-benchmark of the conv-family kernels on the layer shapes of the 256-px networks (GPU).
+Prints algorithmic TFLOP/s (issued = 3x for bf16x3) per launch type."""
+import sys, os, ctypes, math
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rick_amd.op import conv as cv
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+B = int(os.environ.get('B', 4))
+which = sys.argv[1:] or ['fprop', 'dgrad', 'wgrad']
+shapes = [(512, 512, 4), (512, 512, 8), (512, 512, 16), (512, 512, 32), (512, 512, 64), (256, 256, 128), (128, 128, 256),
+          (512, 256, 64), (256, 128, 128)]
+print(f'B={B} precision={cv.get_precision()}')
+for ci, co, r in shapes:
+    x = torch.randn(B, ci, r, r, device='cuda').contiguous(memory_format=torch.channels_last)
+    w = torch.randn(co, ci, 3, 3, device='cuda')
+    gy = torch.randn(B, co, r, r, device='cuda').contiguous(memory_format=torch.channels_last)
+    flops = 2.0 * B * r * r * ci * co * 9
+    wp = cv._pack(w, 1.0)
+    wpT = cv._pack(w.transpose(0, 1), 1.0)
+    out = [f'{ci:4d}->{co:4d} @{r:3d}: {flops/1e9:7.2f} GF']
+    if 'fprop' in which:
+        t = timeit(lambda: cv._conv_launch(x, wp, co, 3, 3, 1, 1))
+        out.append(f'fprop {t*1e6:8.1f} us {flops/t/1e12:6.1f} TF')
+    if 'dgrad' in which:
+        t = timeit(lambda: cv._convT_launch(gy, wpT, ci, 3, 3, 1, 1, (r, r)))
+        out.append(f'dgrad {t*1e6:8.1f} us {flops/t/1e12:6.1f} TF')
+    if 'wgrad' in which:
+        t = timeit(lambda: cv._wgrad_launch(gy, x, 3, 3, 1, 1))
+        out.append(f'wgrad {t*1e6:8.1f} us {flops/t/1e12:6.1f} TF')
+    print(' | '.join(out))
+# stride-2 (D conv2) and transposed (G up)
+for ci, co, r in [(128, 256, 256), (256, 512, 128), (512, 512, 64)]:
+    x = torch.randn(B, ci, r + 1, r + 1, device='cuda').contiguous(memory_format=torch.channels_last)
+    w = torch.randn(co, ci, 3, 3, device='cuda')
+    wp = cv._pack(w, 1.0)
+    flops = 2.0 * B * (r // 2) ** 2 * ci * co * 9
+    t = timeit(lambda: cv._conv_launch(x, wp, co, 3, 3, 2, 0))
+    gy = torch.randn(B, co, r // 2, r // 2, device='cuda').contiguous(memory_format=torch.channels_last)
+    t3 = timeit(lambda: cv._wgrad_launch(gy, x, 3, 3, 2, 0))
+    wpT = cv._pack(w.transpose(0, 1), 1.0)
+    t2 = timeit(lambda: cv._convT_launch(gy, wpT, ci, 3, 3, 2, 0, (r + 1, r + 1)))
+    print(f's2 {ci:4d}->{co:4d} @{r:3d}->{r//2}: {flops/1e9:7.2f} GF | fprop {t*1e6:8.1f} us {flops/t/1e12:6.1f} TF | '
+          f'dgrad(convT) {t2*1e6:8.1f} us {flops/t2/1e12:6.1f} TF | wgrad {t3*1e6:8.1f} us {flops/t3/1e12:6.1f} TF')
