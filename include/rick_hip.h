@@ -116,6 +116,13 @@ int rick_conv_igemm_f32(const float *x, const void *packed_w, float *out,
                         const float *iscale, const float *oscale,
                         const rick_conv_geom *g, void *workspace, void *stream);
 
+/* Several geometries over the same tensors and weights (the 4 output-parity classes of a stride-2
+ * transposed convolution) in one launch.  ngeom <= 4; all share Ci, Co, split. */
+int64_t rick_conv_igemm_multi_workspace_bytes(const rick_conv_geom *geoms, int ngeom);
+int rick_conv_igemm_multi_f32(const float *x, const void *packed_w, float *out,
+                              const float *iscale, const float *oscale,
+                              const rick_conv_geom *geoms, int ngeom, void *workspace, void *stream);
+
 /* Weight gradient for the same geometry:
  *   gw[(co, ci, t)] = alpha * sum_{n, pos} (ascale[n,co] * gy[n, outpix(pos), co]) *
  *                                           (bscale[n,ci] * x[n, inpix(pos, t), ci])

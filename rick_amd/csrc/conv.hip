@@ -227,11 +227,10 @@ __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(
 #define IG_PMAX 10   // patch float4 per thread prefetched in registers (covers NPP <= 320 pixels)
 
 template <int SPLIT, bool VEC>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restrict__ x,
-                                                            const unsigned char *__restrict__ wpk,
-                                                            float *__restrict__ out, const float *__restrict__ iscale,
-                                                            const float *__restrict__ oscale, float *__restrict__ ws,
-                                                            const rick_conv_geom g, const ConvTiling t) {
+__device__ __forceinline__ void igemm_body(const float *__restrict__ x, const unsigned char *__restrict__ wpk,
+                                           float *__restrict__ out, const float *__restrict__ iscale,
+                                           const float *__restrict__ oscale, float *__restrict__ ws,
+                                           const rick_conv_geom &g, const ConvTiling &t, const int bid, const int nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *wbuf = smem;                               // [2][16 KB]
     unsigned char *ph = smem + 2 * CV_WSTEP_BYTES;            // [NPP][64 B]
@@ -240,8 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
     build_patch_table(ptab, t);
     __syncthreads();
 
-    const int nwg = gridDim.x;
-    const int lid = xcd_remap(blockIdx.x, nwg);
+    const int lid = xcd_remap(bid, nwg);
     const int npos_tiles = t.ntx * t.nty * t.ntn;
     int pt = lid % npos_tiles;
     const int split = (lid / npos_tiles) % t.nsplit;
@@ -486,6 +484,45 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
     }
 }
 
+template <int SPLIT, bool VEC>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restrict__ x,
+                                                            const unsigned char *__restrict__ wpk,
+                                                            float *__restrict__ out, const float *__restrict__ iscale,
+                                                            const float *__restrict__ oscale, float *__restrict__ ws,
+                                                            const rick_conv_geom g, const ConvTiling t) {
+    igemm_body<SPLIT, VEC>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x);
+}
+
+// Several geometries (the output-parity classes of a transposed convolution) in ONE launch: block ranges
+// [blk_end[c-1], blk_end[c]) run class c.  Short-K classes (1 or 2 taps) overlap with the long ones instead
+// of each paying its own launch, fill and tail.
+#define IG_MAXCLS 4
+struct IgemmMulti {
+    int ncls;
+    int blk_end[IG_MAXCLS];
+    int64_t ws_off[IG_MAXCLS];       // float offset of each class's split-K workspace
+    rick_conv_geom g[IG_MAXCLS];
+    ConvTiling t[IG_MAXCLS];
+};
+
+template <int SPLIT, bool VEC>
+__global__ __launch_bounds__(256, 2) void conv_igemm_multi_kernel(const float *__restrict__ x,
+                                                                  const unsigned char *__restrict__ wpk,
+                                                                  float *__restrict__ out,
+                                                                  const float *__restrict__ iscale,
+                                                                  const float *__restrict__ oscale,
+                                                                  float *__restrict__ ws, const IgemmMulti m) {
+    int c = 0, start = 0;
+#pragma unroll
+    for (int i = 0; i < IG_MAXCLS - 1; i++)
+        if (i + 1 < m.ncls && (int)blockIdx.x >= m.blk_end[i]) {
+            c = i + 1;
+            start = m.blk_end[i];
+        }
+    igemm_body<SPLIT, VEC>(x, wpk, out, iscale, oscale, ws + m.ws_off[c], m.g[c], m.t[c], (int)blockIdx.x - start,
+                           m.blk_end[c] - start);
+}
+
 // out[n, pix(gy,gx), co] = alpha * oscale[n,co] * sum_s ws[s][n,gy,gx][co]
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
                                                                   const float *__restrict__ oscale, rick_conv_geom g,
@@ -566,6 +603,85 @@ extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *
         if (nb > 4096) nb = 4096;
         hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, t.nsplit);
     }
+    RICK_LAUNCH_STATUS();
+}
+
+static int plan_multi(const rick_conv_geom *geoms, int ngeom, IgemmMulti *m, size_t *lds_max, int64_t *ws_floats) {
+    if (!geoms || ngeom < 1 || ngeom > IG_MAXCLS) return RICK_EINVAL;
+    m->ncls = ngeom;
+    int64_t blocks = 0, wsf = 0;
+    size_t lmax = 0;
+    for (int c = 0; c < ngeom; c++) {
+        const rick_conv_geom *g = &geoms[c];
+        if (check_geom(g) || g->Ci != geoms[0].Ci || g->Co != geoms[0].Co || g->split != geoms[0].split) return RICK_EINVAL;
+        if (make_tiling(g, CV_BN, &m->t[c])) return RICK_EINVAL;
+        igemm_plan_split(&m->t[c]);
+        const ConvTiling &t = m->t[c];
+        const size_t lds = 2 * CV_WSTEP_BYTES + 2 * (size_t)((t.NPP * 64 + 15) & ~15) + (size_t)t.NPP * 4;
+        if (lds > 160 * 1024 || t.PH > 1023 || t.PW > 1023) return RICK_EINVAL;
+        lmax = lds > lmax ? lds : lmax;
+        blocks += (int64_t)t.ntx * t.nty * t.ntn * t.ncot * t.nsplit;
+        if (blocks > 0x7fffffff) return RICK_EINVAL;
+        m->blk_end[c] = (int)blocks;
+        m->g[c] = *g;
+        m->ws_off[c] = wsf;
+        if (t.nsplit > 1) wsf += ((int64_t)t.nsplit * g->N * g->GH * g->GW * g->Co + 63) & ~63LL;
+    }
+    for (int c = ngeom; c < IG_MAXCLS; c++) {
+        m->blk_end[c] = m->blk_end[ngeom - 1];
+        m->ws_off[c] = 0;
+    }
+    *lds_max = lmax;
+    *ws_floats = wsf;
+    return 0;
+}
+
+extern "C" int64_t rick_conv_igemm_multi_workspace_bytes(const rick_conv_geom *geoms, int ngeom) {
+    IgemmMulti m;
+    size_t lds;
+    int64_t wsf;
+    if (plan_multi(geoms, ngeom, &m, &lds, &wsf)) return -1;
+    return wsf * 4;
+}
+
+template <int SPLIT, bool VEC>
+static void launch_igemm_multi(size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
+                               const float *iscale, const float *oscale, float *ws, const IgemmMulti &m) {
+    (void)hipFuncSetAttribute((const void *)conv_igemm_multi_kernel<SPLIT, VEC>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv_igemm_multi_kernel<SPLIT, VEC>), dim3((unsigned)m.blk_end[m.ncls - 1]), dim3(256), lds, st, x,
+                       wp, out, iscale, oscale, ws, m);
+}
+
+extern "C" int rick_conv_igemm_multi_f32(const float *x, const void *packed_w, float *out, const float *iscale,
+                                         const float *oscale, const rick_conv_geom *geoms, int ngeom, void *workspace,
+                                         void *stream) {
+    if (!x || !packed_w || !out) return RICK_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed_w | (uintptr_t)(iscale ? iscale : x)) % 16) return RICK_EINVAL;
+    IgemmMulti m;
+    size_t lds;
+    int64_t wsf;
+    if (plan_multi(geoms, ngeom, &m, &lds, &wsf)) return RICK_EINVAL;
+    if (wsf > 0 && (!workspace || ((uintptr_t)workspace % 16))) return RICK_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    float *ws = (float *)workspace;
+    const unsigned char *wp = (const unsigned char *)packed_w;
+    const bool vec = (geoms[0].Ci & 3) == 0;
+    if (geoms[0].split == 2) {
+        if (vec) launch_igemm_multi<2, true>(lds, st, x, wp, out, iscale, oscale, ws, m);
+        else launch_igemm_multi<2, false>(lds, st, x, wp, out, iscale, oscale, ws, m);
+    } else {
+        if (vec) launch_igemm_multi<1, true>(lds, st, x, wp, out, iscale, oscale, ws, m);
+        else launch_igemm_multi<1, false>(lds, st, x, wp, out, iscale, oscale, ws, m);
+    }
+    for (int c = 0; c < ngeom; c++)
+        if (m.t[c].nsplit > 1) {
+            const int64_t per = (int64_t)geoms[c].N * geoms[c].GH * geoms[c].GW * geoms[c].Co;
+            int64_t nb = cdiv64(per, 256);
+            if (nb > 4096) nb = 4096;
+            hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, ws + m.ws_off[c], out, oscale,
+                               geoms[c], m.t[c].nsplit);
+        }
     RICK_LAUNCH_STATUS();
 }
 

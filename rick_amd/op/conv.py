@@ -172,13 +172,18 @@ def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alph
     y = _empty_nhwc(N, O, OH, OW, x)
     if not full:
         y.zero_()
-    for py, px, GH, GW, taps in classes:
-        if not taps:
-            continue
-        g = _geom(N, IH, IW, I, OH, OW, O, GH, GW, 1, s, py, px, taps, kh * kw, alpha)
-        check(_launch('igemm', 2.0 * N * GH * GW * O * I * len(taps), lib.rick_conv_igemm_f32, ptr(x), ptr(wp), ptr(y),
-                      ptr(iscale), ptr(oscale), ctypes.byref(g), ptr(_igemm_ws(g, x)), stream_ptr()),
-              'rick_conv_igemm_f32')
+    live = [c for c in classes if c[4]]
+    geoms = (ConvGeom * len(live))()
+    flops = 0.0
+    for i, (py, px, GH, GW, taps) in enumerate(live):
+        geoms[i] = _geom(N, IH, IW, I, OH, OW, O, GH, GW, 1, s, py, px, taps, kh * kw, alpha)
+        flops += 2.0 * N * GH * GW * O * I * len(taps)
+    nbytes = lib.rick_conv_igemm_multi_workspace_bytes(geoms, len(live))
+    if nbytes < 0:
+        raise RuntimeError('rick_conv_igemm_multi_workspace_bytes: invalid geometry')
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
+    check(_launch('igemm', flops, lib.rick_conv_igemm_multi_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale),
+                  geoms, len(live), ptr(ws), stream_ptr()), 'rick_conv_igemm_multi_f32')
     return y
 
 
