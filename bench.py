@@ -149,11 +149,21 @@ def main():
             run(16, i0 + args.warmup + args.steps)
             torch.cuda.synchronize()
         agg = {}
-        for kind, flops, e0, e1 in prof:
+        by_tag = {}
+        for kind, flops, e0, e1, tag in prof:
+            dt = e0.elapsed_time(e1) * 1e-3
             a = agg.setdefault(kind, [0.0, 0.0, 0])
             a[0] += flops
-            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[1] += dt
             a[2] += 1
+            bt = by_tag.setdefault(tag, [0.0, 0.0, 0])
+            bt[0] += flops
+            bt[1] += dt
+            bt[2] += 1
+        if os.environ.get('RICK_BENCH_BREAKDOWN'):
+            for tag, (fl, dt, n) in sorted(by_tag.items(), key=lambda kv: -kv[1][1])[:40]:
+                print(f'  {tag:44s} n={n:4d} total {dt*1e3/16:7.3f} ms/step  avg {dt/n*1e6:8.1f} us  {fl/dt/1e12:6.1f} TF',
+                      file=sys.stderr)
         ig = agg.get('igemm', [0.0, 1.0, 1])
         ach = ig[0] / ig[1] / 1e12
         mult = 3.0 if args.precision == 'bf16x3' else 1.0

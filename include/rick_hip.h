@@ -161,10 +161,12 @@ int rick_hw_dot_f32(const float *a, const float *b, float *d, int N, int64_t P, 
 /* y = (a + b) * alpha  (ResBlock merge, model_probe_tune.py:658); b may be NULL */
 int rick_add_scale_f32(const float *a, const float *b, float *y, int64_t n, float alpha, void *stream);
 
-/* Minibatch standard deviation (model_probe_tune.py:748-756) on NHWC x[B, P, C] with
- * group = B: out[B, P, C+1], channel C = mean_{p,c} sqrt(var_b(x) + 1e-8); backward. */
-int rick_mbstd_fwd_f32(const float *x, float *out, float *stat, int B, int P, int C, void *stream);
-int rick_mbstd_bwd_f32(const float *x, const float *gout, float *gx, int B, int P, int C, void *stream);
+/* Minibatch standard deviation (model_probe_tune.py:748-756) on NHWC x[B, P, C]: `groups` runs of
+ * B/groups consecutive samples, each treated like one discriminator call whose stddev group is its whole
+ * batch: out[B, P, C+1], channel C = mean_{p,c} sqrt(var_b(x) + 1e-8) of the sample's run; backward.
+ * (groups = 2 lets D(fake) and D(real) of the D step share one pass with unchanged results.) */
+int rick_mbstd_fwd_f32(const float *x, float *out, float *stat, int B, int P, int C, int groups, void *stream);
+int rick_mbstd_bwd_f32(const float *x, const float *gout, float *gx, int B, int P, int C, int groups, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fisher information + optimiser side (train_dynamic_update_prune.py:252-269, 279-299,

@@ -56,8 +56,8 @@ SIGNATURES = {
     'rick_hw_dot_blocks': (c_int, [c_i64]),
     'rick_hw_dot_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_fp, c_fp]),
     'rick_add_scale_f32': (c_int, [c_fp, c_fp, c_fp, c_i64, c_f, c_fp]),
-    'rick_mbstd_fwd_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
-    'rick_mbstd_bwd_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
+    'rick_mbstd_fwd_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    'rick_mbstd_bwd_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     'rick_sq_accumulate_f32': (c_int, [c_fp, c_fp, c_i64, c_fp]),
     'rick_filter_reduce_f32': (c_int, [c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_fp]),
     'rick_masked_adam_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_fp]),

@@ -323,12 +323,23 @@ class ResBlock(nn.Module):
         self.conv2 = ConvLayer(in_channel, out_channel, 3, downsample=downsample)
         self.skip = ConvLayer(in_channel, out_channel, 1, downsample=downsample, activate=False, bias=False)
 
+    def _skip(self, x):
+        """skip = 1x1 stride-2 conv of blur(x) (model_probe_tune.py:650-652).  A stride-2 1x1 conv only reads
+        the even positions of the blurred map, so the FIR is evaluated directly at those positions
+        (upfirdn2d down=2: same taps, same order per output -> identical values, 4x fewer of them) and the
+        1x1 conv runs dense at stride 1."""
+        blur, conv = self.skip[0], self.skip[1]
+        if not isinstance(blur, _Fir) or conv.stride != 2 or conv.weight.shape[2] != 1:
+            return self.skip(x)
+        y = upfirdn2d(x, blur.kernel, up=1, down=2, pad=blur.pad)
+        return op.conv2d(y, conv.weight, 1, 0, wscale=conv.scale, key=(conv.weight, 'w'))
+
     def forward(self, x, feat=None):
         t1 = self.conv1(x)
         t2 = self.conv2(t1)
         if feat is not None:
             feat += [t1, t2]
-        return op.add_scale(t2, self.skip(x), 1 / math.sqrt(2))
+        return op.add_scale(t2, self._skip(x), 1 / math.sqrt(2))
 
 
 class Discriminator(nn.Module, _FisherMixin):
@@ -348,13 +359,17 @@ class Discriminator(nn.Module, _FisherMixin):
         self.final_linear = nn.Sequential(EqualLinear(ch[4] * 4 * 4, ch[4], activation='fused_lrelu'),
                                           EqualLinear(ch[4], 1))
 
-    def forward(self, inp, ind=None, real=False):
+    def forward(self, inp, ind=None, real=False, calls=1):
+        """Reference signature (model_probe_tune.py:732) plus `calls`: the batch is the concatenation of
+        `calls` independent calls (minibatch-stddev statistics stay per call), e.g. D(cat(fake, real), calls=2)
+        returns exactly cat(D(fake), D(real))."""
         feat = []
         x = self.convs[0](inp)
         feat.append(x)
         for blk in list(self.convs)[1:]:
             x = blk(x, feat)
-        out = op.minibatch_stddev(x, self.stddev_group, self.stddev_feat, second_order=op.second_order_enabled())
+        out = op.minibatch_stddev(x, self.stddev_group, self.stddev_feat, second_order=op.second_order_enabled(),
+                                  calls=calls)
         out = self.final_conv(out)
         feat.append(out)
         out = out.contiguous().view(out.shape[0], -1)      # NCHW flatten order, as the checkpoint expects

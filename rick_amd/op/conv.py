@@ -45,14 +45,14 @@ class launch_profiler:
         _prof = None
 
 
-def _launch(kind, flops, fn, *args):
+def _launch(kind, flops, fn, *args, tag=''):
     if _prof is None:
         return fn(*args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     rc = fn(*args)
     e1.record()
-    _prof.append((kind, flops, e0, e1))
+    _prof.append((kind, flops, e0, e1, tag))
     return rc
 
 
@@ -150,7 +150,8 @@ def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0):
     taps = [(ky - p, kx - p, ky * kw + kx) for ky in range(kh) for kx in range(kw)]
     g = _geom(N, IH, IW, I, OH, OW, O, OH, OW, s, 1, 0, 0, taps, kh * kw, alpha)
     check(_launch('igemm', 2.0 * N * OH * OW * O * I * kh * kw, lib.rick_conv_igemm_f32, ptr(x), ptr(wp), ptr(y),
-                  ptr(iscale), ptr(oscale), ctypes.byref(g), ptr(_igemm_ws(g, x)), stream_ptr()), 'rick_conv_igemm_f32')
+                  ptr(iscale), ptr(oscale), ctypes.byref(g), ptr(_igemm_ws(g, x)), stream_ptr(),
+                  tag=f'conv {I}->{O} k{kh} s{s} N{N} {IH}x{IW}'), 'rick_conv_igemm_f32')
     return y
 
 
@@ -183,7 +184,8 @@ def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alph
         raise RuntimeError('rick_conv_igemm_multi_workspace_bytes: invalid geometry')
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     check(_launch('igemm', flops, lib.rick_conv_igemm_multi_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale),
-                  geoms, len(live), ptr(ws), stream_ptr()), 'rick_conv_igemm_multi_f32')
+                  geoms, len(live), ptr(ws), stream_ptr(), tag=f'convT {I}->{O} k{kh} s{s} N{N} {IH}x{IW}'),
+          'rick_conv_igemm_multi_f32')
     return y
 
 
@@ -202,8 +204,8 @@ def _wgrad_launch(a, b, kh, kw, s, p, alpha=1.0, ascale=None, bscale=None):
         raise RuntimeError('rick_conv_wgrad_workspace_bytes: invalid geometry')
     ws = torch.empty(max(nbytes, 16), device=a.device, dtype=torch.uint8)
     check(_launch('wgrad', 2.0 * N * AH * AW * O * I * kh * kw, lib.rick_conv_wgrad_f32, ptr(b), ptr(a), ptr(gw),
-                  I * kh * kw, kh * kw, 1, ptr(ascale), ptr(bscale), ctypes.byref(g), 0, ptr(ws), stream_ptr()),
-          'rick_conv_wgrad_f32')
+                  I * kh * kw, kh * kw, 1, ptr(ascale), ptr(bscale), ctypes.byref(g), 0, ptr(ws), stream_ptr(),
+                  tag=f'wgrad {I}x{O} k{kh} s{s} N{N} a{AH}x{AW} b{BH}x{BW}'), 'rick_conv_wgrad_f32')
     return gw
 
 

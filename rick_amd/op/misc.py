@@ -212,16 +212,17 @@ def thin_bwdx(t, W):
 
 # ------------------------------------------------------------------- minibatch stddev
 class _MbStd(Function):
-    """First-order HIP path (group == batch).  Second-order callers use the composite below."""
+    """First-order HIP path.  Second-order callers use the composite below."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, groups):
         x = _nhwc(x)
         b, c, h, w = x.shape
         out = torch.empty((b, c + 1, h, w), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
-        stat = torch.empty(1, device=x.device, dtype=x.dtype)
-        check(lib.rick_mbstd_fwd_f32(ptr(x), ptr(out), ptr(stat), b, h * w, c, stream_ptr()), 'rick_mbstd_fwd_f32')
+        stat = torch.empty(groups, device=x.device, dtype=x.dtype)
+        check(lib.rick_mbstd_fwd_f32(ptr(x), ptr(out), ptr(stat), b, h * w, c, groups, stream_ptr()), 'rick_mbstd_fwd_f32')
         ctx.save_for_backward(x)
+        ctx.groups = groups
         return out
 
     @staticmethod
@@ -231,22 +232,33 @@ class _MbStd(Function):
         g = _nhwc(g)
         b, c, h, w = x.shape
         gx = torch.empty_like(x)
-        check(lib.rick_mbstd_bwd_f32(ptr(x), ptr(g), ptr(gx), b, h * w, c, stream_ptr()), 'rick_mbstd_bwd_f32')
-        return gx
+        check(lib.rick_mbstd_bwd_f32(ptr(x), ptr(g), ptr(gx), b, h * w, c, ctx.groups, stream_ptr()), 'rick_mbstd_bwd_f32')
+        return gx, None
 
 
-def minibatch_stddev(x, stddev_group=25, stddev_feat=1, second_order=False):
-    """cat([x, stddev channel]) as in model_probe_tune.py:748-756.  The HIP kernel covers the
-    training configuration (group == batch <= 25, stddev_feat == 1); other group shapes and
-    double-differentiable calls (R1) use the same formula composed from device tensor ops on
-    this [B,512,4,4] tensor (8 K elements per sample)."""
-    require_cuda_f32(x)
+def _mbstd_composite(x, stddev_group, stddev_feat):
     b, c, h, w = x.shape
     group = min(b, stddev_group)
-    if group == b and stddev_feat == 1 and not second_order:
-        return _MbStd.apply(x)
     s = x.reshape(group, -1, stddev_feat, c // stddev_feat, h, w)
     s = torch.sqrt(s.var(0, unbiased=False) + 1e-8)
     s = s.mean([2, 3, 4], keepdim=True).squeeze(2)
     s = s.repeat(group, 1, h, w)
     return torch.cat([x, s], 1)
+
+
+def minibatch_stddev(x, stddev_group=25, stddev_feat=1, second_order=False, calls=1):
+    """cat([x, stddev channel]) as in model_probe_tune.py:748-756.  `calls` > 1 means the batch is the
+    concatenation of that many independent discriminator calls (each keeps its own statistics, exactly as
+    if the module had been called once per chunk).  The HIP kernel covers the training configuration
+    (per-call batch <= stddev_group, stddev_feat == 1); other shapes and double-differentiable calls (R1) use
+    the same formula composed from device tensor ops on this [B,512,4,4] tensor (8 K elements per sample)."""
+    require_cuda_f32(x)
+    b = x.shape[0]
+    if b % calls:
+        raise RuntimeError('minibatch_stddev: batch not divisible by the number of concatenated calls')
+    per = b // calls
+    if per <= stddev_group and stddev_feat == 1 and not second_order:
+        return _MbStd.apply(x, calls)
+    if calls == 1:
+        return _mbstd_composite(x, stddev_group, stddev_feat)
+    return torch.cat([_mbstd_composite(xc, stddev_group, stddev_feat) for xc in x.chunk(calls)], 0)

@@ -297,6 +297,19 @@ def test_minibatch_stddev(B):
         assert rel_err(y, yr) < 1e-5
         (gd,) = torch.autograd.grad(y, xd, g.to(DEV))
         assert rel_err(gd, gr) < 1e-4 if B > 1 else True
+    # two concatenated calls == two separate calls
+    x2 = synth_tensor(f'mbstd2/{B}', (2 * B, 512, 4, 4))
+    g2 = synth_tensor(f'mbstd2/g/{B}', (2 * B, 513, 4, 4))
+    for so in (False, True):
+        xd = x2.to(DEV).requires_grad_(True)
+        y = op.minibatch_stddev(xd, second_order=so, calls=2)
+        (gd,) = torch.autograd.grad(y, xd, g2.to(DEV))
+        xr = x2.double().requires_grad_(True)
+        yr2 = torch.cat([minibatch_stddev_ref(c) for c in xr.chunk(2)], 0)
+        (gr2,) = torch.autograd.grad(yr2, xr, g2.double())
+        assert rel_err(y, yr2) < 1e-5
+        if B > 1:
+            assert rel_err(gd, gr2) < 1e-4
 
 
 def test_fisher_and_optimizer_kernels():
