@@ -246,39 +246,49 @@ extern "C" int rick_chan_scale_f32(const float *x, const float *s, float *y, int
 }
 
 // d[n,c] = sum_p a[n,p,c]*b[n,p,c].  grid (blocks_p, N); partials [blk][n][c]
-#define HWDOT_ROWS 128
+#define HWDOT_ROWS 256
 extern "C" int rick_hw_dot_blocks(int64_t P) {
     int64_t nb = cdiv64(P, HWDOT_ROWS);
-    if (nb > 512) nb = 512;
+    if (nb > 256) nb = 256;
     return (int)(nb < 1 ? 1 : nb);
 }
 
+template <bool VEC4>
 __global__ __launch_bounds__(256) void hw_dot_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                      float *__restrict__ partials, int64_t P, int C) {
-    extern __shared__ float lds[];
+    extern __shared__ float lds[];   // [256 * 4]
+    constexpr int W = VEC4 ? 4 : 1;
     const int n = blockIdx.y, N = gridDim.y, nb = gridDim.x;
     const int64_t ppb = cdiv64(P, nb);
     const int64_t p0 = (int64_t)blockIdx.x * ppb, p1 = p0 + ppb < P ? p0 + ppb : P;
     const float *an = a + (int64_t)n * P * C, *bn = b + (int64_t)n * P * C;
     float *pb = partials + ((int64_t)blockIdx.x * N + n) * C;
-    for (int cbase = 0; cbase < C; cbase += 256) {
-        const int cg = C - cbase < 256 ? C - cbase : 256;
+    const int ncol = C / W;
+    for (int cbase = 0; cbase < ncol; cbase += 256) {
+        const int cg = ncol - cbase < 256 ? ncol - cbase : 256;
         const int rpb = 256 / cg;
         const int lane_c = threadIdx.x % cg, lane_r = threadIdx.x / cg;
-        float acc = 0.f;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         if (lane_r < rpb)
             for (int64_t p = p0 + lane_r; p < p1; p += rpb) {
-                const int64_t off = p * C + cbase + lane_c;
-                acc += an[off] * bn[off];
+                const int64_t off = p * C + (int64_t)(cbase + lane_c) * W;
+                if (VEC4) {
+                    const float4 av = *reinterpret_cast<const float4 *>(an + off);
+                    const float4 bv = *reinterpret_cast<const float4 *>(bn + off);
+                    acc[0] += av.x * bv.x; acc[1] += av.y * bv.y; acc[2] += av.z * bv.z; acc[3] += av.w * bv.w;
+                } else {
+                    acc[0] += an[off] * bn[off];
+                }
             }
         __syncthreads();
-        lds[threadIdx.x] = lane_r < rpb ? acc : 0.f;
+        for (int j = 0; j < W; j++) lds[threadIdx.x * W + j] = lane_r < rpb ? acc[j] : 0.f;
         __syncthreads();
-        if (threadIdx.x < cg) {
-            float s = 0.f;
-            for (int rr = 0; rr < rpb; rr++) s += lds[rr * cg + threadIdx.x];
-            pb[cbase + threadIdx.x] = s;
-        }
+        if (threadIdx.x < cg)
+            for (int j = 0; j < W; j++) {
+                float s = 0.f;
+                for (int rr = 0; rr < rpb; rr++) s += lds[(rr * cg + threadIdx.x) * W + j];
+                pb[(cbase + threadIdx.x) * W + j] = s;
+            }
     }
 }
 
@@ -287,7 +297,10 @@ extern "C" int rick_hw_dot_f32(const float *a, const float *b, float *d, int N, 
     if (!a || !b || !d || !partials || N <= 0 || P <= 0 || C <= 0 || N > 65535) return RICK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nb = rick_hw_dot_blocks(P);
-    hipLaunchKernelGGL(hw_dot_kernel, dim3(nb, N), dim3(256), 256 * sizeof(float), st, a, b, partials, P, C);
+    if (C % 4 == 0 && (((uintptr_t)a | (uintptr_t)b) % 16 == 0))
+        hipLaunchKernelGGL(hw_dot_kernel<true>, dim3(nb, N), dim3(256), 1024 * sizeof(float), st, a, b, partials, P, C);
+    else
+        hipLaunchKernelGGL(hw_dot_kernel<false>, dim3(nb, N), dim3(256), 1024 * sizeof(float), st, a, b, partials, P, C);
     hipLaunchKernelGGL(partial_colsum_kernel, dim3(cdiv(N * C, 32)), dim3(256), 0, st, partials, d, nb, N * C, N * C, 0);
     RICK_LAUNCH_STATUS();
 }

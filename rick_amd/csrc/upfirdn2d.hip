@@ -132,6 +132,60 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_kernel(const float *__rest
     }
 }
 
+// ------------------------------------------------------------- NHWC, 4x4 FIR, up == 1 (hot path)
+// The blur after every transposed conv, the blurs of the discriminator ResBlocks and the skip-path
+// decimation are all 4x4 kernels with up == 1 and down in {1, 2} on >= 64 channels.  Compile-time tile,
+// tap count and strides: 16 unrolled fmaf per output float4, y-outer / x-inner exactly like the generic
+// kernel and the C oracle (bit-identical results).
+template <int DOWN, int TOH, int TOW>
+__global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__restrict__ in,
+                                                                const float *__restrict__ kern,
+                                                                float *__restrict__ out, UfdParams p) {
+    constexpr int TIH = (TOH - 1) * DOWN + 4, TIW = (TOW - 1) * DOWN + 4, CB4 = 16;
+    __shared__ float4 sx[TIH * TIW * CB4];
+    const int tile_x = blockIdx.x % p.tiles_x, tile_y = blockIdx.x / p.tiles_x;
+    const int c0 = blockIdx.y * 64;
+    const int64_t n = blockIdx.z;
+    const int oy0 = tile_y * TOH, ox0 = tile_x * TOW;
+    const int iy_lo = oy0 * DOWN - p.pad_y0, ix_lo = ox0 * DOWN - p.pad_x0;
+    float kr[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) kr[i] = kern[i];
+    const float *src = in + n * (int64_t)p.in_h * p.in_w * p.minor + c0;
+    const int c4 = threadIdx.x & 15;
+    for (int pix = threadIdx.x >> 4; pix < TIH * TIW; pix += 16) {
+        const int r = pix / TIW, c = pix - r * TIW;
+        const int iy = iy_lo + r, ix = ix_lo + c;
+        const bool ok = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+        float4 v = *reinterpret_cast<const float4 *>(ok ? src + ((int64_t)iy * p.in_w + ix) * p.minor + c4 * 4 : in);
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        sx[pix * CB4 + c4] = v;
+    }
+    __syncthreads();
+    float *dst = out + n * (int64_t)p.out_h * p.out_w * p.minor + c0;
+#pragma unroll
+    for (int j = 0; j < TOH * TOW / 16; j++) {
+        const int pix = (threadIdx.x >> 4) + 16 * j;
+        const int ty = pix / TOW, tx = pix % TOW;
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        const float4 *xr = sx + ((ty * DOWN) * TIW + tx * DOWN) * CB4 + c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const float kv = kr[(3 - y) * 4 + (3 - x)];
+                const float4 xv = xr[(y * TIW + x) * CB4];
+                v.x = __builtin_fmaf(xv.x, kv, v.x);
+                v.y = __builtin_fmaf(xv.y, kv, v.y);
+                v.z = __builtin_fmaf(xv.z, kv, v.z);
+                v.w = __builtin_fmaf(xv.w, kv, v.w);
+            }
+        if (oy < p.out_h && ox < p.out_w)
+            *reinterpret_cast<float4 *>(dst + ((int64_t)oy * p.out_w + ox) * p.minor + c4 * 4) = v;
+    }
+}
+
 static int tile_in_extent(int tile_out, int down, int k, int up) {
     // rows touched by tile_out consecutive outputs: <= ((tile_out-1)*down + k - 1)/up + 2
     return ((tile_out - 1) * down + k - 1) / up + 2;
@@ -152,6 +206,19 @@ extern "C" int rick_upfirdn2d_f32(const float *input, const float *kernel, float
     p.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
     if (p.out_h <= 0 || p.out_w <= 0) return RICK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (minor % 64 == 0 && kh == 4 && kw == 4 && up_x == 1 && up_y == 1 && down_x == down_y && (down_x == 1 || down_x == 2) &&
+        major <= 65535 && minor / 64 <= 65535 && (((uintptr_t)input | (uintptr_t)out) % 16 == 0)) {
+        if (down_x == 1) {
+            p.tiles_x = cdiv(p.out_w, 8);
+            dim3 grid(p.tiles_x * cdiv(p.out_h, 8), minor / 64, (unsigned)major);
+            hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<1, 8, 8>), grid, dim3(256), 0, st, input, kernel, out, p);
+        } else {
+            p.tiles_x = cdiv(p.out_w, 8);
+            dim3 grid(p.tiles_x * cdiv(p.out_h, 4), minor / 64, (unsigned)major);
+            hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<2, 4, 8>), grid, dim3(256), 0, st, input, kernel, out, p);
+        }
+        RICK_LAUNCH_STATUS();
+    }
     if (minor % 4 == 0) {
         const int cb4 = (minor >= 64 ? 64 : minor) / 4;
         if (minor % (cb4 * 4) != 0) goto planar_like;    // e.g. minor = 72: fall through to generic
