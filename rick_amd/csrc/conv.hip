@@ -24,6 +24,7 @@
 // offset (checked by simulation against the gfx950 ds_read_b128 lane groups).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
@@ -226,7 +227,7 @@ __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(
 // Forward / data-gradient kernel.
 #define IG_PMAX 10   // patch float4 per thread prefetched in registers (covers NPP <= 320 pixels)
 
-template <int SPLIT, bool VEC>
+template <int SPLIT, bool VEC, bool DEEP>
 __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const unsigned char *__restrict__ wpk,
                                            float *__restrict__ out, const float *__restrict__ iscale,
                                            const float *__restrict__ oscale, float *__restrict__ ws,
@@ -274,14 +275,18 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
 
     // ---- patch staging state.  The tile is fixed for the block, so validity, source offset (relative to
     // the tile-origin pointer) and LDS offset of each of this thread's patch items are computed once.
+    // DEEP (patches of <= 160 pixels: 1x1 convs and the parity classes of transposed convs, whose chunks
+    // last only 1-4 k-steps): the IG_PMAX register slots form TWO sets of 5 and chunks are prefetched two
+    // ahead, so a load has two chunks' worth of MFMAs to land instead of one.
+    constexpr int PSET = DEEP ? IG_PMAX / 2 : IG_PMAX;
     const int p_items = t.NPP * 8;
     const int c4 = threadIdx.x & 7;                      // 256 % 8 == 0: same channel quad for all items
     const float *xt = x + (((int64_t)n0 * g.IH + iy0) * g.IW + ix0) * g.Ci + c4 * 4;
-    int p_rel[IG_PMAX], p_lds[IG_PMAX], p_sc[IG_PMAX];
+    int p_rel[PSET], p_lds[PSET], p_sc[PSET];
     unsigned p_ok = 0;
     float4 pq[IG_PMAX];
 #pragma unroll
-    for (int k = 0; k < IG_PMAX; k++) {
+    for (int k = 0; k < PSET; k++) {
         const int pix = (threadIdx.x >> 3) + 32 * k;
         p_rel[k] = 0;
         p_sc[k] = 0;
@@ -297,24 +302,26 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             }
         }
     }
-    unsigned cur_ok = 0;      // validity of the items currently held in pq (p_ok restricted by ci < Ci)
-    int cur_ci = 0;
-    auto issue_patch = [&](int chunk) {   // raw loads only; consumers live in commit_patch
+    unsigned cur_ok[2] = {0, 0};   // validity of the items held in each register set (p_ok restricted by ci < Ci)
+    auto issue_patch = [&](int chunk, auto SET) {   // raw loads only; consumers live in commit_patch
+        constexpr int S = decltype(SET)::value;
         const int ci = chunk * CV_CK + c4 * 4;
-        cur_ci = ci;
-        cur_ok = ci < g.Ci ? p_ok : 0u;
+        const unsigned okm = ci < g.Ci ? p_ok : 0u;
+        cur_ok[S] = okm;
 #pragma unroll
-        for (int k = 0; k < IG_PMAX; k++) {
-            const bool ok = (cur_ok >> k) & 1u;
-            pq[k] = load4<VEC>(ok ? xt + p_rel[k] + chunk * CV_CK : x, ok, ci, g.Ci);
+        for (int k = 0; k < PSET; k++) {
+            const bool ok = (okm >> k) & 1u;
+            pq[S * PSET + k] = load4<VEC>(ok ? xt + p_rel[k] + chunk * CV_CK : x, ok, ci, g.Ci);
         }
     };
-    auto commit_patch = [&](int chunk) {
+    auto commit_patch = [&](int chunk, auto SET) {
+        constexpr int S = decltype(SET)::value;
+        const int ci0 = chunk * CV_CK + c4 * 4;
 #pragma unroll
-        for (int k = 0; k < IG_PMAX; k++) {
-            const bool ok = (cur_ok >> k) & 1u;
-            float4 v = pq[k];
-            if (iscale) v = mul4(v, load4<VEC>(ok ? iscale + p_sc[k] + chunk * CV_CK : iscale, ok, cur_ci, g.Ci));
+        for (int k = 0; k < PSET; k++) {
+            const bool ok = (cur_ok[S] >> k) & 1u;
+            float4 v = pq[S * PSET + k];
+            if (iscale) v = mul4(v, load4<VEC>(ok ? iscale + p_sc[k] + chunk * CV_CK : iscale, ok, ci0, g.Ci));
             if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 hi, lo;
             split4<SPLIT>(v, hi, lo);
@@ -323,23 +330,27 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds[k]) = lo;
             }
         }
-        // patches larger than IG_PMAX*32 pixels (stride-2 geometry): remaining items, synchronously
-        for (int it = threadIdx.x + 256 * IG_PMAX; it < p_items; it += 256) {
-            const int pix = it >> 3;
-            const unsigned e = ptab[pix];
-            const int n = n0 + (int)(e >> 20), iy = iy0 + (int)((e >> 10) & 1023), ix = ix0 + (int)(e & 1023);
-            const int ci = chunk * CV_CK + c4 * 4;
-            const bool ok = n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW && ci < g.Ci;
-            float4 v = load4<VEC>(ok ? x + (((int64_t)n * g.IH + iy) * g.IW + ix) * g.Ci + ci : x, ok, ci, g.Ci);
-            if (iscale) v = mul4(v, load4<VEC>(ok ? iscale + (int64_t)n * g.Ci + ci : iscale, ok, ci, g.Ci));
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            uint2 hi, lo;
-            split4<SPLIT>(v, hi, lo);
-            const int off = pix * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
-            *reinterpret_cast<uint2 *>(ph + off) = hi;
-            if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + off) = lo;
+        if (!DEEP) {
+            // patches larger than IG_PMAX*32 pixels (stride-2 geometry): remaining items, synchronously
+            for (int it = threadIdx.x + 256 * IG_PMAX; it < p_items; it += 256) {
+                const int pix = it >> 3;
+                const unsigned e = ptab[pix];
+                const int n = n0 + (int)(e >> 20), iy = iy0 + (int)((e >> 10) & 1023), ix = ix0 + (int)(e & 1023);
+                const int ci = chunk * CV_CK + c4 * 4;
+                const bool ok = n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW && ci < g.Ci;
+                float4 v = load4<VEC>(ok ? x + (((int64_t)n * g.IH + iy) * g.IW + ix) * g.Ci + ci : x, ok, ci, g.Ci);
+                if (iscale) v = mul4(v, load4<VEC>(ok ? iscale + (int64_t)n * g.Ci + ci : iscale, ok, ci, g.Ci));
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                uint2 hi, lo;
+                split4<SPLIT>(v, hi, lo);
+                const int off = pix * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
+                *reinterpret_cast<uint2 *>(ph + off) = hi;
+                if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + off) = lo;
+            }
         }
     };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -370,15 +381,16 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         }                                                               \
     } while (0)
 
-    // ---- prologue: patch(c_begin), W(0)
-    issue_patch(c_begin);
+    // ---- prologue: patch(c_begin) [+ patch(c_begin+1) when DEEP], W(0)
+    issue_patch(c_begin, S0{});
+    if (DEEP && c_begin + 1 < c_end) issue_patch(c_begin + 1, S1{});
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(
             wbase + ((int64_t)c_begin * g.nslices + g.wt[0]) * CV_WSTEP_BYTES);
         CV_WLOAD(src);
         CV_WSTORE(wbuf);
     }
-    commit_patch(c_begin);
+    commit_patch(c_begin, S0{});
     __syncthreads();
 
     int chunk = c_begin, tap = 0;
@@ -391,7 +403,13 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 wbase + ((int64_t)nchunk * g.nslices + g.wt[ntap]) * CV_WSTEP_BYTES);
             CV_WLOAD(src);
         }
-        if (tap == 0 && chunk + 1 < c_end) issue_patch(chunk + 1);   // next chunk's patch -> registers
+        if (tap == 0) {   // patch prefetch: next chunk (two ahead when DEEP) -> registers
+            const int cpre = chunk + (DEEP ? 2 : 1);
+            if (cpre < c_end) {
+                if (DEEP && ((cpre - c_begin) & 1)) issue_patch(cpre, S1{});
+                else issue_patch(cpre, S0{});
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);   // prefetches are issued before the MFMAs, consumed after
         {
             const unsigned char *wb = wbuf + (ks & 1) * CV_WSTEP_BYTES;
@@ -423,7 +441,8 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         if (more) {
             if (ntap == 0) {   // next k-step starts a new channel chunk: all waves are done with the patch
                 __syncthreads();
-                commit_patch(nchunk);
+                if (DEEP && ((nchunk - c_begin) & 1)) commit_patch(nchunk, S1{});
+                else commit_patch(nchunk, S0{});
             }
             unsigned char *wd = wbuf + ((ks + 1) & 1) * CV_WSTEP_BYTES;
             CV_WSTORE(wd);
@@ -490,7 +509,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
                                                             float *__restrict__ out, const float *__restrict__ iscale,
                                                             const float *__restrict__ oscale, float *__restrict__ ws,
                                                             const rick_conv_geom g, const ConvTiling t) {
-    igemm_body<SPLIT, VEC>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x);
+    if (t.NPP <= 32 * (IG_PMAX / 2)) igemm_body<SPLIT, VEC, true>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x);
+    else igemm_body<SPLIT, VEC, false>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x);
 }
 
 // Several geometries (the output-parity classes of a transposed convolution) in ONE launch: block ranges
@@ -499,6 +519,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
 #define IG_MAXCLS 4
 struct IgemmMulti {
     int ncls;
+    int deep;                        // all classes have NPP <= 160: two-ahead patch prefetch
     int blk_end[IG_MAXCLS];
     int64_t ws_off[IG_MAXCLS];       // float offset of each class's split-K workspace
     rick_conv_geom g[IG_MAXCLS];
@@ -519,8 +540,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_multi_kernel(const float *_
             c = i + 1;
             start = m.blk_end[i];
         }
-    igemm_body<SPLIT, VEC>(x, wpk, out, iscale, oscale, ws + m.ws_off[c], m.g[c], m.t[c], (int)blockIdx.x - start,
-                           m.blk_end[c] - start);
+    // every parity class of a transposed conv has a patch of <= 160 pixels (tile + at most one halo row/col)
+    // (the host only uses this kernel when every class qualifies for the two-ahead prefetch)
+    igemm_body<SPLIT, VEC, true>(x, wpk, out, iscale, oscale, ws + m.ws_off[c], m.g[c], m.t[c], (int)blockIdx.x - start,
+                                 m.blk_end[c] - start);
 }
 
 // out[n, pix(gy,gx), co] = alpha * oscale[n,co] * sum_s ws[s][n,gy,gx][co]
@@ -609,6 +632,7 @@ extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *
 static int plan_multi(const rick_conv_geom *geoms, int ngeom, IgemmMulti *m, size_t *lds_max, int64_t *ws_floats) {
     if (!geoms || ngeom < 1 || ngeom > IG_MAXCLS) return RICK_EINVAL;
     m->ncls = ngeom;
+    m->deep = 1;
     int64_t blocks = 0, wsf = 0;
     size_t lmax = 0;
     for (int c = 0; c < ngeom; c++) {
@@ -620,6 +644,7 @@ static int plan_multi(const rick_conv_geom *geoms, int ngeom, IgemmMulti *m, siz
         const size_t lds = 2 * CV_WSTEP_BYTES + 2 * (size_t)((t.NPP * 64 + 15) & ~15) + (size_t)t.NPP * 4;
         if (lds > 160 * 1024 || t.PH > 1023 || t.PW > 1023) return RICK_EINVAL;
         lmax = lds > lmax ? lds : lmax;
+        if (t.NPP > 32 * (IG_PMAX / 2)) m->deep = 0;
         blocks += (int64_t)t.ntx * t.nty * t.ntn * t.ncot * t.nsplit;
         if (blocks > 0x7fffffff) return RICK_EINVAL;
         m->blk_end[c] = (int)blocks;
@@ -667,6 +692,14 @@ extern "C" int rick_conv_igemm_multi_f32(const float *x, const void *packed_w, f
     float *ws = (float *)workspace;
     const unsigned char *wp = (const unsigned char *)packed_w;
     const bool vec = (geoms[0].Ci & 3) == 0;
+    if (!m.deep) {   // large patches: one ordinary launch per class
+        for (int c = 0; c < ngeom; c++) {
+            const int rc = rick_conv_igemm_f32(x, packed_w, out, iscale, oscale, &geoms[c],
+                                               m.t[c].nsplit > 1 ? (void *)(ws + m.ws_off[c]) : nullptr, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     if (geoms[0].split == 2) {
         if (vec) launch_igemm_multi<2, true>(lds, st, x, wp, out, iscale, oscale, ws, m);
         else launch_igemm_multi<2, false>(lds, st, x, wp, out, iscale, oscale, ws, m);
