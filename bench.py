@@ -32,8 +32,8 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(size=256):
-    """One non-reg iteration (D step fwd+bwd, G step fwd+bwd) of the CPU oracle at batch 1."""
+def cpu_baseline(size=256, batch=2):
+    """One non-reg iteration (D step fwd+bwd, G step fwd+bwd) of the CPU oracle at BASELINE configs[0]'s batch 2."""
     from oracle.model_ref import discriminator_ref, generator_ref
     from oracle.train_ref import d_logistic_loss_ref, g_nonsaturating_loss_ref
     from rick_amd.synth import synth_latents, synth_reals, synth_state_dict
@@ -44,7 +44,7 @@ def cpu_baseline(size=256):
     sd = synth_state_dict(discriminator_shapes(size))
     pg = [v.requires_grad_(True) for k, v in sg.items() if not k.startswith('noises.')]
     pd = [v.requires_grad_(True) for k, v in sd.items()]
-    z, real = synth_latents(1, seed=11), synth_reals(1, size=size, seed=11)
+    z, real = synth_latents(batch, seed=11), synth_reals(batch, size=size, seed=11)
     t0 = time.perf_counter()
     with torch.no_grad():
         fake, _ = generator_ref(sg, [z], size=size)
@@ -55,8 +55,8 @@ def cpu_baseline(size=256):
     fp, _ = discriminator_ref(sd, fake, size=size)
     torch.autograd.grad(g_nonsaturating_loss_ref(fp), pg, allow_unused=True)
     dt = time.perf_counter() - t0
-    return {'value': 1.0 / dt, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'1 non-reg iteration (D step + G step, fwd+bwd, no optimiser) at batch 1, {size}px, '
+    return {'value': batch / dt, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'1 non-reg iteration (D step + G step, fwd+bwd, no optimiser) at batch {batch}, {size}px, '
                       f'fp32 oneDNN, {dt:.1f} s'}
 
 

@@ -52,15 +52,16 @@ class DataParallelGrads:
     def attach(self, *flats):
         for flat in flats:
             buckets, cur_lo, cur_members = [], None, []
+            first = list(getattr(flat, 'opt_idx', range(len(flat.params))))[0]
             # parameters are laid out in forward order; gradients arrive roughly in reverse, so
             # buckets are cut from the END of the buffer towards the front
-            for i in reversed(range(len(flat.params))):
+            for i in reversed(getattr(flat, 'opt_idx', range(len(flat.params)))):
                 lo, hi = int(flat.offsets[i]), int(flat.offsets[i + 1])
                 if cur_lo is None:
                     cur_hi = hi
                 cur_lo = lo
                 cur_members.append(i)
-                if cur_hi - cur_lo >= self.bucket_elems or i == 0:
+                if cur_hi - cur_lo >= self.bucket_elems or i == first:
                     buckets.append({'lo': cur_lo, 'hi': cur_hi, 'members': list(cur_members)})
                     cur_lo, cur_members = None, []
             st = {'buckets': buckets, 'owner': {}, 'pending': [], 'works': [], 'launched': [], 'flat': flat}
@@ -70,8 +71,8 @@ class DataParallelGrads:
             self._state[id(flat)] = st
             self._arm(st)
             if self.world > 1:
-                for i, p in enumerate(flat.params):
-                    p.register_post_accumulate_grad_hook(self._make_hook(st, i))
+                for i in st['owner']:
+                    flat.params[i].register_post_accumulate_grad_hook(self._make_hook(st, i))
 
     def _arm(self, st):
         st['pending'] = [sum(1 for i in bk['members'] if st['flat'].params[i].requires_grad) for bk in st['buckets']]

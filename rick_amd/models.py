@@ -82,9 +82,17 @@ class EqualLinear(nn.Module):
         self.lr_mul = lr_mul
 
     def forward(self, x):
-        if self.activation:
-            return fused_leaky_relu(F.linear(x, self.weight * self.scale), self.bias * self.lr_mul)
-        return F.linear(x, self.weight * self.scale, bias=self.bias * self.lr_mul)
+        # x @ (W * scale)^T as one rocBLAS call (scale = GEMM alpha) instead of a [out, in] elementwise pass
+        bias = self.bias if self.lr_mul == 1 or self.bias is None else self.bias * self.lr_mul
+        if x.ndim != 2:
+            out = F.linear(x, self.weight * self.scale)
+            if self.activation:
+                return fused_leaky_relu(out, bias)
+            return out if bias is None else out + bias
+        if self.activation or bias is None:
+            out = torch.addmm(x.new_empty(1), x, self.weight.t(), beta=0, alpha=self.scale)
+            return fused_leaky_relu(out, bias) if self.activation else out
+        return torch.addmm(bias, x, self.weight.t(), beta=1, alpha=self.scale)
 
 
 class EqualConv2d(nn.Module):

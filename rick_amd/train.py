@@ -71,12 +71,15 @@ def requires_grad(model, flag=True, only=None):
 
 # ------------------------------------------------------------------ flat params / Adam / EMA
 class FlatParams:
-    """Re-homes a list of parameters into ONE flat fp32 buffer (each parameter becomes a view)
-    with a matching flat gradient buffer (``p.grad`` are views too).  One kernel then covers the
-    mask + Adam update of a whole network, one memset zeroes the gradients and one RCCL
-    all-reduce (optionally in buckets) averages them."""
+    """Re-homes the parameters of a network into ONE flat fp32 buffer (each parameter becomes a view)
+    with a matching flat gradient buffer (``p.grad`` are views too).  `opt_filter` marks the parameters an
+    optimiser owns; they must be contiguous in registration order (true for both reference networks:
+    ``convs.*`` of G, ``convs.1-6 + final_*`` of D) so that one kernel covers mask + Adam of the whole
+    slice, one memset zeroes its gradients, RCCL reduces contiguous buckets, and one kernel does the EMA
+    of the entire network."""
 
-    def __init__(self, named_params):
+    def __init__(self, named_params, opt_filter=None):
+        named_params = list(named_params)
         self.names = [n for n, _ in named_params]
         self.params = [p for _, p in named_params]
         sizes = [p.numel() for p in self.params]
@@ -90,9 +93,14 @@ class FlatParams:
             p.data = self.flat[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
         self.index = {n: i for i, n in enumerate(self.names)}
+        self.opt_idx = [i for i, n in enumerate(self.names) if opt_filter is None or opt_filter(n)]
+        if self.opt_idx and self.opt_idx != list(range(self.opt_idx[0], self.opt_idx[-1] + 1)):
+            raise RuntimeError('FlatParams: optimised parameters must be contiguous in registration order')
+        self.lo = int(self.offsets[self.opt_idx[0]]) if self.opt_idx else 0
+        self.hi = int(self.offsets[self.opt_idx[-1] + 1]) if self.opt_idx else 0
 
     def zero_grad(self):
-        self.grad.zero_()
+        self.grad[self.lo:self.hi].zero_()
 
     def segment(self, name):
         i = self.index[name]
@@ -100,9 +108,9 @@ class FlatParams:
 
 
 class MaskedFlatAdam:
-    """torch.optim.Adam(lr, betas, eps=1e-8) over a FlatParams, with RICK's freeze / prune masks
-    applied in the same kernel (train_dynamic_update_prune.py:427-438, 522-540).  Parameters
-    whose ``requires_grad`` is False at step time are skipped exactly like torch skips
+    """torch.optim.Adam(lr, betas, eps=1e-8) over the optimised slice of a FlatParams, with RICK's
+    freeze / prune masks applied in the same kernel (train_dynamic_update_prune.py:427-438, 522-540).
+    Parameters whose ``requires_grad`` is False at step time are skipped exactly like torch skips
     ``grad is None`` (per-parameter step counts, used by the warm-up stage :202-211)."""
 
     def __init__(self, flat, lr, betas, eps=1e-8):
@@ -117,32 +125,37 @@ class MaskedFlatAdam:
 
     def step(self):
         fp = self.fp
-        active = [p.requires_grad for p in fp.params]
-        i, n = 0, len(fp.params)
-        while i < n:
+        idx = fp.opt_idx
+        active = {i: fp.params[i].requires_grad for i in idx}
+        k, n = 0, len(idx)
+        while k < n:
+            i = idx[k]
             if not active[i]:
-                i += 1
+                k += 1
                 continue
-            j = i
+            kk = k
             self.steps[i] += 1
-            while j + 1 < n and active[j + 1] and self.steps[j + 1] + 1 == self.steps[i]:
-                j += 1
-                self.steps[j] += 1
-            lo, hi = int(fp.offsets[i]), int(fp.offsets[j + 1])
+            while kk + 1 < n and active[idx[kk + 1]] and self.steps[idx[kk + 1]] + 1 == self.steps[i]:
+                kk += 1
+                self.steps[idx[kk]] += 1
+            lo, hi = int(fp.offsets[i]), int(fp.offsets[idx[kk] + 1])
             t = self.steps[i]
             b1, b2 = self.betas
             mk = None if self.mask is None else self.mask[lo:hi]
             check(lib.rick_masked_adam_f32(ptr(fp.flat[lo:hi]), ptr(fp.grad[lo:hi]), ptr(self.m[lo:hi]),
                                            ptr(self.v[lo:hi]), ptr(mk), hi - lo, self.lr, b1, b2, self.eps,
                                            1.0 - b1 ** t, 1.0 - b2 ** t, stream_ptr()), 'rick_masked_adam_f32')
-            i = j + 1
+            k = kk + 1
         op.bump_weights_epoch()
 
 
-def ema_accumulate(ema_params, params, decay):
-    """accumulate() of the reference (train_dynamic_update_prune.py:68-73) over matched lists."""
-    for e, p in zip(ema_params, params):
-        check(lib.rick_ema_f32(ptr(e.data), ptr(p.data), e.numel(), decay, stream_ptr()), 'rick_ema_f32')
+def ema_flat(ema_flat_params, flat_params, decay):
+    """accumulate() of the reference (train_dynamic_update_prune.py:68-73) over every parameter of a
+    network in ONE launch (both sides are FlatParams with the same layout)."""
+    if ema_flat_params.total != flat_params.total:
+        raise RuntimeError('ema_flat: layouts differ')
+    check(lib.rick_ema_f32(ptr(ema_flat_params.flat), ptr(flat_params.flat), flat_params.total, decay, stream_ptr()),
+          'rick_ema_f32')
     op.bump_weights_epoch()
 
 
@@ -315,9 +328,10 @@ class RickTrainer:
     def __init__(self, cfg, generator, discriminator, g_ema, d_ema, dp=None):
         self.cfg, self.g, self.d, self.g_ema, self.d_ema, self.dp = cfg, generator, discriminator, g_ema, d_ema, dp
         self.device = next(generator.parameters()).device
-        g_named = [(n, p) for n, p in generator.named_parameters() if g_optim_filter(n)]
-        d_named = [(n, p) for n, p in discriminator.named_parameters() if d_optim_filter(n)]
-        self.g_flat, self.d_flat = FlatParams(g_named), FlatParams(d_named)
+        self.g_flat = FlatParams(generator.named_parameters(), g_optim_filter)
+        self.d_flat = FlatParams(discriminator.named_parameters(), d_optim_filter)
+        self.g_ema_flat = FlatParams(g_ema.named_parameters())
+        self.d_ema_flat = FlatParams(d_ema.named_parameters())
         g_ratio = cfg.g_reg_every / (cfg.g_reg_every + 1)
         d_ratio = cfg.d_reg_every / (cfg.d_reg_every + 1)
         self.g_optim = MaskedFlatAdam(self.g_flat, cfg.lr * g_ratio, (0 ** g_ratio, 0.99 ** g_ratio))
@@ -434,9 +448,8 @@ class RickTrainer:
 
     def ema_step(self):
         """accumulate(g_ema, g), accumulate(d_ema, d) (:697-698) over ALL named parameters."""
-        dec = self.cfg.ema_decay
-        ema_accumulate([p for _, p in self.g_ema.named_parameters()], [p for _, p in self.g.named_parameters()], dec)
-        ema_accumulate([p for _, p in self.d_ema.named_parameters()], [p for _, p in self.d.named_parameters()], dec)
+        ema_flat(self.g_ema_flat, self.g_flat, self.cfg.ema_decay)
+        ema_flat(self.d_ema_flat, self.d_flat, self.cfg.ema_decay)
 
     # ---- Fisher sweep (:214-393)
     def fisher_sweep(self, latents, reals, first, fixed_noise=False):
