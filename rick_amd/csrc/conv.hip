@@ -503,14 +503,13 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     }
 }
 
-template <int SPLIT, bool VEC>
+template <int SPLIT, bool VEC, bool DEEP>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restrict__ x,
                                                             const unsigned char *__restrict__ wpk,
                                                             float *__restrict__ out, const float *__restrict__ iscale,
                                                             const float *__restrict__ oscale, float *__restrict__ ws,
                                                             const rick_conv_geom g, const ConvTiling t) {
-    if (t.NPP <= 32 * (IG_PMAX / 2)) igemm_body<SPLIT, VEC, true>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x);
-    else igemm_body<SPLIT, VEC, false>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x);
+    igemm_body<SPLIT, VEC, DEEP>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x);
 }
 
 // Several geometries (the output-parity classes of a transposed convolution) in ONE launch: block ranges
@@ -588,13 +587,22 @@ extern "C" int64_t rick_conv_igemm_workspace_bytes(const rick_conv_geom *g) {
     return t.nsplit > 1 ? (int64_t)t.nsplit * g->N * g->GH * g->GW * g->Co * 4 : 0;
 }
 
+template <int SPLIT, bool VEC, bool DEEP>
+static void launch_igemm_k(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
+                           const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
+                           const ConvTiling &t) {
+    (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<SPLIT, VEC, DEEP>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv_igemm_kernel<SPLIT, VEC, DEEP>), dim3(nwg), dim3(256), lds, st, x, wp, out, iscale, oscale, ws,
+                       *g, t);
+}
+
 template <int SPLIT, bool VEC>
 static void launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
                          const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
                          const ConvTiling &t) {
-    (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<SPLIT, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    hipLaunchKernelGGL((conv_igemm_kernel<SPLIT, VEC>), dim3(nwg), dim3(256), lds, st, x, wp, out, iscale, oscale, ws, *g, t);
+    if (t.NPP <= 32 * (IG_PMAX / 2)) launch_igemm_k<SPLIT, VEC, true>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
+    else launch_igemm_k<SPLIT, VEC, false>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
 }
 
 extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *out, const float *iscale,
