@@ -84,6 +84,8 @@ def main():
     rank, local, world = init_from_env()
     if world != args.gpus and not (world == 1 and args.gpus == 1):
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    if os.environ.get('RICK_FORCE_DEVICE') is not None:      # functional test: several ranks on one GPU (gloo)
+        local = int(os.environ['RICK_FORCE_DEVICE'])
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     op.set_precision(args.precision)
@@ -127,7 +129,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 

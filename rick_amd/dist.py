@@ -34,7 +34,7 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('RICK_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -82,7 +82,14 @@ class DataParallelGrads:
     def _launch(self, st, b):
         bk = st['buckets'][b]
         view = st['flat'].grad[bk['lo']:bk['hi']]
-        st['works'].append((dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True), view))
+        if view.is_cuda and dist.get_backend(self.group) == 'gloo':
+            # functional-test path only (two ranks sharing one GPU cannot use RCCL): stage through the host
+            host = view.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            view.copy_(host)
+            st['works'].append((None, view))
+        else:
+            st['works'].append((dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True), view))
         st['launched'][b] = True
 
     def _make_hook(self, st, i):
@@ -104,7 +111,8 @@ class DataParallelGrads:
                 self._launch(st, b)
         inv = 1.0 / self.world
         for work, view in st['works']:
-            work.wait()
+            if work is not None:
+                work.wait()
             view.mul_(inv)
         self._arm(st)
 
@@ -113,7 +121,12 @@ class DataParallelGrads:
         if self.world == 1:
             return
         flat = torch.cat([v.reshape(-1) for v in vectors])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        if flat.is_cuda and dist.get_backend(self.group) == 'gloo':
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            flat = host.to(flat.device)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         off = 0
         for v in vectors:
             n = v.numel()
@@ -126,4 +139,9 @@ class DataParallelGrads:
             return
         for m in modules:
             for t in list(m.parameters()) + list(m.buffers()):
-                dist.broadcast(t.data, src=src, group=self.group)
+                if t.is_cuda and dist.get_backend(self.group) == 'gloo':
+                    host = t.data.cpu()
+                    dist.broadcast(host, src=src, group=self.group)
+                    t.data.copy_(host)
+                else:
+                    dist.broadcast(t.data, src=src, group=self.group)
