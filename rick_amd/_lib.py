@@ -77,7 +77,14 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device (raw accessor: ~0.3 us vs ~3.5 us for
+    torch.cuda.current_stream().cuda_stream; every kernel launch pays it)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -129,6 +129,9 @@ def _geom(N, IH, IW, Ci, OH, OW, Co, GH, GW, is_, os_, oy0, ox0, taps, nslices, 
     return g
 
 
+_geom_cache = {}
+
+
 def _igemm_ws(g, like):
     """Split-K workspace for launches with few output tiles (None when the kernel does not need one)."""
     nbytes = lib.rick_conv_igemm_workspace_bytes(ctypes.byref(g))
@@ -145,47 +148,62 @@ def conv_out_size(i, k, s, p):
 def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0):
     x = _nhwc(x)
     N, I, IH, IW = x.shape
-    OH, OW = conv_out_size(IH, kh, s, p), conv_out_size(IW, kw, s, p)
+    key = ('c', N, I, IH, IW, O, kh, kw, s, p, alpha, _SPLIT)
+    ent = _geom_cache.get(key)
+    if ent is None:
+        OH, OW = conv_out_size(IH, kh, s, p), conv_out_size(IW, kw, s, p)
+        taps = [(ky - p, kx - p, ky * kw + kx) for ky in range(kh) for kx in range(kw)]
+        g = _geom(N, IH, IW, I, OH, OW, O, OH, OW, s, 1, 0, 0, taps, kh * kw, alpha)
+        nbytes = lib.rick_conv_igemm_workspace_bytes(ctypes.byref(g))
+        if nbytes < 0:
+            raise RuntimeError('rick_conv_igemm_workspace_bytes: invalid geometry')
+        ent = (g, ctypes.byref(g), nbytes, OH, OW, 2.0 * N * OH * OW * O * I * kh * kw,
+               f'conv {I}->{O} k{kh} s{s} N{N} {IH}x{IW}')
+        _geom_cache[key] = ent
+    g, gref, nbytes, OH, OW, flops, tag = ent
     y = _empty_nhwc(N, O, OH, OW, x)
-    taps = [(ky - p, kx - p, ky * kw + kx) for ky in range(kh) for kx in range(kw)]
-    g = _geom(N, IH, IW, I, OH, OW, O, OH, OW, s, 1, 0, 0, taps, kh * kw, alpha)
-    check(_launch('igemm', 2.0 * N * OH * OW * O * I * kh * kw, lib.rick_conv_igemm_f32, ptr(x), ptr(wp), ptr(y),
-                  ptr(iscale), ptr(oscale), ctypes.byref(g), ptr(_igemm_ws(g, x)), stream_ptr(),
-                  tag=f'conv {I}->{O} k{kh} s{s} N{N} {IH}x{IW}'), 'rick_conv_igemm_f32')
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
+    check(_launch('igemm', flops, lib.rick_conv_igemm_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), gref,
+                  ptr(ws), stream_ptr(), tag=tag), 'rick_conv_igemm_f32')
     return y
 
 
 def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alpha=1.0):
-    """y[q] += w[k] x[pos], q = pos*s + k - p, one launch per output parity class."""
+    """y[q] += w[k] x[pos], q = pos*s + k - p: the output parity classes (s*s of them) run as one launch."""
     x = _nhwc(x)
     N, I, IH, IW = x.shape
     OH, OW = out_hw
-    classes = []
-    for py in range(s):
-        for px in range(s):
-            taps = [((py + p - ky) // s, (px + p - kx) // s, ky * kw + kx)
-                    for ky in range(kh) for kx in range(kw)
-                    if (py + p - ky) % s == 0 and (px + p - kx) % s == 0]
-            GH, GW = (OH - py + s - 1) // s, (OW - px + s - 1) // s
-            if GH > 0 and GW > 0:
-                classes.append((py, px, GH, GW, taps))
-    full = all(len(c[4]) > 0 for c in classes)
+    key = ('t', N, I, IH, IW, O, kh, kw, s, p, OH, OW, alpha, _SPLIT)
+    ent = _geom_cache.get(key)
+    if ent is None:
+        classes = []
+        for py in range(s):
+            for px in range(s):
+                taps = [((py + p - ky) // s, (px + p - kx) // s, ky * kw + kx)
+                        for ky in range(kh) for kx in range(kw)
+                        if (py + p - ky) % s == 0 and (px + p - kx) % s == 0]
+                GH, GW = (OH - py + s - 1) // s, (OW - px + s - 1) // s
+                if GH > 0 and GW > 0:
+                    classes.append((py, px, GH, GW, taps))
+        full = all(len(c[4]) > 0 for c in classes)
+        live = [c for c in classes if c[4]]
+        geoms = (ConvGeom * len(live))()
+        flops = 0.0
+        for i, (py, px, GH, GW, taps) in enumerate(live):
+            geoms[i] = _geom(N, IH, IW, I, OH, OW, O, GH, GW, 1, s, py, px, taps, kh * kw, alpha)
+            flops += 2.0 * N * GH * GW * O * I * len(taps)
+        nbytes = lib.rick_conv_igemm_multi_workspace_bytes(geoms, len(live))
+        if nbytes < 0:
+            raise RuntimeError('rick_conv_igemm_multi_workspace_bytes: invalid geometry')
+        ent = (geoms, len(live), nbytes, full, flops, f'convT {I}->{O} k{kh} s{s} N{N} {IH}x{IW}')
+        _geom_cache[key] = ent
+    geoms, ngeom, nbytes, full, flops, tag = ent
     y = _empty_nhwc(N, O, OH, OW, x)
     if not full:
         y.zero_()
-    live = [c for c in classes if c[4]]
-    geoms = (ConvGeom * len(live))()
-    flops = 0.0
-    for i, (py, px, GH, GW, taps) in enumerate(live):
-        geoms[i] = _geom(N, IH, IW, I, OH, OW, O, GH, GW, 1, s, py, px, taps, kh * kw, alpha)
-        flops += 2.0 * N * GH * GW * O * I * len(taps)
-    nbytes = lib.rick_conv_igemm_multi_workspace_bytes(geoms, len(live))
-    if nbytes < 0:
-        raise RuntimeError('rick_conv_igemm_multi_workspace_bytes: invalid geometry')
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     check(_launch('igemm', flops, lib.rick_conv_igemm_multi_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale),
-                  geoms, len(live), ptr(ws), stream_ptr(), tag=f'convT {I}->{O} k{kh} s{s} N{N} {IH}x{IW}'),
-          'rick_conv_igemm_multi_f32')
+                  geoms, ngeom, ptr(ws), stream_ptr(), tag=tag), 'rick_conv_igemm_multi_f32')
     return y
 
 
@@ -194,18 +212,24 @@ def _wgrad_launch(a, b, kh, kw, s, p, alpha=1.0, ascale=None, bscale=None):
     a, b = _nhwc(a), _nhwc(b)
     N, O, AH, AW = a.shape
     _, I, BH, BW = b.shape
+    key = ('w', N, O, AH, AW, I, BH, BW, kh, kw, s, p, alpha, _SPLIT)
+    ent = _geom_cache.get(key)
+    if ent is None:
+        taps = [(ky - p, kx - p, ky * kw + kx) for ky in range(kh) for kx in range(kw)]
+        if len(taps) > 9:
+            raise RuntimeError('wgrad: kernels larger than 3x3 are not supported')
+        g = _geom(N, BH, BW, I, AH, AW, O, AH, AW, s, 1, 0, 0, taps, kh * kw, alpha)
+        nbytes = lib.rick_conv_wgrad_workspace_bytes(ctypes.byref(g))
+        if nbytes < 0:
+            raise RuntimeError('rick_conv_wgrad_workspace_bytes: invalid geometry')
+        ent = (g, ctypes.byref(g), max(nbytes, 16), 2.0 * N * AH * AW * O * I * kh * kw,
+               f'wgrad {I}x{O} k{kh} s{s} N{N} a{AH}x{AW} b{BH}x{BW}')
+        _geom_cache[key] = ent
+    g, gref, nbytes, flops, tag = ent
     gw = torch.empty((O, I, kh, kw), device=a.device, dtype=a.dtype)
-    taps = [(ky - p, kx - p, ky * kw + kx) for ky in range(kh) for kx in range(kw)]
-    if len(taps) > 9:
-        raise RuntimeError('wgrad: kernels larger than 3x3 are not supported')
-    g = _geom(N, BH, BW, I, AH, AW, O, AH, AW, s, 1, 0, 0, taps, kh * kw, alpha)
-    nbytes = lib.rick_conv_wgrad_workspace_bytes(ctypes.byref(g))
-    if nbytes < 0:
-        raise RuntimeError('rick_conv_wgrad_workspace_bytes: invalid geometry')
-    ws = torch.empty(max(nbytes, 16), device=a.device, dtype=torch.uint8)
-    check(_launch('wgrad', 2.0 * N * AH * AW * O * I * kh * kw, lib.rick_conv_wgrad_f32, ptr(b), ptr(a), ptr(gw),
-                  I * kh * kw, kh * kw, 1, ptr(ascale), ptr(bscale), ctypes.byref(g), 0, ptr(ws), stream_ptr(),
-                  tag=f'wgrad {I}x{O} k{kh} s{s} N{N} a{AH}x{AW} b{BH}x{BW}'), 'rick_conv_wgrad_f32')
+    ws = torch.empty(nbytes, device=a.device, dtype=torch.uint8)
+    check(_launch('wgrad', flops, lib.rick_conv_wgrad_f32, ptr(b), ptr(a), ptr(gw), I * kh * kw, kh * kw, 1,
+                  ptr(ascale), ptr(bscale), gref, 0, ptr(ws), stream_ptr(), tag=tag), 'rick_conv_wgrad_f32')
     return gw
 
 
