@@ -129,6 +129,7 @@ struct ConvTiling {
     int dymin, dxmin;
     int PH, PW, NPP;            // patch extents (input pixels), NPP = nb*PH*PW
     int nchunks, ncot;
+    int nbe;                    // images per tile actually used (min(nb, N)); patch holds nbe images
     int nsplit, cps;            // igemm split-K over channel chunks: splits, chunks per split
     int debug;                  // ablation switches for tools/bench_conv.py (RICK_CONV_DEBUG); 0 in production
 };
@@ -151,9 +152,10 @@ static int make_tiling(const rick_conv_geom *g, int tile_positions, ConvTiling *
     t->tw_log2 = tw;
     t->th_log2 = th;
     t->nb = tile_positions >> (tw + th);
+    t->nbe = t->nb < g->N ? t->nb : g->N;
     t->ntx = cdiv(g->GW, 1 << tw);
     t->nty = cdiv(g->GH, 1 << th);
-    t->ntn = cdiv(g->N, t->nb);
+    t->ntn = cdiv(g->N, t->nbe);
     int dymin = g->dy[0], dymax = g->dy[0], dxmin = g->dx[0], dxmax = g->dx[0];
     for (int i = 1; i < g->ntaps; i++) {
         dymin = g->dy[i] < dymin ? g->dy[i] : dymin;
@@ -165,7 +167,7 @@ static int make_tiling(const rick_conv_geom *g, int tile_positions, ConvTiling *
     t->dxmin = dxmin;
     t->PH = ((1 << th) - 1) * g->is + (dymax - dymin) + 1;
     t->PW = ((1 << tw) - 1) * g->is + (dxmax - dxmin) + 1;
-    t->NPP = t->nb * t->PH * t->PW;
+    t->NPP = t->nbe * t->PH * t->PW;
     t->nchunks = cdiv(g->Ci, CV_CK);
     t->ncot = cdiv(g->Co, CV_BM);
     t->nsplit = 1;
@@ -225,7 +227,9 @@ __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(
 
 // ==========================================================================================
 // Forward / data-gradient kernel.
-#define IG_PMAX 10   // patch float4 per thread prefetched in registers (covers NPP <= 320 pixels)
+#define IG_PMAX 10        // non-DEEP: patch float4 per thread prefetched in registers (NPP <= 320 pixels)
+#define IG_PSET_DEEP 6     // DEEP: two register sets of 6 (NPP <= 192 pixels), chunks prefetched two ahead
+#define IG_DEEP_NPP (32 * IG_PSET_DEEP)
 
 template <int SPLIT, bool VEC, bool DEEP>
 __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const unsigned char *__restrict__ wpk,
@@ -251,7 +255,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     pt /= t.ntx;
     const int ty_i = pt % t.nty;
     const int tn_i = pt / t.nty;
-    const int gx0 = tx_i << t.tw_log2, gy0 = ty_i << t.th_log2, n0 = tn_i * t.nb;
+    const int gx0 = tx_i << t.tw_log2, gy0 = ty_i << t.th_log2, n0 = tn_i * t.nbe;
     const int iy0 = gy0 * g.is + t.dymin, ix0 = gx0 * g.is + t.dxmin;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -269,7 +273,9 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int pos = wn * 64 + j * 16 + l15;
-        const int px = pos & tw_mask, py = (pos >> t.tw_log2) & th_mask, nbi = pos >> (t.tw_log2 + t.th_log2);
+        const int px = pos & tw_mask, py = (pos >> t.tw_log2) & th_mask;
+        int nbi = pos >> (t.tw_log2 + t.th_log2);
+        nbi = nbi < t.nbe ? nbi : t.nbe - 1;     // image slots beyond nbe are masked in the epilogue; keep LDS reads in range
         pb[j] = (nbi * t.PH + py * g.is) * t.PW + px * g.is;
     }
 
@@ -278,13 +284,14 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     // DEEP (patches of <= 160 pixels: 1x1 convs and the parity classes of transposed convs, whose chunks
     // last only 1-4 k-steps): the IG_PMAX register slots form TWO sets of 5 and chunks are prefetched two
     // ahead, so a load has two chunks' worth of MFMAs to land instead of one.
-    constexpr int PSET = DEEP ? IG_PMAX / 2 : IG_PMAX;
+    constexpr int PSET = DEEP ? IG_PSET_DEEP : IG_PMAX;
+    constexpr int PREGS = DEEP ? 2 * IG_PSET_DEEP : IG_PMAX;
     const int p_items = t.NPP * 8;
     const int c4 = threadIdx.x & 7;                      // 256 % 8 == 0: same channel quad for all items
     const float *xt = x + (((int64_t)n0 * g.IH + iy0) * g.IW + ix0) * g.Ci + c4 * 4;
     int p_rel[PSET], p_lds[PSET], p_sc[PSET];
     unsigned p_ok = 0;
-    float4 pq[IG_PMAX];
+    float4 pq[PREGS];
 #pragma unroll
     for (int k = 0; k < PSET; k++) {
         const int pix = (threadIdx.x >> 3) + 32 * k;
@@ -459,7 +466,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         const int pos = wn * 64 + j * 16 + l15;
         const int px = pos & tw_mask, py = (pos >> t.tw_log2) & th_mask, nbi = pos >> (t.tw_log2 + t.th_log2);
         const int n = n0 + nbi, gy = gy0 + py, gx = gx0 + px;
-        if (n >= g.N || gy >= g.GH || gx >= g.GW) continue;
+        if (nbi >= t.nbe || n >= g.N || gy >= g.GH || gx >= g.GW) continue;
         if (t.nsplit > 1) {   // raw partial sums -> workspace [split][n, gy, gx][Co]; scaled in the reduce kernel
             float *wrow = ws + (((int64_t)split * g.N + n) * g.GH * g.GW + (int64_t)gy * g.GW + gx) * g.Co;
 #pragma unroll
@@ -515,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
 // Several geometries (the output-parity classes of a transposed convolution) in ONE launch: block ranges
 // [blk_end[c-1], blk_end[c]) run class c.  Short-K classes (1 or 2 taps) overlap with the long ones instead
 // of each paying its own launch, fill and tail.
-#define IG_MAXCLS 4
+#define IG_MAXCLS 8
 struct IgemmMulti {
     int ncls;
     int deep;                        // all classes have NPP <= 160: two-ahead patch prefetch
@@ -533,9 +540,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_multi_kernel(const float *_
                                                                   const float *__restrict__ oscale,
                                                                   float *__restrict__ ws, const IgemmMulti m) {
     int c = 0, start = 0;
-#pragma unroll
-    for (int i = 0; i < IG_MAXCLS - 1; i++)
-        if (i + 1 < m.ncls && (int)blockIdx.x >= m.blk_end[i]) {
+    for (int i = 0; i + 1 < m.ncls; i++)
+        if ((int)blockIdx.x >= m.blk_end[i]) {
             c = i + 1;
             start = m.blk_end[i];
         }
@@ -601,7 +607,7 @@ template <int SPLIT, bool VEC>
 static void launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
                          const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
                          const ConvTiling &t) {
-    if (t.NPP <= 32 * (IG_PMAX / 2)) launch_igemm_k<SPLIT, VEC, true>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
+    if (t.NPP <= IG_DEEP_NPP) launch_igemm_k<SPLIT, VEC, true>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
     else launch_igemm_k<SPLIT, VEC, false>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
 }
 
@@ -652,7 +658,7 @@ static int plan_multi(const rick_conv_geom *geoms, int ngeom, IgemmMulti *m, siz
         const size_t lds = 2 * CV_WSTEP_BYTES + 2 * (size_t)((t.NPP * 64 + 15) & ~15) + (size_t)t.NPP * 4;
         if (lds > 160 * 1024 || t.PH > 1023 || t.PW > 1023) return RICK_EINVAL;
         lmax = lds > lmax ? lds : lmax;
-        if (t.NPP > 32 * (IG_PMAX / 2)) m->deep = 0;
+        if (t.NPP > IG_DEEP_NPP) m->deep = 0;
         blocks += (int64_t)t.ntx * t.nty * t.ntn * t.ncot * t.nsplit;
         if (blocks > 0x7fffffff) return RICK_EINVAL;
         m->blk_end[c] = (int)blocks;
@@ -792,7 +798,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             const int r = kk * 32 + G * 8 + h * 4 + q;
             a_row[kk][h] = r * 256;
             a_key[kk][h] = wg_key(r) * 32;
-            const int px = r & tw_mask, py = (r >> t.tw_log2) & th_mask, nbi = r >> (t.tw_log2 + t.th_log2);
+            const int px = r & tw_mask, py = (r >> t.tw_log2) & th_mask;
+            int nbi = r >> (t.tw_log2 + t.th_log2);
+            nbi = nbi < t.nbe ? nbi : t.nbe - 1;   // masked rows (zero gy) still read finite patch data
             pbase[kk][h] = (nbi * t.PH + py * g.is) * t.PW + px * g.is;
         }
     const int b_kg = wn * 2 + (p >> 1), b_sub = (p & 1) * 8;
@@ -816,7 +824,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         const int r = (threadIdx.x >> 5) + 8 * k;
         const int px = r & tw_mask, py = (r >> t.tw_log2) & th_mask, nbi = r >> (t.tw_log2 + t.th_log2);
         g_rel[k] = ((nbi * g.OH + py * g.os) * g.OW + px * g.os) * g.Co;
-        g_pyx[k] = gco < g.Co ? (((unsigned)nbi << 20) | ((unsigned)py << 10) | (unsigned)px) : 0xffffffffu;
+        g_pyx[k] = (gco < g.Co && nbi < t.nbe) ? (((unsigned)nbi << 20) | ((unsigned)py << 10) | (unsigned)px) : 0xffffffffu;
         g_lds[k] = r * 256 + ((gc4 * 8) ^ (wg_key(r) * 32));
     }
 #pragma unroll
@@ -843,7 +851,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         pt /= t.ntx;
         const int ty_i = pt % t.nty;
         const int tn_i = pt / t.nty;
-        const int gx0 = tx_i << t.tw_log2, gy0 = ty_i << t.th_log2, n0 = tn_i * t.nb;
+        const int gx0 = tx_i << t.tw_log2, gy0 = ty_i << t.th_log2, n0 = tn_i * t.nbe;
         const int iy0 = gy0 * g.is + t.dymin, ix0 = gx0 * g.is + t.dxmin;
         const float *gbase = gy + (((int64_t)n0 * g.OH + gy0 * g.os + g.oy0) * g.OW + gx0 * g.os + g.ox0) * g.Co + gco;
         const float *xbase = x + (((int64_t)n0 * g.IH + iy0) * g.IW + ix0) * g.Ci + pci;

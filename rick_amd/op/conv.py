@@ -130,6 +130,7 @@ def _geom(N, IH, IW, Ci, OH, OW, Co, GH, GW, is_, os_, oy0, ox0, taps, nslices, 
 
 
 _geom_cache = {}
+_EDGE_STRIPS = False   # interior + 1-wide strips for (8k+1)x(16k+1) class grids: measured neutral on MI355X, kept off
 
 
 def _igemm_ws(g, like):
@@ -187,11 +188,28 @@ def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alph
                     classes.append((py, px, GH, GW, taps))
         full = all(len(c[4]) > 0 for c in classes)
         live = [c for c in classes if c[4]]
-        geoms = (ConvGeom * len(live))()
+        # A class grid of (8k+1) x (16k+1) positions (stride-2 transposed conv of an 8k x 16k input) would
+        # pad almost a whole extra tile row / column: cut it into an aligned interior plus 1-wide edge strips.
+        rects = []
+        for (py, px, GH, GW, taps) in live:
+            ys = [(0, GH - 1), (GH - 1, GH)] if (_EDGE_STRIPS and GH > 16 and GH % 8 == 1) else [(0, GH)]
+            xs = [(0, GW - 1), (GW - 1, GW)] if (_EDGE_STRIPS and GW > 16 and GW % 16 == 1) else [(0, GW)]
+            parts = [(ys[0], xs[0])]
+            if len(ys) > 1:
+                parts.append((ys[1], (0, GW)))
+            if len(xs) > 1:
+                parts.append((ys[0], xs[1]))
+            for (y0, y1), (x0, x1) in parts:
+                rects.append((py + y0 * s, px + x0 * s, y1 - y0, x1 - x0,
+                              [(dy + y0, dx + x0, wt) for dy, dx, wt in taps]))
+        if len(rects) > 8:
+            rects = [(py, px, GH, GW, taps) for (py, px, GH, GW, taps) in live]
+        geoms = (ConvGeom * len(rects))()
         flops = 0.0
-        for i, (py, px, GH, GW, taps) in enumerate(live):
-            geoms[i] = _geom(N, IH, IW, I, OH, OW, O, GH, GW, 1, s, py, px, taps, kh * kw, alpha)
+        for i, (oy0, ox0, GH, GW, taps) in enumerate(rects):
+            geoms[i] = _geom(N, IH, IW, I, OH, OW, O, GH, GW, 1, s, oy0, ox0, taps, kh * kw, alpha)
             flops += 2.0 * N * GH * GW * O * I * len(taps)
+        live = rects
         nbytes = lib.rick_conv_igemm_multi_workspace_bytes(geoms, len(live))
         if nbytes < 0:
             raise RuntimeError('rick_conv_igemm_multi_workspace_bytes: invalid geometry')
