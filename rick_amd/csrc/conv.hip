@@ -177,6 +177,10 @@ static int make_tiling(const rick_conv_geom *g, int tile_positions, ConvTiling *
     return 0;
 }
 
+// Stride-2 inputs need a patch of ~4x the position tile; a 64-position block (each wave 64 co x 32 positions)
+// keeps it at ~37 KB so two blocks still fit per CU.
+static int igemm_tile_positions(const rick_conv_geom *g) { return (g->is >= 2 && g->ntaps > 1) ? 64 : CV_BN; }
+
 // Split-K plan for launches with too few blocks to fill 256 CUs (the 4x4..32x32, 512-channel layers:
 // K = 4608 is long while there are only 4..128 output tiles).
 static void igemm_plan_split(ConvTiling *t) {
@@ -231,7 +235,7 @@ __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(
 #define IG_PSET_DEEP 6     // DEEP: two register sets of 6 (NPP <= 192 pixels), chunks prefetched two ahead
 #define IG_DEEP_NPP (32 * IG_PSET_DEEP)
 
-template <int SPLIT, bool VEC, bool DEEP>
+template <int SPLIT, bool VEC, bool DEEP, int NJ>
 __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const unsigned char *__restrict__ wpk,
                                            float *__restrict__ out, const float *__restrict__ iscale,
                                            const float *__restrict__ oscale, float *__restrict__ ws,
@@ -268,11 +272,11 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         const int row = wm * 64 + i * 16 + l15;
         a_off[i] = row * 64 + cv_swz(kg, row) * 16;
     }
-    int pb[4];
+    int pb[NJ];   // NJ = position tiles of 16 per wave: 4 (128-position block) or 2 (64-position block, stride-2 input)
     const int tw_mask = (1 << t.tw_log2) - 1, th_mask = (1 << t.th_log2) - 1;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int pos = wn * 64 + j * 16 + l15;
+    for (int j = 0; j < NJ; j++) {
+        const int pos = wn * (NJ * 16) + j * 16 + l15;
         const int px = pos & tw_mask, py = (pos >> t.tw_log2) & th_mask;
         int nbi = pos >> (t.tw_log2 + t.th_log2);
         nbi = nbi < t.nbe ? nbi : t.nbe - 1;     // image slots beyond nbe are masked in the epilogue; keep LDS reads in range
@@ -359,11 +363,11 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nks = (c_end - c_begin) * g.ntaps;
     const unsigned char *wbase = wpk + (int64_t)cot * t.nchunks * g.nslices * CV_WSTEP_BYTES;
@@ -421,14 +425,14 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         {
             const unsigned char *wb = wbuf + (ks & 1) * CV_WSTEP_BYTES;
             const int toff = (g.dy[tap] - t.dymin) * t.PW + (g.dx[tap] - t.dxmin);
-            bf16x8 ahi[4], alo[4], bhi[4], blo[4];
+            bf16x8 ahi[4], alo[4], bhi[NJ], blo[NJ];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 ahi[i] = *reinterpret_cast<const bf16x8 *>(wb + a_off[i]);
                 if (SPLIT == 2) alo[i] = *reinterpret_cast<const bf16x8 *>(wb + CV_WTILE_BYTES + a_off[i]);
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < NJ; j++) {
                 const int pp = pb[j] + toff;
                 const int off = pp * 64 + cv_swz(kg, pp) * 16;
                 bhi[j] = *reinterpret_cast<const bf16x8 *>(ph + off);
@@ -437,7 +441,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < NJ; j++) {
                     if (SPLIT == 2) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
@@ -462,8 +466,8 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     // ---- epilogue
     const bool covec = (g.Co & 3) == 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int pos = wn * 64 + j * 16 + l15;
+    for (int j = 0; j < NJ; j++) {
+        const int pos = wn * (NJ * 16) + j * 16 + l15;
         const int px = pos & tw_mask, py = (pos >> t.tw_log2) & th_mask, nbi = pos >> (t.tw_log2 + t.th_log2);
         const int n = n0 + nbi, gy = gy0 + py, gx = gx0 + px;
         if (nbi >= t.nbe || n >= g.N || gy >= g.GH || gx >= g.GW) continue;
@@ -510,13 +514,13 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     }
 }
 
-template <int SPLIT, bool VEC, bool DEEP>
+template <int SPLIT, bool VEC, bool DEEP, int NJ>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restrict__ x,
                                                             const unsigned char *__restrict__ wpk,
                                                             float *__restrict__ out, const float *__restrict__ iscale,
                                                             const float *__restrict__ oscale, float *__restrict__ ws,
                                                             const rick_conv_geom g, const ConvTiling t) {
-    igemm_body<SPLIT, VEC, DEEP>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x);
+    igemm_body<SPLIT, VEC, DEEP, NJ>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x);
 }
 
 // Several geometries (the output-parity classes of a transposed convolution) in ONE launch: block ranges
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_multi_kernel(const float *_
         }
     // every parity class of a transposed conv has a patch of <= 160 pixels (tile + at most one halo row/col)
     // (the host only uses this kernel when every class qualifies for the two-ahead prefetch)
-    igemm_body<SPLIT, VEC, true>(x, wpk, out, iscale, oscale, ws + m.ws_off[c], m.g[c], m.t[c], (int)blockIdx.x - start,
+    igemm_body<SPLIT, VEC, true, 4>(x, wpk, out, iscale, oscale, ws + m.ws_off[c], m.g[c], m.t[c], (int)blockIdx.x - start,
                                  m.blk_end[c] - start);
 }
 
@@ -588,27 +592,28 @@ static int check_geom(const rick_conv_geom *g) {
 extern "C" int64_t rick_conv_igemm_workspace_bytes(const rick_conv_geom *g) {
     if (check_geom(g)) return -1;
     ConvTiling t;
-    if (make_tiling(g, CV_BN, &t)) return -1;
+    if (make_tiling(g, igemm_tile_positions(g), &t)) return -1;
     igemm_plan_split(&t);
     return t.nsplit > 1 ? (int64_t)t.nsplit * g->N * g->GH * g->GW * g->Co * 4 : 0;
 }
 
-template <int SPLIT, bool VEC, bool DEEP>
+template <int SPLIT, bool VEC, bool DEEP, int NJ>
 static void launch_igemm_k(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
                            const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
                            const ConvTiling &t) {
-    (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<SPLIT, VEC, DEEP>,
+    (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<SPLIT, VEC, DEEP, NJ>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv_igemm_kernel<SPLIT, VEC, DEEP>), dim3(nwg), dim3(256), lds, st, x, wp, out, iscale, oscale, ws,
-                       *g, t);
+    hipLaunchKernelGGL((conv_igemm_kernel<SPLIT, VEC, DEEP, NJ>), dim3(nwg), dim3(256), lds, st, x, wp, out, iscale, oscale,
+                       ws, *g, t);
 }
 
 template <int SPLIT, bool VEC>
 static void launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
                          const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
                          const ConvTiling &t) {
-    if (t.NPP <= IG_DEEP_NPP) launch_igemm_k<SPLIT, VEC, true>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
-    else launch_igemm_k<SPLIT, VEC, false>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
+    if (igemm_tile_positions(g) == 64) launch_igemm_k<SPLIT, VEC, false, 2>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
+    else if (t.NPP <= IG_DEEP_NPP) launch_igemm_k<SPLIT, VEC, true, 4>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
+    else launch_igemm_k<SPLIT, VEC, false, 4>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
 }
 
 extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *out, const float *iscale,
@@ -616,7 +621,7 @@ extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *
     if (!x || !packed_w || !out || check_geom(g)) return RICK_EINVAL;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed_w | (uintptr_t)(iscale ? iscale : x)) % 16) return RICK_EINVAL;
     ConvTiling t;
-    if (make_tiling(g, CV_BN, &t)) return RICK_EINVAL;
+    if (make_tiling(g, igemm_tile_positions(g), &t)) return RICK_EINVAL;
     igemm_plan_split(&t);
     if (t.nsplit > 1 && (!workspace || ((uintptr_t)workspace % 16))) return RICK_EINVAL;
     const size_t lds = 2 * CV_WSTEP_BYTES + 2 * (size_t)((t.NPP * 64 + 15) & ~15) + (size_t)t.NPP * 4;
@@ -947,19 +952,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         }
     }
 
-    // ---- partial tile -> workspace [split][cot][chunk][tap][128 co][32 ci]
+    // ---- partial tile -> workspace [split][cot][chunk][tap][32 ci][128 co]: a lane's 4 accumulator
+    // registers are 4 consecutive co of one ci, so the [ci][co] order makes every store a float4
     float *wsb = ws + (((int64_t)split * t.ncot + cot) * t.nchunks + chunk) * g.ntaps * (CV_BM * CV_CK);
 #pragma unroll
     for (int tt = 0; tt < NT; tt++) {
         if (tt < g.ntaps) {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int co = wm * 64 + i * 16 + G * 4 + r;
-                    const int ci = wn * 16 + (lane & 15);
-                    wsb[(tt * CV_BM + co) * CV_CK + ci] = acc[i][tt][r];
-                }
+            for (int i = 0; i < 4; i++) {
+                const int co = wm * 64 + i * 16 + G * 4;
+                const int ci = wn * 16 + (lane & 15);
+                *reinterpret_cast<float4 *>(wsb + (tt * CV_CK + ci) * CV_BM + co) =
+                    make_float4(acc[i][tt][0], acc[i][tt][1], acc[i][tt][2], acc[i][tt][3]);
+            }
         }
     }
 }
@@ -970,8 +975,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
                                                            int accumulate, rick_conv_geom g) {
     const int64_t per_split = (int64_t)ncot * nchunks * ntaps * CV_BM * CV_CK;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_split; i += (int64_t)gridDim.x * 256) {
-        const int k = (int)(i & 31);
-        const int r = (int)((i >> 5) & 127);
+        const int r = (int)(i & 127);              // co within tile (fastest in the partial layout)
+        const int k = (int)((i >> 7) & 31);        // ci within chunk
         int64_t blk = i >> 12;
         const int tt = (int)(blk % ntaps);
         blk /= ntaps;
@@ -990,7 +995,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 static void wgrad_plan(const rick_conv_geom *g, ConvTiling *t, int *nsplit, int *tps) {
     make_tiling(g, WG_TILE, t);
     const int ntiles = t->ntx * t->nty * t->ntn;
-    int want = 512 / (t->ncot * t->nchunks);   // blocks ~ 2 per CU
+    int want = 256 / (t->ncot * t->nchunks);   // one block per CU (only one 400-register block is resident)
     if (want < 1) want = 1;
     if (want >= 4 && ntiles >= 8) want = (want + 4) / 8 * 8;   // multiple of 8: one set of splits per XCD
     if (want > ntiles) want = ntiles;
