@@ -248,3 +248,75 @@ def test_trainer_steps_match_oracle():
     assert rel(pen, pen_ref.detach()) < 2e-3
     assert rel(tr.mean_path_length, mean_ref) < 1e-3
     tr.ema_step()
+
+
+def test_warmup_stage_and_fisher_sweep_masks():
+    """Rows H / F / Q / K at 32 px: (a) during warm-up only `final_*` of D is updated and the G step is skipped
+    (train_dynamic_update_prune.py:202-211, 518-519); (b) fisher_sweep accumulates grad^2 on device exactly like
+    the per-sample oracle, and its decisions / masks equal the oracle's decisions on the same FIM."""
+    from oracle.train_ref import d_decisions_ref, fisher_sample_ref, g_decisions_ref
+    from rick_amd.train import RickTrainer, TrainConfig
+    size, B = 32, 2
+    cfg = TrainConfig(size=size, batch=B, warmup_iter=3, num_fisher_img=2, fisher_quantile=40, prune_quantile=1.0)
+    g, d = build(size)
+    g_ema, d_ema = build(size)
+    tr = RickTrainer(cfg, g, d, g_ema, d_ema)
+    real = synth_reals(B, size=size, seed=9).to(DEV)
+    before_d = {k: v.detach().clone() for k, v in d.named_parameters()}
+    before_g = {k: v.detach().clone() for k, v in g.named_parameters()}
+    torch.manual_seed(0)
+    tr.iteration(0, real)                       # warm-up iteration (i < warmup_iter, i % 16 == 0 -> also R1)
+    for k, v in d.named_parameters():
+        changed = not torch.equal(v.detach(), before_d[k])
+        assert changed == ('final' in k), k
+    for k, v in g.named_parameters():
+        assert torch.equal(v.detach(), before_g[k]), k          # G step skipped during warm-up
+    assert tr.d_optim.steps[tr.d_flat.index['final_conv.0.weight']] == 2      # D step + R1 step
+    assert tr.d_optim.steps[tr.d_flat.index['convs.1.conv1.0.weight']] == 0
+
+    # ---- Fisher sweep on the EMA networks (fixed noise buffers), 2 samples
+    zs = [synth_latents(1, seed=20 + j) for j in range(2)]
+    rs = [synth_reals(1, size=size, seed=30 + j) for j in range(2)]
+    acc_g, acc_d = tr.fisher_sweep([z.to(DEV) for z in zs], [r.to(DEV) for r in rs], first=True, fixed_noise=True)
+    sg = {k: v.detach().double().cpu() for k, v in g_ema.state_dict().items()}
+    sd = {k: v.detach().double().cpu() for k, v in d_ema.state_dict().items()}
+    ref_g, ref_d = None, None
+    for z, r in zip(zs, rs):
+        fg, fd, _, _ = fisher_sample_ref(sg, sd, z.double(), r.double(), size=size)
+        ref_g = fg if ref_g is None else {k: ref_g[k] + fg[k] for k in fg}
+        ref_d = fd if ref_d is None else {k: ref_d[k] + fd[k] for k in fd}
+    scale = 1.0 / (cfg.num_fisher_img * cfg.batch)
+    got = {k: float(v.double().sum()) for k, v in acc_g.acc.items()}
+    check_grad2(got, {f'x/{k}': float(v.sum()) * scale for k, v in ref_g.items()}, 'x', 2e-3)
+    got = {k: float(v.double().sum()) for k, v in acc_d.acc.items()}
+    check_grad2(got, {f'x/{k}': float(v.sum()) * scale for k, v in ref_d.items()}, 'x', 2e-3)
+    # decisions: oracle restatement applied to the DEVICE Fisher tensors == trainer's index sets
+    n_blocks = len(g.convs)
+    fz_g, _, pr_g = g_decisions_ref({k: v.cpu().numpy() for k, v in acc_g.acc.items()}, cfg.fisher_quantile,
+                                    cfg.prune_quantile, n_blocks=n_blocks)
+    fz_d, _, pr_d = d_decisions_ref({k: v.cpu().numpy() for k, v in acc_d.acc.items()}, cfg.fisher_quantile,
+                                    cfg.prune_quantile, blocks=range(1, len(d.convs)))
+
+    def same(a, b):       # identical up to filters sitting exactly on a percentile line (fp32 vs fp64 means)
+        assert a.keys() == b.keys()
+        diff = sum(len(set(a[k].tolist()) ^ set(b[k].tolist())) for k in a)
+        total = sum(len(b[k]) for k in b) + 1
+        assert diff <= max(2, total // 200), (diff, total)
+    same(tr.idx_freeze_g, fz_g)
+    same(tr.zero_idx_g, pr_g)
+    same(tr.idx_freeze_d, fz_d)
+    same(tr.zero_idx_d, pr_d)
+    # masks: bit0 on frozen filters, bit1 on pruned ones; a masked D step keeps pruned filters at exactly 0
+    key = 'convs.1.conv1.0.weight'
+    lo, hi = tr.d_flat.segment(key)
+    mview = tr.d_optim.mask[lo:hi].view(before_d[key].shape).cpu()
+    for f in tr.idx_freeze_d[key][:5]:
+        assert int(mview[f].min()) & 1
+    tr.iteration(cfg.warmup_iter + 1, real)
+    for k, idx in tr.zero_idx_d.items():
+        if len(idx):
+            assert float(dict(d.named_parameters())[k][idx].abs().max()) == 0.0, k
+    for k, idx in tr.zero_idx_g.items():
+        if len(idx):
+            p = dict(g.named_parameters())[k]
+            assert float((p[:, idx] if p.ndim == 5 else p[idx]).abs().max()) == 0.0, k
