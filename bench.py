@@ -70,6 +70,7 @@ def main():
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--eval', action='store_true', help='also time G inference (BASELINE config 4: batches of 25)')
     ap.add_argument('--fisher-img', type=int, default=2, help='samples of the (untimed) Fisher sweep that sets the masks')
     args = ap.parse_args()
 
@@ -183,6 +184,16 @@ def main():
                                                'avg_launch_us': 1e6 * wg[1] / max(wg[2], 1)}
         conv_s = sum(a[1] for a in agg.values()) / 16
         out['roofline']['conv_family_ms_per_step'] = 1e3 * conv_s
+    if rank == 0 and args.eval:
+        from rick_amd.evaluate import sample_images
+        n = 500
+        sample_images(g_ema, 50, 25)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sample_images(g_ema, n, 25)
+        torch.cuda.synchronize()
+        out['eval_sampling'] = {'images_per_s': n / (time.perf_counter() - t0), 'batch': 25, 'images': n,
+                                'note': 'g_ema inference loop of gan_training/eval.py:34-41, images kept on device'}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg.size)
     if rank == 0:

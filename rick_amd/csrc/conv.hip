@@ -409,12 +409,12 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         int nchunk = chunk, ntap = tap + 1;
         if (ntap == g.ntaps) { ntap = 0; nchunk++; }
         const bool more = ks + 1 < nks;
-        if (more) {   // weights of k-step ks+1 -> registers
+        if (more && !(t.debug & 4)) {   // weights of k-step ks+1 -> registers
             const uint4 *src = reinterpret_cast<const uint4 *>(
                 wbase + ((int64_t)nchunk * g.nslices + g.wt[ntap]) * CV_WSTEP_BYTES);
             CV_WLOAD(src);
         }
-        if (tap == 0) {   // patch prefetch: next chunk (two ahead when DEEP) -> registers
+        if (tap == 0 && !(t.debug & 2)) {   // patch prefetch: next chunk (two ahead when DEEP) -> registers
             const int cpre = chunk + (DEEP ? 2 : 1);
             if (cpre < c_end) {
                 if (DEEP && ((cpre - c_begin) & 1)) issue_patch(cpre, S1{});
@@ -422,7 +422,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             }
         }
         __builtin_amdgcn_sched_barrier(0);   // prefetches are issued before the MFMAs, consumed after
-        {
+        if (!(t.debug & 1)) {
             const unsigned char *wb = wbuf + (ks & 1) * CV_WSTEP_BYTES;
             const int toff = (g.dy[tap] - t.dymin) * t.PW + (g.dx[tap] - t.dxmin);
             bf16x8 ahi[4], alo[4], bhi[NJ], blo[NJ];
@@ -450,13 +450,13 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 }
         }
         if (more) {
-            if (ntap == 0) {   // next k-step starts a new channel chunk: all waves are done with the patch
+            if (ntap == 0 && !(t.debug & 2)) {   // next k-step starts a new channel chunk: all waves are done with the patch
                 __syncthreads();
                 if (DEEP && ((nchunk - c_begin) & 1)) commit_patch(nchunk, S1{});
                 else commit_patch(nchunk, S0{});
             }
             unsigned char *wd = wbuf + ((ks + 1) & 1) * CV_WSTEP_BYTES;
-            CV_WSTORE(wd);
+            if (!(t.debug & 4)) CV_WSTORE(wd);
         }
         __syncthreads();
         chunk = nchunk;

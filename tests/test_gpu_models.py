@@ -320,3 +320,22 @@ def test_warmup_stage_and_fisher_sweep_masks():
         if len(idx):
             p = dict(g.named_parameters())[k]
             assert float((p[:, idx] if p.ndim == 5 else p[idx]).abs().max()) == 0.0, k
+
+
+def test_eval_sampling_loop_matches_oracle():
+    """§8f.1: g_ema inference in batches (gan_training/eval.py:34-41) — device-resident loop == oracle images."""
+    from oracle.model_ref import generator_ref
+    from rick_amd.evaluate import sample_images
+    size = 32
+    g, _ = build(size)
+    z = synth_latents(7, seed=77)
+    noises = None
+    # fixed noise: make the module use its registered noise buffers by monkey-patching randomize_noise off
+    fwd = g.forward
+    g.forward = lambda styles, **kw: fwd(styles, randomize_noise=False, **kw)
+    imgs, feats = sample_images(g, 7, n_sample_store=3, latents=z, feature_fn=lambda im: im.mean(dim=(1, 2, 3)))
+    sg = {k: v.double() for k, v in synth_state_dict(generator_shapes(size)).items()}
+    ref, _ = generator_ref(sg, [z.double()], size=size, randomize_noise=False)
+    assert imgs.shape == (7, 3, size, size) and feats.shape == (7,)
+    assert rel(imgs, ref) < 1e-4
+    assert rel(feats, ref.mean(dim=(1, 2, 3))) < 1e-4
