@@ -101,37 +101,47 @@ extern "C" int rick_thin_wgrad_blocks(int64_t P) {
     return (int)(nb < 1 ? 1 : nb);
 }
 
+// float4 over channels: thread owns 4 consecutive channels of a row-lane, J x 4 accumulators.
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float *__restrict__ t, const float *__restrict__ x,
                                                          float *__restrict__ partials, int64_t P, int C, int J) {
-    extern __shared__ float lds[];   // [256]
+    extern __shared__ float lds[];   // [256 * 4]
     const int n = blockIdx.y, N = gridDim.y, nb = gridDim.x;
     const int64_t ppb = cdiv64(P, nb);
     const int64_t p0 = (int64_t)blockIdx.x * ppb, p1 = p0 + ppb < P ? p0 + ppb : P;
     const float *xn = x + (int64_t)n * P * C;
     const float *tn = t + (int64_t)n * J * P;
     float *pb = partials + ((int64_t)blockIdx.x * N + n) * J * C;
-    for (int cbase = 0; cbase < C; cbase += 256) {
-        const int cg = C - cbase < 256 ? C - cbase : 256;
+    const int ncol = C >> 2;
+    for (int cbase = 0; cbase < ncol; cbase += 256) {
+        const int cg = ncol - cbase < 256 ? ncol - cbase : 256;
         const int rpb = 256 / cg;
         const int lane_c = threadIdx.x % cg, lane_r = threadIdx.x / cg;
-        float acc[THIN_MAXJ] = {0.f, 0.f, 0.f, 0.f};
+        float4 acc[THIN_MAXJ];
+#pragma unroll
+        for (int j = 0; j < THIN_MAXJ; j++) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (lane_r < rpb)
             for (int64_t p = p0 + lane_r; p < p1; p += rpb) {
-                const float xv = xn[p * C + cbase + lane_c];
+                const float4 xv = *reinterpret_cast<const float4 *>(xn + p * C + (int64_t)(cbase + lane_c) * 4);
 #pragma unroll
                 for (int j = 0; j < THIN_MAXJ; j++)
-                    if (j < J) acc[j] += tn[(int64_t)j * P + p] * xv;
+                    if (j < J) {
+                        const float tv = tn[(int64_t)j * P + p];
+                        acc[j].x += tv * xv.x; acc[j].y += tv * xv.y; acc[j].z += tv * xv.z; acc[j].w += tv * xv.w;
+                    }
             }
 #pragma unroll
         for (int j = 0; j < THIN_MAXJ; j++) {
             if (j >= J) break;
             __syncthreads();
-            lds[threadIdx.x] = lane_r < rpb ? acc[j] : 0.f;
+            reinterpret_cast<float4 *>(lds)[threadIdx.x] = lane_r < rpb ? acc[j] : make_float4(0.f, 0.f, 0.f, 0.f);
             __syncthreads();
             if (threadIdx.x < cg) {
-                float s = 0.f;
-                for (int rr = 0; rr < rpb; rr++) s += lds[rr * cg + threadIdx.x];
-                pb[(int64_t)j * C + cbase + threadIdx.x] = s;
+                float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int rr = 0; rr < rpb; rr++) {
+                    const float4 v = reinterpret_cast<float4 *>(lds)[rr * cg + threadIdx.x];
+                    sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
+                }
+                *reinterpret_cast<float4 *>(pb + (int64_t)j * C + (cbase + threadIdx.x) * 4) = sacc;
             }
         }
     }
@@ -148,10 +158,11 @@ __global__ __launch_bounds__(256) void thin_partial_sum_kernel(const float *__re
 
 extern "C" int rick_thin_wgrad_f32(const float *t, const float *x, float *G, int N, int64_t P, int C, int J,
                                    float *partials, void *stream) {
-    if (!x || !G || !t || !partials || N <= 0 || P <= 0 || C <= 0 || J < 1 || J > THIN_MAXJ || N > 65535) return RICK_EINVAL;
+    if (!x || !G || !t || !partials || N <= 0 || P <= 0 || C <= 0 || (C & 3) || J < 1 || J > THIN_MAXJ || N > 65535) return RICK_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)partials) % 16) return RICK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nb = rick_thin_wgrad_blocks(P);
-    hipLaunchKernelGGL(thin_wgrad_kernel, dim3(nb, N), dim3(256), 256 * sizeof(float), st, t, x, partials, P, C, J);
+    hipLaunchKernelGGL(thin_wgrad_kernel, dim3(nb, N), dim3(256), 1024 * sizeof(float), st, t, x, partials, P, C, J);
     const int64_t n = (int64_t)N * J * C;
     hipLaunchKernelGGL(thin_partial_sum_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, partials, G, nb, n);
     RICK_LAUNCH_STATUS();
