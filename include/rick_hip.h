@@ -107,6 +107,22 @@ int64_t rick_conv_packed_bytes(int Co, int Ci, int nslices);
  * A-operand LDS image (bf16 hi/lo, swizzled, zero padded to 128 x 32 tiles). */
 int rick_conv_pack_weight(const float *w, int64_t s_co, int64_t s_ci, int64_t s_t,
                           int Co, int Ci, int nslices, float scale, int split, void *packed, void *stream);
+/* The same packing for MANY weights in one launch (every convolution of a network after an optimiser step;
+ * replaces one launch per layer and orientation).  `descs_device` is an array of n descriptors in DEVICE
+ * memory; descriptor d owns blocks [blk_begin[d], blk_begin[d] + rick_conv_pack_blocks(Co, Ci)), in order;
+ * total_blocks = the sum.  `w` need not be a whole tensor: any (s_co, s_ci, s_t) view, e.g. the transposed
+ * view the data gradient uses. */
+typedef struct {
+    const float *w;
+    int64_t s_co, s_ci, s_t;
+    void *packed;           /* rick_conv_packed_bytes(Co, Ci, nslices) bytes */
+    int Co, Ci, nslices;
+    float scale;
+    int blk_begin;
+    int reserved;
+} rick_pack_desc;
+int rick_conv_pack_blocks(int Co, int Ci);
+int rick_conv_pack_weights_multi(const rick_pack_desc *descs_device, int n, int total_blocks, int split, void *stream);
 /* Launches with too few output tiles to fill the chip (the 4x4..32x32 512-channel layers) are
  * split over the channel-chunk dimension; partial sums go through `workspace`
  * (rick_conv_igemm_workspace_bytes bytes, 0 = not needed, may then be NULL) and a deterministic

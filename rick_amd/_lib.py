@@ -41,6 +41,8 @@ SIGNATURES = {
                                       c_f, c_f, c_fp, c_fp]),
     'rick_conv_packed_bytes': (c_i64, [c_int, c_int, c_int]),
     'rick_conv_pack_weight': (c_int, [c_fp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_f, c_int, c_fp, c_fp]),
+    'rick_conv_pack_blocks': (c_int, [c_int, c_int]),
+    'rick_conv_pack_weights_multi': (c_int, [c_fp, c_int, c_int, c_int, c_fp]),
     'rick_conv_igemm_workspace_bytes': (c_i64, [ctypes.POINTER(ConvGeom)]),
     'rick_conv_igemm_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(ConvGeom), c_fp, c_fp]),
     'rick_conv_igemm_multi_workspace_bytes': (c_i64, [ctypes.POINTER(ConvGeom), c_int]),

@@ -121,6 +121,49 @@ extern "C" int rick_conv_pack_weight(const float *w, int64_t s_co, int64_t s_ci,
     RICK_LAUNCH_STATUS();
 }
 
+// Many weights in ONE launch (all convolutions of a network after an optimiser step): block b serves the
+// descriptor d with blk_begin[d] <= b < blk_begin[d+1]; a thread owns one (co, ci) of a 128 x 32 tile and
+// walks the tap slices (contiguous in memory for [O, I, kh, kw] parameters).
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const rick_pack_desc *__restrict__ descs, int n, int split) {
+    int d = 0;
+    for (int i = 1; i < n; i++)
+        if ((int)blockIdx.x >= descs[i].blk_begin) d = i;
+    const rick_pack_desc ds = descs[d];
+    const int nchunks = (ds.Ci + CV_CK - 1) / CV_CK;
+    const int i = ((int)blockIdx.x - ds.blk_begin) * 256 + threadIdx.x;   // over (cotile, chunk, r, k)
+    const int k = i & 31, r = (i >> 5) & 127, tile = i >> 12;
+    const int chunk = tile % nchunks, cot = tile / nchunks;
+    const int co = cot * CV_BM + r, ci = chunk * CV_CK + k;
+    const bool ok = co < ds.Co && ci < ds.Ci;
+    const float *src = ds.w + (ok ? co * ds.s_co + ci * ds.s_ci : 0);
+    unsigned short *dst = (unsigned short *)ds.packed + (int64_t)tile * ds.nslices * (CV_WSTEP_BYTES / 2) +
+                          r * 32 + cv_swz(k >> 3, r) * 8 + (k & 7);
+    for (int sl = 0; sl < ds.nslices; sl++) {
+        float v = src[sl * ds.s_t] * ds.scale;
+        if (!ok) v = 0.f;
+        unsigned short h, l;
+        if (split == 1) {
+            h = f32_to_bf16_rne(v);
+            l = 0;
+        } else {
+            h = (unsigned short)(__float_as_uint(v) >> 16);
+            l = f32_to_bf16_rne(v - bf16_to_f32(h));
+        }
+        dst[(int64_t)sl * (CV_WSTEP_BYTES / 2)] = h;
+        dst[(int64_t)sl * (CV_WSTEP_BYTES / 2) + CV_WTILE_BYTES / 2] = l;
+    }
+}
+
+extern "C" int rick_conv_pack_blocks(int Co, int Ci) { return cdiv(Co, CV_BM) * cdiv(Ci, CV_CK) * (CV_BM * CV_CK / 256); }
+
+extern "C" int rick_conv_pack_weights_multi(const rick_pack_desc *descs_device, int n, int total_blocks, int split,
+                                            void *stream) {
+    if (!descs_device || n < 1 || total_blocks < 1 || (split != 1 && split != 2)) return RICK_EINVAL;
+    hipLaunchKernelGGL(pack_weight_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       descs_device, n, split);
+    RICK_LAUNCH_STATUS();
+}
+
 // ------------------------------------------------------------------------------------------
 struct ConvTiling {
     int tw_log2, th_log2;       // position tile = (1<<tw) x (1<<th) x nb images = 128 (igemm) / 64 (wgrad)
@@ -179,6 +222,12 @@ static int make_tiling(const rick_conv_geom *g, int tile_positions, ConvTiling *
 
 // Stride-2 inputs need a patch of ~4x the position tile; a 64-position block (each wave 64 co x 32 positions)
 // keeps it at ~37 KB so two blocks still fit per CU.
+static size_t igemm_lds_bytes(const ConvTiling &t, bool has_iscale) {
+    (void)has_iscale;   // the scale table is always present (filled with 1 when the conv has no input scale)
+    return 2 * CV_WSTEP_BYTES + 2 * (size_t)(t.NPP + 1) * 64 + (size_t)((t.NPP + 3) & ~3) * 4 +
+           (size_t)t.nbe * t.cps * CV_CK * 4;
+}
+
 static int igemm_tile_positions(const rick_conv_geom *g) { return (g->is >= 2 && g->ntaps > 1) ? 64 : CV_BN; }
 
 // Split-K plan for launches with too few blocks to fill 256 CUs (the 4x4..32x32, 512-channel layers:
@@ -242,11 +291,11 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                                            const rick_conv_geom &g, const ConvTiling &t, const int bid, const int nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *wbuf = smem;                               // [2][16 KB]
-    unsigned char *ph = smem + 2 * CV_WSTEP_BYTES;            // [NPP][64 B]
-    unsigned char *pl = ph + ((t.NPP * 64 + 15) & ~15);
-    unsigned *ptab = reinterpret_cast<unsigned *>(pl + ((t.NPP * 64 + 15) & ~15));   // [NPP]
+    unsigned char *ph = smem + 2 * CV_WSTEP_BYTES;            // [NPP + 1][64 B]
+    unsigned char *pl = ph + (t.NPP + 1) * 64;                // (+1: spare row for out-of-patch items)
+    unsigned *ptab = reinterpret_cast<unsigned *>(pl + (t.NPP + 1) * 64);             // [NPP]
+    float *sct = reinterpret_cast<float *>(ptab + ((t.NPP + 3) & ~3));                // [nbe][cps * 32] input scales
     build_patch_table(ptab, t);
-    __syncthreads();
 
     const int lid = xcd_remap(bid, nwg);
     const int npos_tiles = t.ntx * t.nty * t.ntn;
@@ -261,6 +310,15 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     const int tn_i = pt / t.nty;
     const int gx0 = tx_i << t.tw_log2, gy0 = ty_i << t.th_log2, n0 = tn_i * t.nbe;
     const int iy0 = gy0 * g.is + t.dymin, ix0 = gx0 * g.is + t.dxmin;
+    // per-(image, input channel) scales of this block's images and channel range (1 when the conv has none):
+    // read from HBM once, then applied from LDS while the patch is converted — no global-load round trip
+    // and no branch per patch item
+    const int cspan = t.cps * CV_CK;
+    for (int i = threadIdx.x; i < t.nbe * cspan; i += 256) {
+        const int nbi = i / cspan, c = c_begin * CV_CK + (i - nbi * cspan);
+        sct[i] = !iscale ? 1.f : (n0 + nbi < g.N && c < g.Ci) ? iscale[(int64_t)(n0 + nbi) * g.Ci + c] : 0.f;
+    }
+    __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -301,7 +359,8 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         const int pix = (threadIdx.x >> 3) + 32 * k;
         p_rel[k] = 0;
         p_sc[k] = 0;
-        p_lds[k] = pix * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
+        // items past the patch land in a spare row behind it, so the LDS writes need no guard
+        p_lds[k] = (pix < t.NPP ? pix : t.NPP) * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
         if (pix < t.NPP) {
             const unsigned e = ptab[pix];
             const int nbi = (int)(e >> 20), py = (int)((e >> 10) & 1023), px = (int)(e & 1023);
@@ -309,7 +368,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             if (n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
                 p_ok |= 1u << k;
                 p_rel[k] = ((nbi * g.IH + py) * g.IW + px) * g.Ci;
-                p_sc[k] = n * g.Ci + c4 * 4;
+                p_sc[k] = nbi * cspan + c4 * 4;
             }
         }
     }
@@ -327,19 +386,16 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     };
     auto commit_patch = [&](int chunk, auto SET) {
         constexpr int S = decltype(SET)::value;
-        const int ci0 = chunk * CV_CK + c4 * 4;
 #pragma unroll
         for (int k = 0; k < PSET; k++) {
             const bool ok = (cur_ok[S] >> k) & 1u;
             float4 v = pq[S * PSET + k];
-            if (iscale) v = mul4(v, load4<VEC>(ok ? iscale + p_sc[k] + chunk * CV_CK : iscale, ok, ci0, g.Ci));
+            v = mul4(v, *reinterpret_cast<const float4 *>(sct + p_sc[k] + (chunk - c_begin) * CV_CK));
             if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 hi, lo;
             split4<SPLIT>(v, hi, lo);
-            if ((threadIdx.x >> 3) + 32 * k < t.NPP) {
-                *reinterpret_cast<uint2 *>(ph + p_lds[k]) = hi;
-                if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds[k]) = lo;
-            }
+            *reinterpret_cast<uint2 *>(ph + p_lds[k]) = hi;
+            if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds[k]) = lo;
         }
         if (!DEEP) {
             // patches larger than IG_PMAX*32 pixels (stride-2 geometry): remaining items, synchronously
@@ -350,7 +406,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 const int ci = chunk * CV_CK + c4 * 4;
                 const bool ok = n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW && ci < g.Ci;
                 float4 v = load4<VEC>(ok ? x + (((int64_t)n * g.IH + iy) * g.IW + ix) * g.Ci + ci : x, ok, ci, g.Ci);
-                if (iscale) v = mul4(v, load4<VEC>(ok ? iscale + (int64_t)n * g.Ci + ci : iscale, ok, ci, g.Ci));
+                v = mul4(v, *reinterpret_cast<const float4 *>(sct + (int)(e >> 20) * cspan + (chunk - c_begin) * CV_CK + c4 * 4));
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 hi, lo;
                 split4<SPLIT>(v, hi, lo);
@@ -463,55 +519,78 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         tap = ntap;
     }
 
-    // ---- epilogue
+    // ---- epilogue.  Instantiated twice (with / without output scales) so the scale loads of a j-column
+    // are unconditional in their variant: hipcc otherwise sinks each into its own branch + vmcnt(0).
     const bool covec = (g.Co & 3) == 0;
+    auto epilogue = [&](auto HAS_OS) {
+        constexpr bool OS = decltype(HAS_OS)::value;
 #pragma unroll
-    for (int j = 0; j < NJ; j++) {
-        const int pos = wn * (NJ * 16) + j * 16 + l15;
-        const int px = pos & tw_mask, py = (pos >> t.tw_log2) & th_mask, nbi = pos >> (t.tw_log2 + t.th_log2);
-        const int n = n0 + nbi, gy = gy0 + py, gx = gx0 + px;
-        if (nbi >= t.nbe || n >= g.N || gy >= g.GH || gx >= g.GW) continue;
-        if (t.nsplit > 1) {   // raw partial sums -> workspace [split][n, gy, gx][Co]; scaled in the reduce kernel
-            float *wrow = ws + (((int64_t)split * g.N + n) * g.GH * g.GW + (int64_t)gy * g.GW + gx) * g.Co;
+        for (int j = 0; j < NJ; j++) {
+            const int pos = wn * (NJ * 16) + j * 16 + l15;
+            const int px = pos & tw_mask, py = (pos >> t.tw_log2) & th_mask, nbi = pos >> (t.tw_log2 + t.th_log2);
+            const int n = n0 + nbi, gy = gy0 + py, gx = gx0 + px;
+            if (nbi >= t.nbe || n >= g.N || gy >= g.GH || gx >= g.GW) continue;
+            if (t.nsplit > 1) {   // raw partial sums -> workspace [split][n, gy, gx][Co]; scaled in the reduce kernel
+                float *wrow = ws + (((int64_t)split * g.N + n) * g.GH * g.GW + (int64_t)gy * g.GW + gx) * g.Co;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int co = cot * CV_BM + wm * 64 + i * 16 + kg * 4;
+                    if (co >= g.Co) continue;
+                    if (covec) {
+                        *reinterpret_cast<float4 *>(wrow + co) =
+                            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    } else {
+                        wrow[co] = acc[i][j][0];
+                        if (co + 1 < g.Co) wrow[co + 1] = acc[i][j][1];
+                        if (co + 2 < g.Co) wrow[co + 2] = acc[i][j][2];
+                        if (co + 3 < g.Co) wrow[co + 3] = acc[i][j][3];
+                    }
+                }
+                continue;
+            }
+            const int64_t opix = ((int64_t)n * g.OH + gy * g.os + g.oy0) * g.OW + gx * g.os + g.ox0;
+            float *orow = out + opix * g.Co;
+            if (covec) {   // 4 batched float4 scale loads (clamped address), then 4 float4 stores
+                float4 sc[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int co = cot * CV_BM + wm * 64 + i * 16 + kg * 4;
+                    sc[i] = make_float4(g.alpha, g.alpha, g.alpha, g.alpha);
+                    if (OS) {
+                        const float4 o = *reinterpret_cast<const float4 *>(oscale + (int64_t)n * g.Co + (co < g.Co ? co : 0));
+                        sc[i] = make_float4(o.x * g.alpha, o.y * g.alpha, o.z * g.alpha, o.w * g.alpha);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int co = cot * CV_BM + wm * 64 + i * 16 + kg * 4;
+                    if (co < g.Co)
+                        *reinterpret_cast<float4 *>(orow + co) = make_float4(
+                            acc[i][j][0] * sc[i].x, acc[i][j][1] * sc[i].y, acc[i][j][2] * sc[i].z, acc[i][j][3] * sc[i].w);
+                }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int co = cot * CV_BM + wm * 64 + i * 16 + kg * 4;
                 if (co >= g.Co) continue;
-                if (covec) {
-                    *reinterpret_cast<float4 *>(wrow + co) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                } else {
-                    wrow[co] = acc[i][j][0];
-                    if (co + 1 < g.Co) wrow[co + 1] = acc[i][j][1];
-                    if (co + 2 < g.Co) wrow[co + 2] = acc[i][j][2];
-                    if (co + 3 < g.Co) wrow[co + 3] = acc[i][j][3];
+                f32x4 v = acc[i][j] * g.alpha;
+                if (OS) {
+                    const float *sp = oscale + (int64_t)n * g.Co + co;
+                    v[0] *= sp[0];
+                    if (co + 1 < g.Co) v[1] *= sp[1];
+                    if (co + 2 < g.Co) v[2] *= sp[2];
+                    if (co + 3 < g.Co) v[3] *= sp[3];
                 }
-            }
-            continue;
-        }
-        const int64_t opix = ((int64_t)n * g.OH + gy * g.os + g.oy0) * g.OW + gx * g.os + g.ox0;
-        float *orow = out + opix * g.Co;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int co = cot * CV_BM + wm * 64 + i * 16 + kg * 4;
-            if (co >= g.Co) continue;
-            f32x4 v = acc[i][j] * g.alpha;
-            if (oscale) {
-                const float *sp = oscale + (int64_t)n * g.Co + co;
-                v[0] *= sp[0];
-                if (co + 1 < g.Co) v[1] *= sp[1];
-                if (co + 2 < g.Co) v[2] *= sp[2];
-                if (co + 3 < g.Co) v[3] *= sp[3];
-            }
-            if (covec) {
-                *reinterpret_cast<float4 *>(orow + co) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
                 orow[co] = v[0];
                 if (co + 1 < g.Co) orow[co + 1] = v[1];
                 if (co + 2 < g.Co) orow[co + 2] = v[2];
                 if (co + 3 < g.Co) orow[co + 3] = v[3];
             }
         }
-    }
+    };
+    if (oscale) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 template <int SPLIT, bool VEC, bool DEEP, int NJ>
@@ -619,12 +698,13 @@ static void launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *
 extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *out, const float *iscale,
                                    const float *oscale, const rick_conv_geom *g, void *workspace, void *stream) {
     if (!x || !packed_w || !out || check_geom(g)) return RICK_EINVAL;
-    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed_w | (uintptr_t)(iscale ? iscale : x)) % 16) return RICK_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed_w | (uintptr_t)(iscale ? iscale : x) | (uintptr_t)(oscale ? oscale : x)) % 16)
+        return RICK_EINVAL;
     ConvTiling t;
     if (make_tiling(g, igemm_tile_positions(g), &t)) return RICK_EINVAL;
     igemm_plan_split(&t);
     if (t.nsplit > 1 && (!workspace || ((uintptr_t)workspace % 16))) return RICK_EINVAL;
-    const size_t lds = 2 * CV_WSTEP_BYTES + 2 * (size_t)((t.NPP * 64 + 15) & ~15) + (size_t)t.NPP * 4;
+    const size_t lds = igemm_lds_bytes(t, iscale != nullptr);
     if (lds > 160 * 1024 || t.PH > 1023 || t.PW > 1023) return RICK_EINVAL;
     const int64_t nwg = (int64_t)t.ntx * t.nty * t.ntn * t.ncot * t.nsplit;
     if (nwg > 0x7fffffff) return RICK_EINVAL;
@@ -660,7 +740,7 @@ static int plan_multi(const rick_conv_geom *geoms, int ngeom, IgemmMulti *m, siz
         if (make_tiling(g, CV_BN, &m->t[c])) return RICK_EINVAL;
         igemm_plan_split(&m->t[c]);
         const ConvTiling &t = m->t[c];
-        const size_t lds = 2 * CV_WSTEP_BYTES + 2 * (size_t)((t.NPP * 64 + 15) & ~15) + (size_t)t.NPP * 4;
+        const size_t lds = igemm_lds_bytes(t, true);
         if (lds > 160 * 1024 || t.PH > 1023 || t.PW > 1023) return RICK_EINVAL;
         lmax = lds > lmax ? lds : lmax;
         if (t.NPP > IG_DEEP_NPP) m->deep = 0;
@@ -701,7 +781,8 @@ extern "C" int rick_conv_igemm_multi_f32(const float *x, const void *packed_w, f
                                          const float *oscale, const rick_conv_geom *geoms, int ngeom, void *workspace,
                                          void *stream) {
     if (!x || !packed_w || !out) return RICK_EINVAL;
-    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed_w | (uintptr_t)(iscale ? iscale : x)) % 16) return RICK_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed_w | (uintptr_t)(iscale ? iscale : x) | (uintptr_t)(oscale ? oscale : x)) % 16)
+        return RICK_EINVAL;
     IgemmMulti m;
     size_t lds;
     int64_t wsf;
@@ -767,10 +848,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     unsigned char *gh = smem;                          // gy hi
     unsigned char *gl = smem + WG_GY_BYTES;            // gy lo
     unsigned char *ph = smem + 2 * WG_GY_BYTES;
-    unsigned char *pl = ph + ((t.NPP * 64 + 15) & ~15);
-    unsigned *ptab = reinterpret_cast<unsigned *>(pl + ((t.NPP * 64 + 15) & ~15));
+    unsigned char *pl = ph + (t.NPP + 1) * 64;         // (+1: spare row for out-of-patch items)
+    unsigned *ptab = reinterpret_cast<unsigned *>(pl + (t.NPP + 1) * 64);
+    float *sA = reinterpret_cast<float *>(ptab + ((t.NPP + 3) & ~3));   // [N][128 co] scales of gy (1 if none)
+    float *sB = sA + g.N * CV_BM;                                        // [N][32 ci]  scales of x
     build_patch_table(ptab, t);
-    __syncthreads();
 
     // XCD-aware mapping: blocks with equal blockIdx % 8 share an XCD (and its L2).  Every XCD owns its own
     // slices of the position range; all (co-tile, chunk) blocks of a slice run there, so a gy tile is fetched
@@ -824,6 +906,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     const int gc4 = threadIdx.x & 31, pc4 = threadIdx.x & 7;
     const int co_base = cot * CV_BM, ci_base = chunk * CV_CK;
     const int gco = co_base + gc4 * 4, pci = ci_base + pc4 * 4;
+    // per-(image, channel) scales of this block's channel ranges -> LDS once (applied in store_tile without
+    // a global-load round trip per item)
+    for (int i = threadIdx.x; i < g.N * CV_BM; i += 256) {
+        const int n = i >> 7, co = co_base + (i & 127);
+        sA[i] = !ascale ? 1.f : co < g.Co ? ascale[(int64_t)n * g.Co + co] : 0.f;
+    }
+    for (int i = threadIdx.x; i < g.N * CV_CK; i += 256) {
+        const int n = i >> 5, ci = ci_base + (i & 31);
+        sB[i] = !bscale ? 1.f : ci < g.Ci ? bscale[(int64_t)n * g.Ci + ci] : 0.f;
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int r = (threadIdx.x >> 5) + 8 * k;
@@ -837,7 +930,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         const int pix = (threadIdx.x >> 3) + 32 * k;
         p_rel[k] = 0;
         p_pyx[k] = 0xffffffffu;
-        p_lds[k] = pix * 64 + cv_swz(pc4 >> 1, pix) * 16 + (pc4 & 1) * 8;
+        p_lds[k] = (pix < t.NPP ? pix : t.NPP) * 64 + cv_swz(pc4 >> 1, pix) * 16 + (pc4 & 1) * 8;
         if (pix < t.NPP) {
             const unsigned e = ptab[pix];
             p_rel[k] = (((int)(e >> 20) * g.IH + (int)((e >> 10) & 1023)) * g.IW + (int)(e & 1023)) * g.Ci;
@@ -886,8 +979,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         for (int k = 0; k < 8; k++) {
             const bool ok = (okmask >> k) & 1u;
             float4 v = gq[k];
-            if (ascale)
-                v = mul4(v, load4<VEC>(ok ? ascale + (int64_t)(st_n0 + (int)(g_pyx[k] >> 20)) * g.Co + gco : ascale, ok, gco, g.Co));
+            v = mul4(v, *reinterpret_cast<const float4 *>(sA + (ok ? (st_n0 + (int)(g_pyx[k] >> 20)) * CV_BM : 0) + gc4 * 4));
             if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 hi, lo;
             split4<SPLIT>(v, hi, lo);
@@ -898,15 +990,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         for (int k = 0; k < PMAX; k++) {
             const bool ok = (okmask >> (8 + k)) & 1u;
             float4 v = pq[k];
-            if (bscale)
-                v = mul4(v, load4<VEC>(ok ? bscale + (int64_t)(st_n0 + (int)(p_pyx[k] >> 20)) * g.Ci + pci : bscale, ok, pci, g.Ci));
+            v = mul4(v, *reinterpret_cast<const float4 *>(sB + (ok ? (st_n0 + (int)(p_pyx[k] >> 20)) * CV_CK : 0) + pc4 * 4));
             if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 hi, lo;
             split4<SPLIT>(v, hi, lo);
-            if ((threadIdx.x >> 3) + 32 * k < t.NPP) {
-                *reinterpret_cast<uint2 *>(ph + p_lds[k]) = hi;
-                if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds[k]) = lo;
-            }
+            *reinterpret_cast<uint2 *>(ph + p_lds[k]) = hi;
+            if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds[k]) = lo;
         }
     };
 
@@ -1042,7 +1131,8 @@ extern "C" int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw, i
     ConvTiling t;
     int nsplit, tps;
     wgrad_plan(g, &t, &nsplit, &tps);
-    const size_t lds = 2 * WG_GY_BYTES + 2 * (size_t)((t.NPP * 64 + 15) & ~15) + (size_t)t.NPP * 4;
+    const size_t lds = 2 * WG_GY_BYTES + 2 * (size_t)(t.NPP + 1) * 64 + (size_t)((t.NPP + 3) & ~3) * 4 +
+                       (size_t)g->N * (CV_BM + CV_CK) * 4;
     if (lds > 160 * 1024 || t.NPP > 12 * 32 || t.PH > 1023 || t.PW > 1023) return RICK_EINVAL;
     if (g->split == 1 && (((g->Ci | g->Co) & 3) != 0)) return RICK_EINVAL;   // plain-bf16 option: vector path only
     hipStream_t st = (hipStream_t)stream;

@@ -95,7 +95,7 @@ extern "C" int rick_bias_act_f32(const float *x, const float *bias, const float 
 // One pass over g / ref: writes gx and per-block partial sums for gb[C] and gnw.
 // Block = 256 threads handling a contiguous slab of rows; thread t owns column group
 // (t % cg) and walks rows t / cg, t / cg + rpb, ...  (cg = min(C/4 or C, 256) lanes per row).
-#define BAB_ROWS_PER_BLOCK 64
+#define BAB_ROWS_PER_BLOCK 16
 
 extern "C" int rick_bias_act_bwd_blocks(int64_t rows, int C) {
     (void)C;
@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restri
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float nsum = 0.f;
     float *pb = partials + (int64_t)blockIdx.x * (C + 1);
+    const bool per_sample = noise_nb * rows_per_img == rows;
     // column groups are processed in chunks of up to 256 lanes
     for (int cbase = 0; cbase < ncol; cbase += 256) {
         const int cg = ncol - cbase < 256 ? ncol - cbase : 256;   // lanes per row in this chunk
@@ -127,27 +128,87 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restri
         const int lane_c = threadIdx.x % cg, lane_r = threadIdx.x / cg;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         if (lane_r < rpb) {
-            for (int64_t r = r0 + lane_r; r < r1; r += rpb) {
-                const int64_t off = r * C + (int64_t)(cbase + lane_c) * W;
+            // noise index of row r = (image % noise_nb) * noise_hw + pixel, advanced incrementally (no division per row)
+            int64_t r = r0 + lane_r;
+            int64_t img = noise ? r / rows_per_img : 0;
+            int64_t pix = noise ? r - img * rows_per_img : 0;   // host guarantees noise_hw == rows_per_img
+            img = noise ? img % noise_nb : 0;
+            const float *gp = g + r * C + (int64_t)(cbase + lane_c) * W;
+            const float *rp = ref + r * C + (int64_t)(cbase + lane_c) * W;
+            float *op = gx + r * C + (int64_t)(cbase + lane_c) * W;
+            const int64_t step = (int64_t)rpb * C;
+            if (VEC4) {
+                // 4 rows per iteration: 8 independent 16-byte loads in flight per thread
+                for (; r + 3 * rpb < r1; r += 4 * rpb) {
+                    float4 gv[4], rv[4];
+                    float nv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        gv[u] = *reinterpret_cast<const float4 *>(gp + u * step);
+                        rv[u] = *reinterpret_cast<const float4 *>(rp + u * step);
+                    }
+                    if (noise && per_sample) {   // one noise map per image: the noise index is the row index
+#pragma unroll
+                        for (int u = 0; u < 4; u++) nv[u] = noise[r + (int64_t)u * rpb];
+                    } else if (noise) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            nv[u] = noise[img * noise_hw + pix];
+                            pix += rpb;
+                            while (pix >= rows_per_img) {
+                                pix -= rows_per_img;
+                                img = img + 1 == noise_nb ? 0 : img + 1;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        float4 o;
+                        o.x = gv[u].x * (rv[u].x > 0.f ? 1.f : alpha) * scale;
+                        o.y = gv[u].y * (rv[u].y > 0.f ? 1.f : alpha) * scale;
+                        o.z = gv[u].z * (rv[u].z > 0.f ? 1.f : alpha) * scale;
+                        o.w = gv[u].w * (rv[u].w > 0.f ? 1.f : alpha) * scale;
+                        *reinterpret_cast<float4 *>(op + u * step) = o;
+                        acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
+                        nsum += (o.x + o.y + o.z + o.w) * nv[u];
+                    }
+                    gp += 4 * step;
+                    rp += 4 * step;
+                    op += 4 * step;
+                }
+            }
+            for (; r < r1; r += rpb) {
                 float nv = 0.f;
-                if (noise) nv = noise[((r / rows_per_img) % noise_nb) * noise_hw + r % noise_hw];
+                if (noise && per_sample) {
+                    nv = noise[r];
+                } else if (noise) {
+                    nv = noise[img * noise_hw + pix];
+                    pix += rpb;
+                    while (pix >= rows_per_img) {
+                        pix -= rows_per_img;
+                        img = img + 1 == noise_nb ? 0 : img + 1;
+                    }
+                }
                 if (VEC4) {
-                    const float4 gv = *reinterpret_cast<const float4 *>(g + off);
-                    const float4 rv = *reinterpret_cast<const float4 *>(ref + off);
+                    const float4 gv = *reinterpret_cast<const float4 *>(gp);
+                    const float4 rv = *reinterpret_cast<const float4 *>(rp);
                     float4 o;
                     o.x = gv.x * (rv.x > 0.f ? 1.f : alpha) * scale;
                     o.y = gv.y * (rv.y > 0.f ? 1.f : alpha) * scale;
                     o.z = gv.z * (rv.z > 0.f ? 1.f : alpha) * scale;
                     o.w = gv.w * (rv.w > 0.f ? 1.f : alpha) * scale;
-                    *reinterpret_cast<float4 *>(gx + off) = o;
+                    *reinterpret_cast<float4 *>(op) = o;
                     acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
                     nsum += (o.x + o.y + o.z + o.w) * nv;
                 } else {
-                    const float o = g[off] * (ref[off] > 0.f ? 1.f : alpha) * scale;
-                    gx[off] = o;
+                    const float o = gp[0] * (rp[0] > 0.f ? 1.f : alpha) * scale;
+                    op[0] = o;
                     acc[0] += o;
                     nsum += o * nv;
                 }
+                gp += step;
+                rp += step;
+                op += step;
             }
         }
         if (want_gb) {
@@ -170,24 +231,47 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restri
     }
 }
 
-// out[c] = sum_b partials[b*stride + col0 + c].  Block = 32 columns x 8 partial-row groups; the 8
-// group sums are combined through LDS in a fixed order (deterministic).
+// out[c] = sum_b partials[b*stride + col0 + c].  Block = CPB columns x (256 / CPB) row groups; a thread walks
+// its group's partial rows with 4 loads in flight, the group sums are combined by a fixed LDS tree
+// (deterministic).  CPB = 8 keeps many rows in parallel (the stage is latency-bound: few KB..MB of partials),
+// CPB = 1 spends the whole block on a single column (the noise-strength gradient).
+template <int CPB>
 __global__ __launch_bounds__(256) void partial_colsum_kernel(const float *__restrict__ partials, float *__restrict__ out,
                                                              int nb, int stride, int ncols, int col0) {
+    constexpr int G = 256 / CPB;
     __shared__ float red[256];
-    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    const int cl = threadIdx.x % CPB, grp = threadIdx.x / CPB;
+    const int c = blockIdx.x * CPB + cl;
     float s = 0.f;
-    if (c < ncols)
-        for (int b = grp; b < nb; b += 8) s += partials[(int64_t)b * stride + col0 + c];
+    if (c < ncols) {
+        const float *pp = partials + col0 + c;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = grp;
+        for (; b + 3 * G < nb; b += 4 * G) {
+            s0 += pp[(int64_t)b * stride];
+            s1 += pp[(int64_t)(b + G) * stride];
+            s2 += pp[(int64_t)(b + 2 * G) * stride];
+            s3 += pp[(int64_t)(b + 3 * G) * stride];
+        }
+        for (; b < nb; b += G) s0 += pp[(int64_t)b * stride];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[threadIdx.x] = s;
     __syncthreads();
-    if (grp == 0 && c < ncols) {
-        float t = 0.f;
 #pragma unroll
-        for (int g = 0; g < 8; g++) t += red[g * 32 + cl];
-        out[c] = t;
+    for (int off = G / 2; off > 0; off >>= 1) {
+        if (grp < off) red[threadIdx.x] += red[threadIdx.x + off * CPB];
+        __syncthreads();
     }
+    if (grp == 0 && c < ncols) out[c] = red[cl];
+}
+
+static void launch_colsum(const float *partials, float *out, int nb, int stride, int ncols, int col0, hipStream_t st) {
+    if (ncols == 1)
+        hipLaunchKernelGGL(partial_colsum_kernel<1>, dim3(1), dim3(256), 0, st, partials, out, nb, stride, ncols, col0);
+    else
+        hipLaunchKernelGGL(partial_colsum_kernel<8>, dim3(cdiv(ncols, 8)), dim3(256), 0, st, partials, out, nb, stride, ncols,
+                           col0);
 }
 
 extern "C" int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx, float *gb, float *gnw,
@@ -196,7 +280,7 @@ extern "C" int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx
                                      float *partials, void *stream) {
     if (!g || !ref || !gx || rows <= 0 || C <= 0 || ((gb || gnw) && !partials)) return RICK_EINVAL;
     if (gnw && !noise) return RICK_EINVAL;
-    if (noise && (rows_per_img <= 0 || noise_nb <= 0 || noise_hw <= 0)) return RICK_EINVAL;
+    if (noise && (rows_per_img <= 0 || noise_nb <= 0 || noise_hw != rows_per_img)) return RICK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nb = rick_bias_act_bwd_blocks(rows, C);
     const bool vec = (C % 4 == 0) && (((uintptr_t)g | (uintptr_t)ref | (uintptr_t)gx) % 16 == 0);
@@ -208,8 +292,8 @@ extern "C" int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx
     else
         hipLaunchKernelGGL(bias_act_bwd_kernel<false>, dim3(nb), dim3(256), lds, st, g, ref, gx, nz, partials, rows, C,
                            rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0);
-    if (gb) hipLaunchKernelGGL(partial_colsum_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, partials, gb, nb, C + 1, C, 0);
-    if (gnw) hipLaunchKernelGGL(partial_colsum_kernel, dim3(1), dim3(256), 0, st, partials, gnw, nb, C + 1, 1, C);
+    if (gb) launch_colsum(partials, gb, nb, C + 1, C, 0, st);
+    if (gnw) launch_colsum(partials, gnw, nb, C + 1, 1, C, st);
     RICK_LAUNCH_STATUS();
 }
 
@@ -246,10 +330,10 @@ extern "C" int rick_chan_scale_f32(const float *x, const float *s, float *y, int
 }
 
 // d[n,c] = sum_p a[n,p,c]*b[n,p,c].  grid (blocks_p, N); partials [blk][n][c]
-#define HWDOT_ROWS 256
+#define HWDOT_ROWS 16
 extern "C" int rick_hw_dot_blocks(int64_t P) {
     int64_t nb = cdiv64(P, HWDOT_ROWS);
-    if (nb > 256) nb = 256;
+    if (nb > 512) nb = 512;
     return (int)(nb < 1 ? 1 : nb);
 }
 
@@ -269,17 +353,38 @@ __global__ __launch_bounds__(256) void hw_dot_kernel(const float *__restrict__ a
         const int rpb = 256 / cg;
         const int lane_c = threadIdx.x % cg, lane_r = threadIdx.x / cg;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (lane_r < rpb)
-            for (int64_t p = p0 + lane_r; p < p1; p += rpb) {
-                const int64_t off = p * C + (int64_t)(cbase + lane_c) * W;
+        if (lane_r < rpb) {
+            int64_t p = p0 + lane_r;
+            const int64_t step = (int64_t)rpb * C;
+            const float *ap = an + p * C + (int64_t)(cbase + lane_c) * W, *bp = bn + p * C + (int64_t)(cbase + lane_c) * W;
+            if (VEC4)
+                for (; p + 3 * rpb < p1; p += 4 * rpb) {   // 8 independent 16-byte loads in flight per thread
+                    float4 av[4], bv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        av[u] = *reinterpret_cast<const float4 *>(ap + u * step);
+                        bv[u] = *reinterpret_cast<const float4 *>(bp + u * step);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        acc[0] += av[u].x * bv[u].x; acc[1] += av[u].y * bv[u].y;
+                        acc[2] += av[u].z * bv[u].z; acc[3] += av[u].w * bv[u].w;
+                    }
+                    ap += 4 * step;
+                    bp += 4 * step;
+                }
+            for (; p < p1; p += rpb) {
                 if (VEC4) {
-                    const float4 av = *reinterpret_cast<const float4 *>(an + off);
-                    const float4 bv = *reinterpret_cast<const float4 *>(bn + off);
+                    const float4 av = *reinterpret_cast<const float4 *>(ap);
+                    const float4 bv = *reinterpret_cast<const float4 *>(bp);
                     acc[0] += av.x * bv.x; acc[1] += av.y * bv.y; acc[2] += av.z * bv.z; acc[3] += av.w * bv.w;
                 } else {
-                    acc[0] += an[off] * bn[off];
+                    acc[0] += ap[0] * bp[0];
                 }
+                ap += step;
+                bp += step;
             }
+        }
         __syncthreads();
         for (int j = 0; j < W; j++) lds[threadIdx.x * W + j] = lane_r < rpb ? acc[j] : 0.f;
         __syncthreads();
@@ -301,7 +406,7 @@ extern "C" int rick_hw_dot_f32(const float *a, const float *b, float *d, int N, 
         hipLaunchKernelGGL(hw_dot_kernel<true>, dim3(nb, N), dim3(256), 1024 * sizeof(float), st, a, b, partials, P, C);
     else
         hipLaunchKernelGGL(hw_dot_kernel<false>, dim3(nb, N), dim3(256), 1024 * sizeof(float), st, a, b, partials, P, C);
-    hipLaunchKernelGGL(partial_colsum_kernel, dim3(cdiv(N * C, 32)), dim3(256), 0, st, partials, d, nb, N * C, N * C, 0);
+    launch_colsum(partials, d, nb, N * C, N * C, 0, st);
     RICK_LAUNCH_STATUS();
 }
 

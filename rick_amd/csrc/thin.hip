@@ -8,9 +8,66 @@
 #define THIN_MAXJ 4
 
 // t[n,j,p] = sum_c x[n,p,c] * W[n,j,c] (+ add[n,j,p]);  LPP lanes cooperate on one pixel.
+// A lane owns the same NQ channel quads for every pixel it visits, so its W values live in registers
+// (NQ x J float4) and the loop body is one 16-byte load of x per quad; UNR pixels are in flight per lane.
+template <int NQ>
 __global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__ x, const float *__restrict__ W,
                                                        int64_t w_bstride, const float *__restrict__ add,
                                                        float *__restrict__ t, int64_t P, int C, int J, int lpp) {
+    constexpr int UNR = 4;
+    const int n = blockIdx.y;
+    const int pix_per_block = 256 / lpp;
+    const int sub = threadIdx.x % lpp, pl = threadIdx.x / lpp;
+    const float *Wn = W + (int64_t)n * w_bstride;
+    float4 wr[NQ][THIN_MAXJ];
+#pragma unroll
+    for (int qd = 0; qd < NQ; qd++)
+#pragma unroll
+        for (int j = 0; j < THIN_MAXJ; j++)
+            // rows j >= J re-read row J-1 (their sums are never stored): no branch, so the 4 x NQ loads batch
+            wr[qd][j] = *reinterpret_cast<const float4 *>(Wn + (int64_t)(j < J ? j : J - 1) * C + (sub + qd * lpp) * 4);
+    const float *xn = x + (int64_t)n * P * C + sub * 4;
+    const int64_t stride = (int64_t)gridDim.x * pix_per_block;
+    for (int64_t p0 = (int64_t)blockIdx.x * pix_per_block + pl; p0 < P; p0 += stride * UNR) {
+        float4 xv[UNR][NQ];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int64_t p = p0 + u * stride;
+#pragma unroll
+            for (int qd = 0; qd < NQ; qd++)
+                xv[u][qd] = *reinterpret_cast<const float4 *>(xn + (p < P ? p : 0) * C + qd * lpp * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int64_t p = p0 + u * stride;
+            float acc[THIN_MAXJ] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qd = 0; qd < NQ; qd++)
+#pragma unroll
+                for (int j = 0; j < THIN_MAXJ; j++)
+                    acc[j] += xv[u][qd].x * wr[qd][j].x + xv[u][qd].y * wr[qd][j].y + xv[u][qd].z * wr[qd][j].z +
+                              xv[u][qd].w * wr[qd][j].w;
+#pragma unroll
+            for (int j = 0; j < THIN_MAXJ; j++)
+                for (int off = lpp >> 1; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off, 64);
+            if (p < P && sub < J) {
+                // lane `sub` writes output channel j = sub (select without dynamic register indexing)
+                float v = acc[0];
+                if (sub == 1) v = acc[1];
+                if (sub == 2) v = acc[2];
+                if (sub == 3) v = acc[3];
+                const int64_t o = ((int64_t)n * J + sub) * P + p;
+                if (add) v += add[o];
+                t[o] = v;
+            }
+        }
+    }
+}
+
+// Generic form (any C % 4 == 0): lanes stride over the channel quads, W re-read through L1.
+__global__ __launch_bounds__(256) void thin_fwd_generic_kernel(const float *__restrict__ x, const float *__restrict__ W,
+                                                               int64_t w_bstride, const float *__restrict__ add,
+                                                               float *__restrict__ t, int64_t P, int C, int J, int lpp) {
     const int n = blockIdx.y;
     const int pix_per_block = 256 / lpp;
     const int sub = threadIdx.x % lpp, pl = threadIdx.x / lpp;
@@ -35,7 +92,6 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__
         for (int j = 0; j < THIN_MAXJ; j++)
             for (int off = lpp >> 1; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off, 64);
         if (p < P && sub < J) {
-            // lane `sub` writes output channel j = sub (select without dynamic register indexing)
             float v = acc[0];
             if (sub == 1) v = acc[1];
             if (sub == 2) v = acc[2];
@@ -50,13 +106,38 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__
 extern "C" int rick_thin_fwd_f32(const float *x, const float *W, int64_t w_bstride, const float *add, float *t,
                                  int N, int64_t P, int C, int J, void *stream) {
     if (!x || !W || !t || N <= 0 || P <= 0 || C <= 0 || C % 4 || J < 1 || J > THIN_MAXJ || N > 65535) return RICK_EINVAL;
+    const int C4 = C / 4;
+    hipStream_t st = (hipStream_t)stream;
+    // fast path: lanes per pixel = a power of two (>= 4: J lanes store) dividing C/4, every lane owns nq whole quads
     int lpp = 64;
-    while (lpp > C / 4) lpp >>= 1;
-    if (lpp < J) lpp = 4;   // J <= 4 lanes needed for the store; C%4==0 && C>=4 guarantees c4 loop ok
-    int64_t nb = cdiv64(P, 256 / lpp);
+    while (lpp > 4 && (C4 % lpp || lpp > C4)) lpp >>= 1;
+    const int nq = C4 / lpp;
+    if (C4 % lpp || lpp > C4 || nq > 8) {
+        lpp = 64;
+        while (lpp > C4) lpp >>= 1;
+        if (lpp < J) lpp = 4;
+        int64_t nbg = cdiv64(P, 256 / lpp);
+        if (nbg > 4096) nbg = 4096;
+        hipLaunchKernelGGL(thin_fwd_generic_kernel, dim3((unsigned)nbg, N), dim3(256), 0, st, x, W, w_bstride, add, t, P, C,
+                           J, lpp);
+        RICK_LAUNCH_STATUS();
+    }
+    int64_t nb = cdiv64(P, (int64_t)(256 / lpp) * 4);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(thin_fwd_kernel, dim3((unsigned)nb, N), dim3(256), 0, (hipStream_t)stream, x, W, w_bstride, add, t,
-                       P, C, J, lpp);
+    if (nb < 1) nb = 1;
+    const dim3 grid((unsigned)nb, N), blk(256);
+#define THIN_FWD_LAUNCH(Q) hipLaunchKernelGGL(thin_fwd_kernel<Q>, grid, blk, 0, st, x, W, w_bstride, add, t, P, C, J, lpp)
+    switch (nq) {
+    case 1: THIN_FWD_LAUNCH(1); break;
+    case 2: THIN_FWD_LAUNCH(2); break;
+    case 3: THIN_FWD_LAUNCH(3); break;
+    case 4: THIN_FWD_LAUNCH(4); break;
+    case 5: THIN_FWD_LAUNCH(5); break;
+    case 6: THIN_FWD_LAUNCH(6); break;
+    case 7: THIN_FWD_LAUNCH(7); break;
+    default: THIN_FWD_LAUNCH(8); break;
+    }
+#undef THIN_FWD_LAUNCH
     RICK_LAUNCH_STATUS();
 }
 
@@ -73,13 +154,19 @@ __global__ __launch_bounds__(256) void thin_bwdx_kernel(const float *__restrict_
         const int64_t p = i4 / C4;
         const int c4 = (int)(i4 - p * C4);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float tv[THIN_MAXJ];
+        float4 wv[THIN_MAXJ];
 #pragma unroll
-        for (int j = 0; j < THIN_MAXJ; j++)
-            if (j < J) {
-                const float tv = tn[(int64_t)j * P + p];
-                const float4 wv = *reinterpret_cast<const float4 *>(Wn + (int64_t)j * C + c4 * 4);
-                acc.x += tv * wv.x; acc.y += tv * wv.y; acc.z += tv * wv.z; acc.w += tv * wv.w;
-            }
+        for (int j = 0; j < THIN_MAXJ; j++) {   // unconditional loads (row J-1 again for j >= J), zero weight after
+            const int jj = j < J ? j : J - 1;
+            tv[j] = tn[(int64_t)jj * P + p];
+            wv[j] = *reinterpret_cast<const float4 *>(Wn + (int64_t)jj * C + c4 * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < THIN_MAXJ; j++) {
+            const float tj = j < J ? tv[j] : 0.f;
+            acc.x += tj * wv[j].x; acc.y += tj * wv[j].y; acc.z += tj * wv[j].z; acc.w += tj * wv[j].w;
+        }
         xn[i4] = acc;
     }
 }
@@ -122,12 +209,13 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float *__restrict
         if (lane_r < rpb)
             for (int64_t p = p0 + lane_r; p < p1; p += rpb) {
                 const float4 xv = *reinterpret_cast<const float4 *>(xn + p * C + (int64_t)(cbase + lane_c) * 4);
+                float tv[THIN_MAXJ];
 #pragma unroll
-                for (int j = 0; j < THIN_MAXJ; j++)
-                    if (j < J) {
-                        const float tv = tn[(int64_t)j * P + p];
-                        acc[j].x += tv * xv.x; acc[j].y += tv * xv.y; acc[j].z += tv * xv.z; acc[j].w += tv * xv.w;
-                    }
+                for (int j = 0; j < THIN_MAXJ; j++) tv[j] = tn[(int64_t)(j < J ? j : J - 1) * P + p];   // no branch
+#pragma unroll
+                for (int j = 0; j < THIN_MAXJ; j++) {   // accumulators of rows j >= J are never stored
+                    acc[j].x += tv[j] * xv.x; acc[j].y += tv[j] * xv.y; acc[j].z += tv[j] * xv.z; acc[j].w += tv[j] * xv.w;
+                }
             }
 #pragma unroll
         for (int j = 0; j < THIN_MAXJ; j++) {

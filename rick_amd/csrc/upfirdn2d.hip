@@ -12,6 +12,7 @@
 //   planar  (minor == 1, e.g. the RGB skip path): 16x64 output tile per 256-thread block
 //   nhwc    (minor % 4 == 0): 64-channel slab x TOHxTOW pixel tile, float4 per lane
 #include "common.h"
+#include <stdlib.h>
 
 struct UfdParams {
     int in_h, in_w, minor, kh, kw;
@@ -143,7 +144,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
                                                                 float *__restrict__ out, UfdParams p) {
     constexpr int TIH = (TOH - 1) * DOWN + 4, TIW = (TOW - 1) * DOWN + 4, CB4 = 16;
     __shared__ float4 sx[TIH * TIW * CB4];
-    const int tile_x = blockIdx.x % p.tiles_x, tile_y = blockIdx.x / p.tiles_x;
+    // blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of tiles (row-major), so the
+    // halo rows / columns that neighbouring tiles share are re-read from the same L2 (placement only)
+    int tile = blockIdx.x;
+    if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int tile_x = tile % p.tiles_x, tile_y = tile / p.tiles_x;
     const int c0 = blockIdx.y * 64;
     const int64_t n = blockIdx.z;
     const int oy0 = tile_y * TOH, ox0 = tile_x * TOW;
@@ -153,13 +158,24 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
     for (int i = 0; i < 16; i++) kr[i] = kern[i];
     const float *src = in + n * (int64_t)p.in_h * p.in_w * p.minor + c0;
     const int c4 = threadIdx.x & 15;
-    for (int pix = threadIdx.x >> 4; pix < TIH * TIW; pix += 16) {
+    // stage the input tile: all of a thread's 16-byte loads are issued first (clamped addresses, no branch),
+    // then written to LDS — one HBM round trip per block instead of one per staged pixel
+    constexpr int NLD = (TIH * TIW + 15) / 16;
+    float4 stage[NLD];
+    unsigned okm = 0;
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+        const int pix = (threadIdx.x >> 4) + 16 * k;
         const int r = pix / TIW, c = pix - r * TIW;
         const int iy = iy_lo + r, ix = ix_lo + c;
-        const bool ok = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-        float4 v = *reinterpret_cast<const float4 *>(ok ? src + ((int64_t)iy * p.in_w + ix) * p.minor + c4 * 4 : in);
-        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        sx[pix * CB4 + c4] = v;
+        const bool ok = pix < TIH * TIW && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+        okm |= (ok ? 1u : 0u) << k;
+        stage[k] = *reinterpret_cast<const float4 *>(ok ? src + ((int64_t)iy * p.in_w + ix) * p.minor + c4 * 4 : in);
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+        const int pix = (threadIdx.x >> 4) + 16 * k;
+        if (pix < TIH * TIW) sx[pix * CB4 + c4] = ((okm >> k) & 1u) ? stage[k] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     float *dst = out + n * (int64_t)p.out_h * p.out_w * p.minor + c0;

@@ -101,6 +101,13 @@ class DataParallelGrads:
         return hook
 
     # --------------------------------------------------------------------------- public
+    def prepare(self, flat):
+        """Re-count the gradients each bucket waits for from the parameters' CURRENT requires_grad
+        flags.  Call after changing flags (warm-up gating, frozen D in the G step) and before
+        backward: a bucket armed with stale flags could leave before all of its gradients exist."""
+        if self.world > 1:
+            self._arm(self._state[id(flat)])
+
     def all_reduce(self, flat):
         """Average flat.grad over ranks (finishes the buckets the hooks already started)."""
         if self.world == 1:

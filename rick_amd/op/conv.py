@@ -19,6 +19,7 @@ plain bf16 MFMA.
 """
 import ctypes
 
+import numpy as np
 import torch
 from torch.autograd import Function
 
@@ -66,9 +67,17 @@ def get_precision():
     return 'bf16x3' if _SPLIT == 2 else 'bf16'
 
 
-def bump_weights_epoch():
-    """Invalidate cached packed weights (call after any raw-pointer parameter update)."""
+def bump_weights_epoch(params=None):
+    """Invalidate cached packed weights (call after any raw-pointer parameter update).  With `params`
+    (the parameters that were updated) only their PackGroups go stale; parameters outside any group, or
+    no argument, invalidate everything."""
     global _weights_epoch
+    if params is not None:
+        groups = [getattr(p, '_rick_group', None) for p in params]
+        if all(g is not None for g in groups):
+            for g in {id(g): g for g in groups}.values():
+                g.epoch += 1
+            return
     _weights_epoch += 1
 
 
@@ -91,11 +100,88 @@ def _w_strides(w):
     return w, st[0], st[1], s_t
 
 
+# rick_pack_desc (include/rick_hip.h), 64 bytes
+_DESC = np.dtype([('w', '<u8'), ('s_co', '<i8'), ('s_ci', '<i8'), ('s_t', '<i8'), ('packed', '<u8'), ('Co', '<i4'),
+                  ('Ci', '<i4'), ('nslices', '<i4'), ('scale', '<f4'), ('blk_begin', '<i4'), ('reserved', '<i4')])
+
+
+class PackGroup:
+    """All packed conv weights of one network, refreshed by ONE launch.
+
+    The optimiser updates every parameter of a network together, so the first stale lookup after a step
+    repacks every (parameter view, orientation) the network has asked for so far — rick_conv_pack_weights_multi —
+    instead of one pack launch + one allocation per layer and orientation.  Destination buffers and the device
+    descriptor table persist across steps."""
+
+    def __init__(self):
+        self.reqs = {}          # request key -> dict(param, buf, desc fields, stamp)
+        self.table = None       # device copy of the descriptor array
+        self.total_blocks = 0
+        self.epoch = 0          # bumped when this network's parameters were updated through raw pointers
+
+    def lookup(self, w, scale, key):
+        param, tag = key
+        rk = (id(param), tag, float(scale), tuple(w.shape), w.stride(), w.data_ptr())
+        req = self.reqs.get(rk)
+        if req is None:
+            w2, s_o, s_i, s_t = _w_strides(w)
+            if w2.data_ptr() != w.data_ptr():
+                return None                      # needed a temporary copy: not a stable view, pack individually
+            O, I, kh, kw = w.shape
+            buf = torch.empty(lib.rick_conv_packed_bytes(O, I, kh * kw), device=w.device, dtype=torch.uint8)
+            req = dict(param=param, off=w.data_ptr() - param.data_ptr(), buf=buf, stamp=None,
+                       desc=(w.data_ptr(), s_o, s_i, s_t, buf.data_ptr(), O, I, kh * kw, float(scale)))
+            self.reqs[rk] = req
+            self.table = None
+        if req['stamp'] != (param._version, _weights_epoch, self.epoch, _SPLIT):
+            self._repack()
+        return req['buf']
+
+    def _repack(self):
+        # requests whose parameter storage moved (e.g. .to(), re-flattening) are dropped; they re-register on use
+        stale = [k for k, r in self.reqs.items() if r['param'].data_ptr() + r['off'] != r['desc'][0]]
+        for k in stale:
+            del self.reqs[k]
+            self.table = None
+        if not self.reqs:
+            return
+        reqs = list(self.reqs.values())
+        if self.table is None:
+            arr = np.zeros(len(reqs), dtype=_DESC)
+            blk = 0
+            for i, r in enumerate(reqs):
+                w, s_o, s_i, s_t, packed, O, I, ns, sc = r['desc']
+                arr[i] = (w, s_o, s_i, s_t, packed, O, I, ns, sc, blk, 0)
+                blk += lib.rick_conv_pack_blocks(O, I)
+            self.total_blocks = blk
+            dev = reqs[0]['buf'].device
+            self.table = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
+        check(lib.rick_conv_pack_weights_multi(ptr(self.table), len(reqs), self.total_blocks, _SPLIT, stream_ptr()),
+              'rick_conv_pack_weights_multi')
+        for r in reqs:
+            r['stamp'] = (r['param']._version, _weights_epoch, self.epoch, _SPLIT)
+
+
+def register_pack_group(*modules):
+    """Put every parameter of `modules` (one network) into one PackGroup; returns the group."""
+    grp = PackGroup()
+    for m in modules:
+        for p in m.parameters():
+            p._rick_group = grp
+    return grp
+
+
 def _pack(w, scale, key=None):
     """Pack w[O, I, kh, kw] (any strides) * scale for the igemm A operand.  `key` = (param, tag)
-    enables caching across calls until the parameter changes."""
+    enables caching across calls until the parameter changes; parameters that belong to a PackGroup are
+    refreshed together with the rest of their network."""
     O, I, kh, kw = w.shape
     if key is not None:
+        grp = getattr(key[0], '_rick_group', None)
+        if grp is not None:
+            buf = grp.lookup(w, scale, key)
+            if buf is not None:
+                return buf
         ent = getattr(key[0], '_rick_packed', None)
         sig = (key[1], key[0]._version, _weights_epoch, _SPLIT, float(scale), tuple(w.shape), w.stride(), w.data_ptr())
         if ent is not None and sig in ent:

@@ -146,7 +146,7 @@ class MaskedFlatAdam:
                                            ptr(self.v[lo:hi]), ptr(mk), hi - lo, self.lr, b1, b2, self.eps,
                                            1.0 - b1 ** t, 1.0 - b2 ** t, stream_ptr()), 'rick_masked_adam_f32')
             k = kk + 1
-        op.bump_weights_epoch()
+        op.bump_weights_epoch(fp.params)
 
 
 def ema_flat(ema_flat_params, flat_params, decay):
@@ -156,7 +156,7 @@ def ema_flat(ema_flat_params, flat_params, decay):
         raise RuntimeError('ema_flat: layouts differ')
     check(lib.rick_ema_f32(ptr(ema_flat_params.flat), ptr(flat_params.flat), flat_params.total, decay, stream_ptr()),
           'rick_ema_f32')
-    op.bump_weights_epoch()
+    op.bump_weights_epoch(ema_flat_params.params)
 
 
 # ------------------------------------------------------------------------ Fisher sweep
@@ -328,6 +328,8 @@ class RickTrainer:
     def __init__(self, cfg, generator, discriminator, g_ema, d_ema, dp=None):
         self.cfg, self.g, self.d, self.g_ema, self.d_ema, self.dp = cfg, generator, discriminator, g_ema, d_ema, dp
         self.device = next(generator.parameters()).device
+        for net in (generator, discriminator, g_ema, d_ema):      # packed conv weights: one refresh launch per network
+            op.register_pack_group(net)
         self.g_flat = FlatParams(generator.named_parameters(), g_optim_filter)
         self.d_flat = FlatParams(discriminator.named_parameters(), d_optim_filter)
         self.g_ema_flat = FlatParams(g_ema.named_parameters())
@@ -372,6 +374,11 @@ class RickTrainer:
         if self.dp is not None:
             self.dp.all_reduce(flat)
 
+    def _zero_grad(self, flat):
+        flat.zero_grad()
+        if self.dp is not None:
+            self.dp.prepare(flat)          # bucket counts follow the stage's requires_grad flags
+
     # ---- steps (each returns the loss tensor; no host sync)
     def d_step(self, real_img, noise, i=10 ** 9, g_noise=None):
         self._set_d_stage(i)
@@ -382,7 +389,7 @@ class RickTrainer:
         pred, _ = self.d(torch.cat([fake_img, real_img], 0), calls=2)
         fake_pred, real_pred = pred.chunk(2, 0)
         d_loss = d_logistic_loss(real_pred, fake_pred)
-        self.d_flat.zero_grad()
+        self._zero_grad(self.d_flat)
         d_loss.backward()
         self._reduce(self.d_flat)
         self.d_optim.step()
@@ -397,7 +404,7 @@ class RickTrainer:
             real_pred, _ = self.d(real_img)
             real_pred = real_pred.view(real_img.size(0), -1).mean(dim=1).unsqueeze(1)
             r1_loss = d_r1_loss(real_pred, real_img)
-            self.d_flat.zero_grad()
+            self._zero_grad(self.d_flat)
             (cfg.r1 / 2 * r1_loss * cfg.d_reg_every + 0 * real_pred[0]).backward()
         self._reduce(self.d_flat)
         self.d_optim.step()
@@ -409,7 +416,7 @@ class RickTrainer:
         with self._d_frozen():
             fake_pred, _ = self.d(fake_img)
             g_loss = g_nonsaturating_loss(fake_pred)
-            self.g_flat.zero_grad()
+            self._zero_grad(self.g_flat)
             g_loss.backward()
         self._reduce(self.g_flat)
         self.g_optim.step()
@@ -436,7 +443,7 @@ class RickTrainer:
             fake_img, latents = self.g(noise, return_latents=True, noise=g_noise)
             path_loss, self.mean_path_length, path_lengths = g_path_regularize(
                 fake_img, latents, self.mean_path_length, noise=pl_noise)
-            self.g_flat.zero_grad()
+            self._zero_grad(self.g_flat)
             weighted = cfg.path_regularize * cfg.g_reg_every * path_loss
             if cfg.path_batch_shrink:
                 weighted = weighted + 0 * fake_img[0, 0, 0, 0]

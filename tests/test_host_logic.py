@@ -145,8 +145,8 @@ def _dp_worker(rank, world, port, q):
         res.append(flat.grad.clone())
     # frozen parameter (warm-up stage): its bucket must still complete
     named[0][1].requires_grad = False
-    dp._arm(dp._state[id(flat)])
     flat.zero_grad()
+    dp.prepare(flat)
     lin(xs[rank * 4:(rank + 1) * 4]).pow(2).mean().backward()
     dp.all_reduce(flat)
     vec = [torch.full((5,), float(rank + 1)), torch.full((3,), 10.0 * (rank + 1))]

@@ -18,10 +18,11 @@ def timeit(fn, reps=20, warm=3):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 B = int(os.environ.get('B', 4))
+SC = int(os.environ.get('SCALES', 0))   # 1: per-(image, channel) input/output scales as in the modulated convs
 which = sys.argv[1:] or ['fprop', 'dgrad', 'wgrad']
 shapes = [(512, 512, 4), (512, 512, 8), (512, 512, 16), (512, 512, 32), (512, 512, 64), (256, 256, 128), (128, 128, 256),
           (512, 256, 64), (256, 128, 128)]
-print(f'B={B} precision={cv.get_precision()}')
+print(f'B={B} precision={cv.get_precision()} scales={SC}')
 for ci, co, r in shapes:
     x = torch.randn(B, ci, r, r, device='cuda').contiguous(memory_format=torch.channels_last)
     w = torch.randn(co, ci, 3, 3, device='cuda')
@@ -29,15 +30,17 @@ for ci, co, r in shapes:
     flops = 2.0 * B * r * r * ci * co * 9
     wp = cv._pack(w, 1.0)
     wpT = cv._pack(w.transpose(0, 1), 1.0)
+    si = torch.rand(B, ci, device='cuda') + 0.5 if SC else None
+    so = torch.rand(B, co, device='cuda') + 0.5 if SC else None
     out = [f'{ci:4d}->{co:4d} @{r:3d}: {flops/1e9:7.2f} GF']
     if 'fprop' in which:
-        t = timeit(lambda: cv._conv_launch(x, wp, co, 3, 3, 1, 1))
+        t = timeit(lambda: cv._conv_launch(x, wp, co, 3, 3, 1, 1, iscale=si, oscale=so))
         out.append(f'fprop {t*1e6:8.1f} us {flops/t/1e12:6.1f} TF')
     if 'dgrad' in which:
-        t = timeit(lambda: cv._convT_launch(gy, wpT, ci, 3, 3, 1, 1, (r, r)))
+        t = timeit(lambda: cv._convT_launch(gy, wpT, ci, 3, 3, 1, 1, (r, r), iscale=so, oscale=si))
         out.append(f'dgrad {t*1e6:8.1f} us {flops/t/1e12:6.1f} TF')
     if 'wgrad' in which:
-        t = timeit(lambda: cv._wgrad_launch(gy, x, 3, 3, 1, 1))
+        t = timeit(lambda: cv._wgrad_launch(gy, x, 3, 3, 1, 1, ascale=so, bscale=si))
         out.append(f'wgrad {t*1e6:8.1f} us {flops/t/1e12:6.1f} TF')
     print(' | '.join(out))
 # stride-2 (D conv2) and transposed (G up)
