@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'librick_hip.so')
+LIB_PATH = os.environ.get('RICK_HIP_LIB') or os.path.join(_HERE, 'lib', 'librick_hip.so')   # override: kernel experiments
 MAX_TAPS = 16
 
 c_fp = ctypes.c_void_p

@@ -837,19 +837,30 @@ __device__ __forceinline__ bf16x8 tr_read2(const unsigned char *base, int off0, 
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &f) {   // f(integral_constant<int, I>) ... f(<N-1>): indices usable as constants
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 __device__ __forceinline__ int wg_key(int r) { return (((r >> 3) & 1) << 2) + (r & 3); }
 
-template <int NT, int SPLIT, bool VEC, int PMAX>
+template <int NT, int SPLIT, bool VEC, int PMAX, bool PIPE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                          float *__restrict__ ws, const float *__restrict__ ascale,
                                                          const float *__restrict__ bscale, const rick_conv_geom g,
                                                          const ConvTiling t, int nsplit, int tiles_per_split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // one operand buffer = [gy hi 16 KB][gy lo 16 KB][patch hi (NPP+1) x 64 B][patch lo]; PIPE keeps two of them
+    // (+1 patch row: spare row for out-of-patch items)
+    const int bufsz = 2 * WG_GY_BYTES + 2 * (t.NPP + 1) * 64;
     unsigned char *gh = smem;                          // gy hi
     unsigned char *gl = smem + WG_GY_BYTES;            // gy lo
     unsigned char *ph = smem + 2 * WG_GY_BYTES;
-    unsigned char *pl = ph + (t.NPP + 1) * 64;         // (+1: spare row for out-of-patch items)
-    unsigned *ptab = reinterpret_cast<unsigned *>(pl + (t.NPP + 1) * 64);
+    unsigned char *pl = ph + (t.NPP + 1) * 64;
+    unsigned *ptab = reinterpret_cast<unsigned *>(smem + (PIPE ? 2 : 1) * bufsz);
     float *sA = reinterpret_cast<float *>(ptab + ((t.NPP + 3) & ~3));   // [N][128 co] scales of gy (1 if none)
     float *sB = sA + g.N * CV_BM;                                        // [N][32 ci]  scales of x
     build_patch_table(ptab, t);
@@ -999,46 +1010,207 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         }
     };
 
-    if (tile_begin < tile_end) load_tile(tile_begin);
-    for (int tile = tile_begin; tile < tile_end; tile++) {
-        __syncthreads();   // previous tile fully consumed
-        if (!(t.debug & 6) || tile == tile_begin) store_tile();
-        __syncthreads();
-        if (tile + 1 < tile_end && !(t.debug & 10)) load_tile(tile + 1);
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads ahead of the MFMA phase
-        if (t.debug & 1) continue;
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            bf16x8 ahi[4], alo[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int cb = (wm * 64 + i * 16 + p * 4) * 2;
-                const int o0 = a_row[kk][0] + (cb ^ a_key[kk][0]);
-                const int o1 = a_row[kk][1] + (cb ^ a_key[kk][1]);
-                ahi[i] = tr_read2(gh, o0, o1);
-                if (SPLIT == 2) alo[i] = tr_read2(gl, o0, o1);
-            }
-#pragma unroll
-            for (int tt = 0; tt < NT; tt++) {
-                if (tt < g.ntaps) {
-                    const int toff = (g.dy[tt] - t.dymin) * t.PW + (g.dx[tt] - t.dxmin);
-                    const int pp0 = pbase[kk][0] + toff, pp1 = pbase[kk][1] + toff;
-                    const int o0 = pp0 * 64 + cv_swz(b_kg, pp0) * 16 + b_sub;
-                    const int o1 = pp1 * 64 + cv_swz(b_kg, pp1) * 16 + b_sub;
-                    const bf16x8 bhi = tr_read2(ph, o0, o1);
-                    bf16x8 blo;
-                    if (SPLIT == 2) blo = tr_read2(pl, o0, o1);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        if (SPLIT == 2) {
-                            acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi, acc[i][tt], 0, 0, 0);
-                            acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo, acc[i][tt], 0, 0, 0);
+    if (!PIPE) {
+        if (tile_begin < tile_end) load_tile(tile_begin);
+        for (int tile = tile_begin; tile < tile_end; tile++) {
+            __syncthreads();   // previous tile fully consumed
+            if (!(t.debug & 6) || tile == tile_begin) store_tile();
+            __syncthreads();
+            if (tile + 1 < tile_end && !(t.debug & 10)) load_tile(tile + 1);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads ahead of the MFMA phase
+            if (t.debug & 1) continue;
+    #pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                bf16x8 ahi[4], alo[4];
+    #pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int cb = (wm * 64 + i * 16 + p * 4) * 2;
+                    const int o0 = a_row[kk][0] + (cb ^ a_key[kk][0]);
+                    const int o1 = a_row[kk][1] + (cb ^ a_key[kk][1]);
+                    ahi[i] = tr_read2(gh, o0, o1);
+                    if (SPLIT == 2) alo[i] = tr_read2(gl, o0, o1);
+                }
+    #pragma unroll
+                for (int tt = 0; tt < NT; tt++) {
+                    if (tt < g.ntaps) {
+                        const int toff = (g.dy[tt] - t.dymin) * t.PW + (g.dx[tt] - t.dxmin);
+                        const int pp0 = pbase[kk][0] + toff, pp1 = pbase[kk][1] + toff;
+                        const int o0 = pp0 * 64 + cv_swz(b_kg, pp0) * 16 + b_sub;
+                        const int o1 = pp1 * 64 + cv_swz(b_kg, pp1) * 16 + b_sub;
+                        const bf16x8 bhi = tr_read2(ph, o0, o1);
+                        bf16x8 blo;
+                        if (SPLIT == 2) blo = tr_read2(pl, o0, o1);
+    #pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            if (SPLIT == 2) {
+                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi, acc[i][tt], 0, 0, 0);
+                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo, acc[i][tt], 0, 0, 0);
+                            }
+                            acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi, acc[i][tt], 0, 0, 0);
                         }
-                        acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi, acc[i][tt], 0, 0, 0);
                     }
                 }
             }
         }
+    } else {
+        // ---- software-pipelined form (two operand buffers in LDS).  While the MFMAs of tile t run from buffer
+        // t&1, the same wave converts the raw registers of tile t+1 into buffer (t+1)&1 — one staging item per
+        // (k-half, tap) slot, placed in program order between the MFMA groups so its VALU / LDS-write work issues
+        // in the shadow of the matrix pipe — and re-issues each register's global load for tile t+2 as soon as
+        // the register is free.  One barrier per tile; a load has a whole tile period to land.
+        constexpr int NITEM = 8 + PMAX, NSLOT = 2 * NT, IPS = (NITEM + NSLOT - 1) / NSLOT;
+        const float *gbase = gy, *xbase = x;     // bases of the tile being LOADED
+        int l_n0 = 0, l_nrem = 0, l_yrem = 0, l_xrem = 0, l_iy0 = 0, l_ix0 = 0;
+        unsigned mask_ld = 0, mask_cv = 0;       // validity of the registers being loaded / converted
+        int cv_n0 = 0;
+        // a tile inside ONE image (every layer >= 8x8) has one gy / x scale vector per thread: kept in registers,
+        // fetched from the LDS table once per tile instead of once per staged item
+        const bool one_img = t.nbe == 1;
+        float4 sa_cv = make_float4(1.f, 1.f, 1.f, 1.f), sb_cv = sa_cv;
+        auto set_tile = [&](int tile) {
+            int pt = tile;
+            const int tx_i = pt % t.ntx;
+            pt /= t.ntx;
+            const int ty_i = pt % t.nty;
+            const int tn_i = pt / t.nty;
+            const int gx0 = tx_i << t.tw_log2, gy0 = ty_i << t.th_log2;
+            l_n0 = tn_i * t.nbe;
+            l_iy0 = gy0 * g.is + t.dymin;
+            l_ix0 = gx0 * g.is + t.dxmin;
+            gbase = gy + (((int64_t)l_n0 * g.OH + gy0 * g.os + g.oy0) * g.OW + gx0 * g.os + g.ox0) * g.Co + gco;
+            xbase = x + (((int64_t)l_n0 * g.IH + l_iy0) * g.IW + l_ix0) * g.Ci + pci;
+            l_nrem = g.N - l_n0;
+            l_yrem = g.GH - gy0;
+            l_xrem = g.GW - gx0;
+            mask_ld = 0;
+        };
+        auto issue_item = [&](auto KC) {         // raw load of staging item K of the tile selected by set_tile
+            constexpr int K = decltype(KC)::value;
+            if constexpr (K < 8) {
+                const unsigned e = g_pyx[K];
+                const int nbi = (int)(e >> 20), py = (int)((e >> 10) & 1023), px = (int)(e & 1023);
+                const bool ok = e != 0xffffffffu && nbi < l_nrem && py < l_yrem && px < l_xrem;
+                mask_ld |= (ok ? 1u : 0u) << K;
+                gq[K] = load4<VEC>(ok ? gbase + g_rel[K] : gy, ok, gco, g.Co);
+            } else {
+                constexpr int P = K - 8;
+                const unsigned e = p_pyx[P];
+                const int nbi = (int)(e >> 20), iy = l_iy0 + (int)((e >> 10) & 1023), ix = l_ix0 + (int)(e & 1023);
+                const bool ok = e != 0xffffffffu && nbi < l_nrem && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+                mask_ld |= (ok ? 1u : 0u) << K;
+                pq[P] = load4<VEC>(ok ? xbase + p_rel[P] : x, ok, pci, g.Ci);
+            }
+        };
+        auto convert_item = [&](auto KC, unsigned char *buf, auto ONE) {   // raw register K -> scaled bf16 hi/lo in `buf`
+            constexpr int K = decltype(KC)::value;
+            constexpr bool ONE_IMG = decltype(ONE)::value;
+            const bool ok = (mask_cv >> K) & 1u;
+            if constexpr (K < 8) {
+                float4 v = gq[K];
+                if constexpr (ONE_IMG) v = mul4(v, sa_cv);
+                else v = mul4(v, *reinterpret_cast<const float4 *>(sA + (ok ? (cv_n0 + (int)(g_pyx[K] >> 20)) * CV_BM : 0) + gc4 * 4));
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                uint2 hi, lo;
+                split4<SPLIT>(v, hi, lo);
+                *reinterpret_cast<uint2 *>(buf + g_lds[K]) = hi;
+                if (SPLIT == 2) *reinterpret_cast<uint2 *>(buf + WG_GY_BYTES + g_lds[K]) = lo;
+            } else {
+                constexpr int P = K - 8;
+                float4 v = pq[P];
+                if constexpr (ONE_IMG) v = mul4(v, sb_cv);
+                else v = mul4(v, *reinterpret_cast<const float4 *>(sB + (ok ? (cv_n0 + (int)(p_pyx[P] >> 20)) * CV_CK : 0) + pc4 * 4));
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                uint2 hi, lo;
+                split4<SPLIT>(v, hi, lo);
+                *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + p_lds[P]) = hi;
+                if (SPLIT == 2) *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + (t.NPP + 1) * 64 + p_lds[P]) = lo;
+            }
+        };
+        auto for_items = [&](auto LO, auto fn) {  // fn(K) for the IPS items of one slot, K static
+            constexpr int L = decltype(LO)::value;
+            if constexpr (L < NITEM) fn(std::integral_constant<int, L>{});
+            if constexpr (IPS > 1 && L + 1 < NITEM) fn(std::integral_constant<int, L + 1>{});
+            if constexpr (IPS > 2 && L + 2 < NITEM) fn(std::integral_constant<int, L + 2>{});
+            if constexpr (IPS > 3 && L + 3 < NITEM) fn(std::integral_constant<int, L + 3>{});
+            if constexpr (IPS > 4 && L + 4 < NITEM) fn(std::integral_constant<int, L + 4>{});
+            if constexpr (IPS > 5 && L + 5 < NITEM) fn(std::integral_constant<int, L + 5>{});
+            if constexpr (IPS > 6 && L + 6 < NITEM) fn(std::integral_constant<int, L + 6>{});
+            if constexpr (IPS > 7 && L + 7 < NITEM) fn(std::integral_constant<int, L + 7>{});
+            if constexpr (IPS > 8 && L + 8 < NITEM) fn(std::integral_constant<int, L + 8>{});
+            if constexpr (IPS > 9 && L + 9 < NITEM) fn(std::integral_constant<int, L + 9>{});
+            static_assert(IPS <= 10, "items per slot");
+        };
+        auto for_slots = [&](auto fn) { static_for<0, NSLOT>(fn); };   // fn(slot), slot static
+        // prologue: tile_begin -> buffer 0, raw registers <- tile_begin + 1
+        if (tile_begin < tile_end) {
+            set_tile(tile_begin);
+            for_slots([&](auto S) { for_items(std::integral_constant<int, decltype(S)::value * IPS>{}, [&](auto K) { issue_item(K); }); });
+            mask_cv = mask_ld;
+            cv_n0 = l_n0;
+            sa_cv = *reinterpret_cast<const float4 *>(sA + (cv_n0 < g.N ? cv_n0 : 0) * CV_BM + gc4 * 4);
+            sb_cv = *reinterpret_cast<const float4 *>(sB + (cv_n0 < g.N ? cv_n0 : 0) * CV_CK + pc4 * 4);
+            for_slots([&](auto S) {
+                for_items(std::integral_constant<int, decltype(S)::value * IPS>{}, [&](auto K) { convert_item(K, smem, std::false_type{}); });
+            });
+            set_tile(tile_begin + 1 < tile_end ? tile_begin + 1 : tile_end - 1);
+            for_slots([&](auto S) { for_items(std::integral_constant<int, decltype(S)::value * IPS>{}, [&](auto K) { issue_item(K); }); });
+        }
+        __syncthreads();
+        // two copies of the tile loop (tile within one image / spanning images): a run-time select per item would
+        // put a branch between the loads and cost the exact vmcnt counts
+        auto run = [&](auto ONE) {
+            for (int tile = tile_begin; tile < tile_end; tile++) {
+                const int cur = (tile - tile_begin) & 1;
+                const unsigned char *bgh = smem + cur * bufsz, *bgl = bgh + WG_GY_BYTES;
+                const unsigned char *bph = bgh + 2 * WG_GY_BYTES, *bpl = bph + (t.NPP + 1) * 64;
+                unsigned char *nbuf = smem + (cur ^ 1) * bufsz;
+                mask_cv = mask_ld;                   // the registers hold tile + 1
+                cv_n0 = l_n0;
+                sa_cv = *reinterpret_cast<const float4 *>(sA + (cv_n0 < g.N ? cv_n0 : 0) * CV_BM + gc4 * 4);
+                sb_cv = *reinterpret_cast<const float4 *>(sB + (cv_n0 < g.N ? cv_n0 : 0) * CV_CK + pc4 * 4);
+                // No branch around the staging work: past the end of the range the last tile is simply staged again
+                // (never consumed).  With straight-line VMEM traffic hipcc's waitcnt pass keeps exact counts
+                // (vmcnt(NITEM-1) per converted register); any branch here makes it fall back to vmcnt(0) per slot.
+                set_tile(tile + 2 < tile_end ? tile + 2 : tile_end - 1);
+                bf16x8 ahi[4], alo[4];
+                for_slots([&](auto SC) {
+                    constexpr int S = decltype(SC)::value, kk = S / NT, tt = S % NT;
+                    if constexpr (tt == 0) {
+    #pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int cb = (wm * 64 + i * 16 + p * 4) * 2;
+                            const int o0 = a_row[kk][0] + (cb ^ a_key[kk][0]);
+                            const int o1 = a_row[kk][1] + (cb ^ a_key[kk][1]);
+                            ahi[i] = tr_read2(bgh, o0, o1);
+                            if (SPLIT == 2) alo[i] = tr_read2(bgl, o0, o1);
+                        }
+                    }
+                    for_items(std::integral_constant<int, S * IPS>{}, [&](auto K) { convert_item(K, nbuf, ONE); });
+                    for_items(std::integral_constant<int, S * IPS>{}, [&](auto K) { issue_item(K); });
+                    if (tt < g.ntaps) {
+                        const int ts = tt < g.ntaps ? tt : 0;
+                        const int toff = (g.dy[ts] - t.dymin) * t.PW + (g.dx[ts] - t.dxmin);
+                        const int pp0 = pbase[kk][0] + toff, pp1 = pbase[kk][1] + toff;
+                        const int o0 = pp0 * 64 + cv_swz(b_kg, pp0) * 16 + b_sub;
+                        const int o1 = pp1 * 64 + cv_swz(b_kg, pp1) * 16 + b_sub;
+                        const bf16x8 bhi = tr_read2(bph, o0, o1);
+                        bf16x8 blo;
+                        if (SPLIT == 2) blo = tr_read2(bpl, o0, o1);
+    #pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            if (SPLIT == 2) {
+                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi, acc[i][tt], 0, 0, 0);
+                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo, acc[i][tt], 0, 0, 0);
+                            }
+                            acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi, acc[i][tt], 0, 0, 0);
+                        }
+                    }
+                });
+                __syncthreads();   // buffer `cur` fully consumed, buffer cur^1 fully written
+            }
+        };
+        if (one_img) run(std::true_type{});
+        else run(std::false_type{});
     }
 
     // ---- partial tile -> workspace [split][cot][chunk][tap][32 ci][128 co]: a lane's 4 accumulator
@@ -1101,25 +1273,39 @@ extern "C" int64_t rick_conv_wgrad_workspace_bytes(const rick_conv_geom *g) {
     return (int64_t)nsplit * t.ncot * t.nchunks * g->ntaps * CV_BM * CV_CK * 4;
 }
 
-template <int NT, int SPLIT, bool VEC, int PMAX>
+template <int NT, int SPLIT, bool VEC, int PMAX, bool PIPE>
 static void launch_wgrad_k(const float *x, const float *gy, float *ws, const float *ascale, const float *bscale,
                            const rick_conv_geom *g, const ConvTiling &t, int nsplit, int tps, size_t lds, hipStream_t st) {
     const unsigned nwg = (unsigned)(nsplit * t.ncot * t.nchunks);
-    (void)hipFuncSetAttribute((const void *)conv_wgrad_kernel<NT, SPLIT, VEC, PMAX>,
+    (void)hipFuncSetAttribute((const void *)conv_wgrad_kernel<NT, SPLIT, VEC, PMAX, PIPE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv_wgrad_kernel<NT, SPLIT, VEC, PMAX>), dim3(nwg), dim3(256), lds, st, x, gy, ws, ascale, bscale,
-                       *g, t, nsplit, tps);
+    hipLaunchKernelGGL((conv_wgrad_kernel<NT, SPLIT, VEC, PMAX, PIPE>), dim3(nwg), dim3(256), lds, st, x, gy, ws, ascale,
+                       bscale, *g, t, nsplit, tps);
+}
+
+static size_t wgrad_lds_bytes(const rick_conv_geom *g, const ConvTiling &t, bool pipe) {
+    const size_t buf = 2 * WG_GY_BYTES + 2 * (size_t)(t.NPP + 1) * 64;
+    return (pipe ? 2 : 1) * buf + (size_t)((t.NPP + 3) & ~3) * 4 + (size_t)g->N * (CV_BM + CV_CK) * 4;
+}
+// The software-pipelined form needs two operand buffers in LDS; production path only (bf16x3, vector loads).
+static bool wgrad_use_pipe(const rick_conv_geom *g, const ConvTiling &t) {
+    static const int off = getenv("RICK_WGRAD_NOPIPE") ? atoi(getenv("RICK_WGRAD_NOPIPE")) : 0;
+    return !off && g->split == 2 && ((g->Ci | g->Co) & 3) == 0 && wgrad_lds_bytes(g, t, true) <= 160 * 1024;
 }
 
 template <int NT>
 static void launch_wgrad(const float *x, const float *gy, float *ws, const float *ascale, const float *bscale,
-                         const rick_conv_geom *g, const ConvTiling &t, int nsplit, int tps, size_t lds, hipStream_t st) {
+                         const rick_conv_geom *g, const ConvTiling &t, int nsplit, int tps, hipStream_t st) {
     const bool vec = ((g->Ci | g->Co) & 3) == 0;
     const bool small = t.NPP <= 4 * 32;
-    if (g->split == 1 && vec) launch_wgrad_k<NT, 1, true, 12>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
-    else if (!vec) launch_wgrad_k<NT, 2, false, 12>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
-    else if (small) launch_wgrad_k<NT, 2, true, 4>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
-    else launch_wgrad_k<NT, 2, true, 12>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    const bool pipe = wgrad_use_pipe(g, t);
+    const size_t lds = wgrad_lds_bytes(g, t, pipe);
+    if (g->split == 1 && vec) launch_wgrad_k<NT, 1, true, 12, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (!vec) launch_wgrad_k<NT, 2, false, 12, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (small && pipe) launch_wgrad_k<NT, 2, true, 4, true>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (small) launch_wgrad_k<NT, 2, true, 4, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (pipe) launch_wgrad_k<NT, 2, true, 12, true>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else launch_wgrad_k<NT, 2, true, 12, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
 }
 
 extern "C" int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw, int64_t s_co, int64_t s_ci, int64_t s_t,
@@ -1131,15 +1317,13 @@ extern "C" int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw, i
     ConvTiling t;
     int nsplit, tps;
     wgrad_plan(g, &t, &nsplit, &tps);
-    const size_t lds = 2 * WG_GY_BYTES + 2 * (size_t)(t.NPP + 1) * 64 + (size_t)((t.NPP + 3) & ~3) * 4 +
-                       (size_t)g->N * (CV_BM + CV_CK) * 4;
-    if (lds > 160 * 1024 || t.NPP > 12 * 32 || t.PH > 1023 || t.PW > 1023) return RICK_EINVAL;
+    if (wgrad_lds_bytes(g, t, false) > 160 * 1024 || t.NPP > 12 * 32 || t.PH > 1023 || t.PW > 1023) return RICK_EINVAL;
     if (g->split == 1 && (((g->Ci | g->Co) & 3) != 0)) return RICK_EINVAL;   // plain-bf16 option: vector path only
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
-    if (g->ntaps == 1) launch_wgrad<1>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
-    else if (g->ntaps <= 4) launch_wgrad<4>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
-    else launch_wgrad<9>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    if (g->ntaps == 1) launch_wgrad<1>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
+    else if (g->ntaps <= 4) launch_wgrad<4>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
+    else launch_wgrad<9>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
     const int64_t per_split = (int64_t)t.ncot * t.nchunks * g->ntaps * CV_BM * CV_CK;
     int64_t nb = cdiv64(per_split, 256);
     if (nb > 4096) nb = 4096;
