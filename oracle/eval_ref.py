@@ -1,0 +1,30 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): CPU restatement of the FID statistics the reference
+computes around its Inception network (gan_training/metrics/fid_score.py).  Pinned against
+tests/golden/fid.npz, which tools/make_golden.py produces by running the reference's own
+``calculate_frechet_distance`` / ``np.cov`` path in the build container."""
+import numpy as np
+from scipy import linalg
+
+
+def activation_statistics_ref(act):
+    """fid_score.py:138-142: mu = mean over samples, sigma = np.cov(act, rowvar=False)."""
+    act = np.asarray(act, dtype=np.float64)
+    return np.mean(act, axis=0), np.cov(act, rowvar=False)
+
+
+def frechet_distance_ref(mu1, sigma1, mu2, sigma2, eps=1e-6):
+    """fid_score.py:94-129: |mu1-mu2|^2 + tr S1 + tr S2 - 2 tr sqrtm(S1 S2), with the reference's eps-offset retry
+    for a singular product and its check on the imaginary part."""
+    mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)
+    sigma1, sigma2 = np.atleast_2d(sigma1), np.atleast_2d(sigma2)
+    assert mu1.shape == mu2.shape and sigma1.shape == sigma2.shape
+    diff = mu1 - mu2
+    covmean, _ = linalg.sqrtm(sigma1.dot(sigma2), disp=False)
+    if not np.isfinite(covmean).all():
+        offset = np.eye(sigma1.shape[0]) * eps
+        covmean = linalg.sqrtm((sigma1 + offset).dot(sigma2 + offset))
+    if np.iscomplexobj(covmean):
+        if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
+            raise ValueError('Imaginary component {}'.format(np.max(np.abs(covmean.imag))))
+        covmean = covmean.real
+    return diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean)

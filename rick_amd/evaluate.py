@@ -44,3 +44,86 @@ def sample_images(g_ema, n_sample_test, n_sample_store=25, latent=512, generator
     if was_training:
         g_ema.train()
     return out, (torch.cat(feats, 0) if feats else None)
+
+
+class FeatureStats:
+    """Streaming mean / covariance of feature vectors on the device (fp64 accumulators).
+
+    Replaces ``calculate_activation_statistics`` (gan_training/metrics/fid_score.py:132-142), which
+    gathers every activation on the host and calls ``np.mean`` / ``np.cov(rowvar=False)``: here each
+    batch adds ``sum x`` and ``x^T x`` (one hipBLAS GEMM) and the statistics are finalised once —
+    no [n_samples, dims] array ever exists, on either side of PCIe."""
+
+    def __init__(self, dims, device):
+        self.n = 0
+        self.sum = torch.zeros(dims, device=device, dtype=torch.float64)
+        self.outer = torch.zeros(dims, dims, device=device, dtype=torch.float64)
+
+    @torch.no_grad()
+    def update(self, feats):
+        f = feats.reshape(feats.shape[0], -1).to(torch.float64)
+        if f.shape[1] != self.sum.shape[0]:
+            raise RuntimeError(f'FeatureStats: expected {self.sum.shape[0]} features, got {f.shape[1]}')
+        self.sum += f.sum(0)
+        self.outer += f.t() @ f
+        self.n += f.shape[0]
+        return self
+
+    def finalize(self):
+        """-> (mu[dims], sigma[dims, dims]) with np.cov's default normalisation (n - 1)."""
+        if self.n < 2:
+            raise RuntimeError('FeatureStats: need at least two samples')
+        mu = self.sum / self.n
+        sigma = (self.outer - self.n * torch.outer(mu, mu)) / (self.n - 1)
+        return mu, sigma
+
+
+@torch.no_grad()
+def frechet_distance(mu1, sigma1, mu2, sigma2):
+    """d^2 = |mu1 - mu2|^2 + tr(S1) + tr(S2) - 2 tr sqrt(S1 S2)   (fid_score.py:94-129), on the device.
+
+    The reference takes scipy's ``sqrtm`` of the non-symmetric product and keeps the real part of its
+    trace.  S1 S2 is similar to the symmetric PSD matrix S1^(1/2) S2 S1^(1/2), so the same trace is the sum
+    of the square roots of that matrix's eigenvalues: two symmetric eigen-decompositions in fp64, no
+    host round trip, and no singular-product fallback is needed (negative round-off eigenvalues clamp to 0)."""
+    mu1, mu2 = mu1.to(torch.float64), mu2.to(torch.float64)
+    s1, s2 = sigma1.to(torch.float64), sigma2.to(torch.float64)
+    if mu1.shape != mu2.shape or s1.shape != s2.shape:
+        raise RuntimeError('frechet_distance: statistics have different shapes')
+    w, u = torch.linalg.eigh((s1 + s1.t()) * 0.5)
+    s1h = (u * w.clamp_min(0).sqrt()) @ u.t()
+    m = s1h @ s2 @ s1h
+    lam = torch.linalg.eigvalsh((m + m.t()) * 0.5)
+    tr_covmean = lam.clamp_min(0).sqrt().sum()
+    diff = mu1 - mu2
+    return diff.dot(diff) + torch.trace(s1) + torch.trace(s2) - 2 * tr_covmean
+
+
+@torch.no_grad()
+def fid_from_generator(g_ema, real_stats, feature_fn, n_sample_test=5000, n_sample_store=25, latent=512,
+                       generator=None, latents=None):
+    """BASELINE config 4 end to end on the device: sample ``n_sample_test`` images in batches of
+    ``n_sample_store`` (gan_training/eval.py:31-46), push each batch through ``feature_fn`` (the Inception
+    pool3 plug point: weights are supplied by the user, they are a download in the reference), accumulate
+    the statistics, and return the Frechet distance to ``real_stats = (mu, sigma)``."""
+    dev = next(g_ema.parameters()).device
+    stats = None
+    was_training = g_ema.training
+    g_ema.eval()
+    done = 0
+    while done < n_sample_test:
+        if latents is not None:
+            z = latents[done:done + n_sample_store].to(dev)
+        else:
+            z = torch.randn(n_sample_store, latent, device=dev, generator=generator)
+        img, _ = g_ema([z])
+        img = img[:n_sample_test - done]
+        f = feature_fn(img)
+        if stats is None:
+            stats = FeatureStats(f.reshape(f.shape[0], -1).shape[1], dev)
+        stats.update(f)
+        done += img.shape[0]
+    if was_training:
+        g_ema.train()
+    mu, sigma = stats.finalize()
+    return frechet_distance(mu, sigma, real_stats[0].to(dev), real_stats[1].to(dev))

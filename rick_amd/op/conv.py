@@ -133,6 +133,10 @@ class PackGroup:
                        desc=(w.data_ptr(), s_o, s_i, s_t, buf.data_ptr(), O, I, kh * kw, float(scale)))
             self.reqs[rk] = req
             self.table = None
+            # first use: pack just this one (the group launch takes over from the next refresh on)
+            check(lib.rick_conv_pack_weight(w.data_ptr(), s_o, s_i, s_t, O, I, kh * kw, float(scale), _SPLIT,
+                                            buf.data_ptr(), stream_ptr()), 'rick_conv_pack_weight')
+            req['stamp'] = (param._version, _weights_epoch, self.epoch, _SPLIT)
         if req['stamp'] != (param._version, _weights_epoch, self.epoch, _SPLIT):
             self._repack()
         return req['buf']

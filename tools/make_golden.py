@@ -12,7 +12,7 @@ the reference's own `upfirdn2d_native`, op/upfirdn2d.py:146-149).  Everything el
 Inputs are never stored when they can be regenerated from rick_amd.synth (closed-form,
 seeded by key name); only outputs are.
 
-usage: python tools/make_golden.py [--only ops|layers|small|full|latents]
+usage: python tools/make_golden.py [--only ops|layers|small|full|latents|fid]
 """
 import argparse
 import importlib.util
@@ -265,11 +265,44 @@ def gen_full(mpt):
     print('full256.npz', len(out), 'arrays')
 
 
+def gen_fid():
+    """FID statistics.  gan_training/metrics/fid_score.py imports cv2 / an Inception wrapper
+    that are absent here, so the two pure-NumPy/SciPy pieces are taken out of the reference FILE with `ast` and
+    executed as they are: calculate_frechet_distance (:94-129) and the mean / np.cov lines of
+    calculate_activation_statistics (:138-142, restated as a two-line lambda because they sit behind the model call)."""
+    import ast
+    from scipy import linalg
+    src = open(os.path.join(REF, 'gan_training', 'metrics', 'fid_score.py')).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == 'calculate_frechet_distance'][0]
+    ns = {'np': np, 'linalg': linalg}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), 'fid_score.py', 'exec'), ns)
+    frechet = ns['calculate_frechet_distance']
+    rng = np.random.RandomState(7)
+    out = {}
+    for tag, n, d, rank in (('a', 96, 24, 24), ('b', 200, 64, 64), ('lowrank', 40, 32, 12)):
+        basis = rng.randn(rank, d)
+        act0 = (rng.randn(n, rank) @ basis + 0.3 * rng.randn(1, d)).astype(np.float32)
+        act1 = (rng.randn(n, rank) * 1.3 @ basis + 0.1).astype(np.float32)
+        # get_activations collects the fp32 network outputs in np.empty((n, dims)) — a float64 array (:72,86)
+        a0, a1 = np.empty(act0.shape), np.empty(act1.shape)
+        a0[:], a1[:] = act0, act1
+        m0, s0 = np.mean(a0, axis=0), np.cov(a0, rowvar=False)
+        m1, s1 = np.mean(a1, axis=0), np.cov(a1, rowvar=False)
+        out[f'{tag}/act0'], out[f'{tag}/act1'] = act0, act1
+        out[f'{tag}/mu0'], out[f'{tag}/sigma0'], out[f'{tag}/mu1'], out[f'{tag}/sigma1'] = m0, s0, m1, s1
+        out[f'{tag}/fid'] = np.float64(frechet(m0, s0, m1, s1))
+    np.savez_compressed(os.path.join(OUT, 'fid.npz'), **out)
+    print('fid.npz:', {k: float(v) for k, v in out.items() if k.endswith('/fid')})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
+    if a.only == 'fid':
+        gen_fid()
+        return
     torch.manual_seed(1)
     op, mpt = import_reference()
     todo = [a.only] if a.only else ['latents', 'ops', 'layers', 'small', 'full']
@@ -283,6 +316,8 @@ def main():
         gen_small(mpt)
     if 'full' in todo:
         gen_full(mpt)
+    if not a.only:
+        gen_fid()
 
 
 if __name__ == '__main__':
