@@ -278,13 +278,21 @@ __device__ __forceinline__ float4 load4(const float *p, bool ok, int c, int C) {
 
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &f) {   // f(integral_constant<int, I>) ... f(<N-1>): indices usable as constants
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 // ==========================================================================================
 // Forward / data-gradient kernel.
 #define IG_PMAX 10        // non-DEEP: patch float4 per thread prefetched in registers (NPP <= 320 pixels)
 #define IG_PSET_DEEP 6     // DEEP: two register sets of 6 (NPP <= 192 pixels), chunks prefetched two ahead
 #define IG_DEEP_NPP (32 * IG_PSET_DEEP)
 
-template <int SPLIT, bool VEC, bool DEEP, int NJ>
+template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT>
 __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const unsigned char *__restrict__ wpk,
                                            float *__restrict__ out, const float *__restrict__ iscale,
                                            const float *__restrict__ oscale, float *__restrict__ ws,
@@ -346,8 +354,9 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     // DEEP (patches of <= 160 pixels: 1x1 convs and the parity classes of transposed convs, whose chunks
     // last only 1-4 k-steps): the IG_PMAX register slots form TWO sets of 5 and chunks are prefetched two
     // ahead, so a load has two chunks' worth of MFMAs to land instead of one.
-    constexpr int PSET = DEEP ? IG_PSET_DEEP : IG_PMAX;
-    constexpr int PREGS = DEEP ? 2 * IG_PSET_DEEP : IG_PMAX;
+    // register prefetch slots per set: the unrolled 128-position form only serves patches of <= 192 pixels
+    constexpr int PSET = (DEEP || (NT > 0 && NJ == 4)) ? IG_PSET_DEEP : IG_PMAX;
+    constexpr int PREGS = DEEP ? 2 * IG_PSET_DEEP : PSET;
     const int p_items = t.NPP * 8;
     const int c4 = threadIdx.x & 7;                      // 256 % 8 == 0: same channel quad for all items
     const float *xt = x + (((int64_t)n0 * g.IH + iy0) * g.IW + ix0) * g.Ci + c4 * 4;
@@ -399,7 +408,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         }
         if (!DEEP) {
             // patches larger than IG_PMAX*32 pixels (stride-2 geometry): remaining items, synchronously
-            for (int it = threadIdx.x + 256 * IG_PMAX; it < p_items; it += 256) {
+            for (int it = threadIdx.x + 256 * PSET; it < p_items; it += 256) {
                 const int pix = it >> 3;
                 const unsigned e = ptab[pix];
                 const int n = n0 + (int)(e >> 20), iy = iy0 + (int)((e >> 10) & 1023), ix = ix0 + (int)(e & 1023);
@@ -448,75 +457,159 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         }                                                               \
     } while (0)
 
-    // ---- prologue: patch(c_begin) [+ patch(c_begin+1) when DEEP], W(0)
-    issue_patch(c_begin, S0{});
-    if (DEEP && c_begin + 1 < c_end) issue_patch(c_begin + 1, S1{});
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(
-            wbase + ((int64_t)c_begin * g.nslices + g.wt[0]) * CV_WSTEP_BYTES);
-        CV_WLOAD(src);
-        CV_WSTORE(wbuf);
-    }
-    commit_patch(c_begin, S0{});
-    __syncthreads();
-
-    int chunk = c_begin, tap = 0;
-    for (int ks = 0; ks < nks; ks++) {
-        int nchunk = chunk, ntap = tap + 1;
-        if (ntap == g.ntaps) { ntap = 0; nchunk++; }
-        const bool more = ks + 1 < nks;
-        if (more && !(t.debug & 4)) {   // weights of k-step ks+1 -> registers
+    if constexpr (NT > 0) {
+        // ---- straight-line form for a compile-time tap count (the 3x3 layers that carry the FLOPs).  One channel
+        // chunk = NT fully unrolled k-steps; every k-step loads the next weight tile and a slice of the NEXT chunk's
+        // patch items, unconditionally (past the end of the range the last chunk is staged again and never used).
+        // With no branch between VMEM instructions hipcc keeps exact vmcnt counts: the weight store at the end of a
+        // k-step waits only for its own 4 loads, and the patch loads stay in flight until the chunk boundary
+        // (up to NT-1 k-steps) instead of being drained by the first weight wait.
+        static_assert(!DEEP, "the unrolled form prefetches one chunk ahead");
+        constexpr int IPT = (PSET + NT - 1) / NT;
+        auto issue_item = [&](auto KC, int chunk) {
+            constexpr int K = decltype(KC)::value;
+            const bool ok = (cur_ok[0] >> K) & 1u;
+            pq[K] = load4<VEC>(ok ? xt + p_rel[K] + chunk * CV_CK : x, ok, chunk * CV_CK + c4 * 4, g.Ci);
+        };
+        issue_patch(c_begin, S0{});
+        {
             const uint4 *src = reinterpret_cast<const uint4 *>(
-                wbase + ((int64_t)nchunk * g.nslices + g.wt[ntap]) * CV_WSTEP_BYTES);
+                wbase + ((int64_t)c_begin * g.nslices + g.wt[0]) * CV_WSTEP_BYTES);
             CV_WLOAD(src);
+            CV_WSTORE(wbuf);
         }
-        if (tap == 0 && !(t.debug & 2)) {   // patch prefetch: next chunk (two ahead when DEEP) -> registers
-            const int cpre = chunk + (DEEP ? 2 : 1);
-            if (cpre < c_end) {
-                if (DEEP && ((cpre - c_begin) & 1)) issue_patch(cpre, S1{});
-                else issue_patch(cpre, S0{});
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // prefetches are issued before the MFMAs, consumed after
-        if (!(t.debug & 1)) {
-            const unsigned char *wb = wbuf + (ks & 1) * CV_WSTEP_BYTES;
-            const int toff = (g.dy[tap] - t.dymin) * t.PW + (g.dx[tap] - t.dxmin);
-            bf16x8 ahi[4], alo[4], bhi[NJ], blo[NJ];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                ahi[i] = *reinterpret_cast<const bf16x8 *>(wb + a_off[i]);
-                if (SPLIT == 2) alo[i] = *reinterpret_cast<const bf16x8 *>(wb + CV_WTILE_BYTES + a_off[i]);
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; j++) {
-                const int pp = pb[j] + toff;
-                const int off = pp * 64 + cv_swz(kg, pp) * 16;
-                bhi[j] = *reinterpret_cast<const bf16x8 *>(ph + off);
-                if (SPLIT == 2) blo[j] = *reinterpret_cast<const bf16x8 *>(pl + off);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < NJ; j++) {
-                    if (SPLIT == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
-                }
-        }
-        if (more) {
-            if (ntap == 0 && !(t.debug & 2)) {   // next k-step starts a new channel chunk: all waves are done with the patch
-                __syncthreads();
-                if (DEEP && ((nchunk - c_begin) & 1)) commit_patch(nchunk, S1{});
-                else commit_patch(nchunk, S0{});
-            }
-            unsigned char *wd = wbuf + ((ks + 1) & 1) * CV_WSTEP_BYTES;
-            if (!(t.debug & 4)) CV_WSTORE(wd);
-        }
+        commit_patch(c_begin, S0{});
         __syncthreads();
-        chunk = nchunk;
-        tap = ntap;
+        for (int chunk = c_begin; chunk < c_end; chunk++) {
+            const int cnext = chunk + 1 < c_end ? chunk + 1 : chunk;
+            const int par = ((chunk - c_begin) * NT) & 1;
+            auto kstep = [&](auto TC) {
+                constexpr int tap = decltype(TC)::value;
+                {   // weights of the next k-step -> registers
+                    const int wchunk = tap + 1 < NT ? chunk : cnext, wtap = tap + 1 < NT ? tap + 1 : 0;
+                    const uint4 *src = reinterpret_cast<const uint4 *>(
+                        wbase + ((int64_t)wchunk * g.nslices + g.wt[wtap]) * CV_WSTEP_BYTES);
+                    CV_WLOAD(src);
+                }
+                if constexpr (tap == 0) cur_ok[0] = cnext * CV_CK + c4 * 4 < g.Ci ? p_ok : 0u;
+                if constexpr (tap * IPT < PSET) issue_item(std::integral_constant<int, tap * IPT>{}, cnext);
+                if constexpr (IPT > 1 && tap * IPT + 1 < PSET) issue_item(std::integral_constant<int, tap * IPT + 1>{}, cnext);
+                if constexpr (IPT > 2 && tap * IPT + 2 < PSET) issue_item(std::integral_constant<int, tap * IPT + 2>{}, cnext);
+                static_assert(IPT <= 3 || NT >= 4, "patch items per k-step");
+                if constexpr (IPT > 3) {   // few taps: the remaining items of this slice
+                    auto rest = [&](auto KC) {
+                        constexpr int K = decltype(KC)::value + 3;
+                        if constexpr (K < IPT && tap * IPT + K < PSET) issue_item(std::integral_constant<int, tap * IPT + K>{}, cnext);
+                    };
+                    static_for<0, 8>(rest);
+                }
+                {
+                    const unsigned char *wb = wbuf + ((par + tap) & 1) * CV_WSTEP_BYTES;
+                    const int toff = (g.dy[tap] - t.dymin) * t.PW + (g.dx[tap] - t.dxmin);
+                    bf16x8 ahi[4], alo[4], bhi[NJ], blo[NJ];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        ahi[i] = *reinterpret_cast<const bf16x8 *>(wb + a_off[i]);
+                        if (SPLIT == 2) alo[i] = *reinterpret_cast<const bf16x8 *>(wb + CV_WTILE_BYTES + a_off[i]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) {
+                        const int pp = pb[j] + toff;
+                        const int off = pp * 64 + cv_swz(kg, pp) * 16;
+                        bhi[j] = *reinterpret_cast<const bf16x8 *>(ph + off);
+                        if (SPLIT == 2) blo[j] = *reinterpret_cast<const bf16x8 *>(pl + off);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < NJ; j++) {
+                            if (SPLIT == 2) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
+                            }
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
+                        }
+                }
+                if constexpr (tap == NT - 1) {   // chunk boundary: all waves are done with the patch
+                    __syncthreads();
+                    commit_patch(cnext, S0{});
+                }
+                CV_WSTORE(wbuf + ((par + tap + 1) & 1) * CV_WSTEP_BYTES);
+                __syncthreads();
+            };
+            static_for<0, NT>(kstep);
+        }
+    } else {
+        // ---- prologue: patch(c_begin) [+ patch(c_begin+1) when DEEP], W(0)
+        issue_patch(c_begin, S0{});
+        if (DEEP && c_begin + 1 < c_end) issue_patch(c_begin + 1, S1{});
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(
+                wbase + ((int64_t)c_begin * g.nslices + g.wt[0]) * CV_WSTEP_BYTES);
+            CV_WLOAD(src);
+            CV_WSTORE(wbuf);
+        }
+        commit_patch(c_begin, S0{});
+        __syncthreads();
+
+        int chunk = c_begin, tap = 0;
+        for (int ks = 0; ks < nks; ks++) {
+            int nchunk = chunk, ntap = tap + 1;
+            if (ntap == g.ntaps) { ntap = 0; nchunk++; }
+            const bool more = ks + 1 < nks;
+            if (more && !(t.debug & 4)) {   // weights of k-step ks+1 -> registers
+                const uint4 *src = reinterpret_cast<const uint4 *>(
+                    wbase + ((int64_t)nchunk * g.nslices + g.wt[ntap]) * CV_WSTEP_BYTES);
+                CV_WLOAD(src);
+            }
+            if (tap == 0 && !(t.debug & 2)) {   // patch prefetch: next chunk (two ahead when DEEP) -> registers
+                const int cpre = chunk + (DEEP ? 2 : 1);
+                if (cpre < c_end) {
+                    if (DEEP && ((cpre - c_begin) & 1)) issue_patch(cpre, S1{});
+                    else issue_patch(cpre, S0{});
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // prefetches are issued before the MFMAs, consumed after
+            if (!(t.debug & 1)) {
+                const unsigned char *wb = wbuf + (ks & 1) * CV_WSTEP_BYTES;
+                const int toff = (g.dy[tap] - t.dymin) * t.PW + (g.dx[tap] - t.dxmin);
+                bf16x8 ahi[4], alo[4], bhi[NJ], blo[NJ];
+    #pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    ahi[i] = *reinterpret_cast<const bf16x8 *>(wb + a_off[i]);
+                    if (SPLIT == 2) alo[i] = *reinterpret_cast<const bf16x8 *>(wb + CV_WTILE_BYTES + a_off[i]);
+                }
+    #pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    const int pp = pb[j] + toff;
+                    const int off = pp * 64 + cv_swz(kg, pp) * 16;
+                    bhi[j] = *reinterpret_cast<const bf16x8 *>(ph + off);
+                    if (SPLIT == 2) blo[j] = *reinterpret_cast<const bf16x8 *>(pl + off);
+                }
+    #pragma unroll
+                for (int i = 0; i < 4; i++)
+    #pragma unroll
+                    for (int j = 0; j < NJ; j++) {
+                        if (SPLIT == 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (more) {
+                if (ntap == 0 && !(t.debug & 2)) {   // next k-step starts a new channel chunk: all waves are done with the patch
+                    __syncthreads();
+                    if (DEEP && ((nchunk - c_begin) & 1)) commit_patch(nchunk, S1{});
+                    else commit_patch(nchunk, S0{});
+                }
+                unsigned char *wd = wbuf + ((ks + 1) & 1) * CV_WSTEP_BYTES;
+                if (!(t.debug & 4)) CV_WSTORE(wd);
+            }
+            __syncthreads();
+            chunk = nchunk;
+            tap = ntap;
+        }
     }
 
     // ---- epilogue.  Instantiated twice (with / without output scales) so the scale loads of a j-column
@@ -593,13 +686,13 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     else epilogue(std::false_type{});
 }
 
-template <int SPLIT, bool VEC, bool DEEP, int NJ>
+template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restrict__ x,
                                                             const unsigned char *__restrict__ wpk,
                                                             float *__restrict__ out, const float *__restrict__ iscale,
                                                             const float *__restrict__ oscale, float *__restrict__ ws,
                                                             const rick_conv_geom g, const ConvTiling t) {
-    igemm_body<SPLIT, VEC, DEEP, NJ>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x);
+    igemm_body<SPLIT, VEC, DEEP, NJ, NT>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x);
 }
 
 // Several geometries (the output-parity classes of a transposed convolution) in ONE launch: block ranges
@@ -630,7 +723,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_multi_kernel(const float *_
         }
     // every parity class of a transposed conv has a patch of <= 160 pixels (tile + at most one halo row/col)
     // (the host only uses this kernel when every class qualifies for the two-ahead prefetch)
-    igemm_body<SPLIT, VEC, true, 4>(x, wpk, out, iscale, oscale, ws + m.ws_off[c], m.g[c], m.t[c], (int)blockIdx.x - start,
+    igemm_body<SPLIT, VEC, true, 4, 0>(x, wpk, out, iscale, oscale, ws + m.ws_off[c], m.g[c], m.t[c], (int)blockIdx.x - start,
                                  m.blk_end[c] - start);
 }
 
@@ -676,21 +769,27 @@ extern "C" int64_t rick_conv_igemm_workspace_bytes(const rick_conv_geom *g) {
     return t.nsplit > 1 ? (int64_t)t.nsplit * g->N * g->GH * g->GW * g->Co * 4 : 0;
 }
 
-template <int SPLIT, bool VEC, bool DEEP, int NJ>
+template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT = 0>
 static void launch_igemm_k(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
                            const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
                            const ConvTiling &t) {
-    (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<SPLIT, VEC, DEEP, NJ>,
+    (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv_igemm_kernel<SPLIT, VEC, DEEP, NJ>), dim3(nwg), dim3(256), lds, st, x, wp, out, iscale, oscale,
-                       ws, *g, t);
+    hipLaunchKernelGGL((conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT>), dim3(nwg), dim3(256), lds, st, x, wp, out, iscale,
+                       oscale, ws, *g, t);
 }
 
 template <int SPLIT, bool VEC>
 static void launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
                          const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
                          const ConvTiling &t) {
+    // production path (bf16x3, vector loads), 3x3 stride-1 layers with a long channel loop and a full grid: the
+    // straight-line 9-tap k-loop (measured +3..8 % there; slower on split-K, short-K and stride-2 launches)
+    static const int no_unroll = getenv("RICK_IGEMM_NOUNROLL") ? atoi(getenv("RICK_IGEMM_NOUNROLL")) : 0;
+    const bool u9 = SPLIT == 2 && VEC && g->ntaps == 9 && !no_unroll && !t.debug && igemm_tile_positions(g) == CV_BN &&
+                    t.NPP <= IG_DEEP_NPP && t.nsplit == 1 && t.nchunks >= 8;
     if (igemm_tile_positions(g) == 64) launch_igemm_k<SPLIT, VEC, false, 2>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
+    else if (u9) launch_igemm_k<2, true, false, 4, 9>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
     else if (t.NPP <= IG_DEEP_NPP) launch_igemm_k<SPLIT, VEC, true, 4>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
     else launch_igemm_k<SPLIT, VEC, false, 4>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
 }
@@ -792,7 +891,7 @@ extern "C" int rick_conv_igemm_multi_f32(const float *x, const void *packed_w, f
     float *ws = (float *)workspace;
     const unsigned char *wp = (const unsigned char *)packed_w;
     const bool vec = (geoms[0].Ci & 3) == 0;
-    if (!m.deep) {   // large patches: one ordinary launch per class
+    if (!m.deep || ngeom == 1) {   // large patches: one ordinary launch per class; a single class needs no multi launch
         for (int c = 0; c < ngeom; c++) {
             const int rc = rick_conv_igemm_f32(x, packed_w, out, iscale, oscale, &geoms[c],
                                                m.t[c].nsplit > 1 ? (void *)(ws + m.ws_off[c]) : nullptr, stream);
@@ -835,14 +934,6 @@ __device__ __forceinline__ bf16x8 tr_read2(const unsigned char *base, int off0, 
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_ptr)(base + off0));
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_ptr)(base + off1));
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &f) {   // f(integral_constant<int, I>) ... f(<N-1>): indices usable as constants
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
 }
 
 __device__ __forceinline__ int wg_key(int r) { return (((r >> 3) & 1) << 2) + (r & 3); }
