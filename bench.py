@@ -70,6 +70,9 @@ def main():
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-graphs', action='store_true', help='issue every launch from Python instead of replaying captured hipGraphs')
+    ap.add_argument('--graphs', action='store_true', help='replay captured step graphs also with N > 1 (default: N = 1 only; '
+                    'with data parallelism the eager path overlaps the bucketed all-reduce with backward)')
     ap.add_argument('--eval', action='store_true', help='also time G inference (BASELINE config 4: batches of 25)')
     ap.add_argument('--fisher-img', type=int, default=2, help='samples of the (untimed) Fisher sweep that sets the masks')
     args = ap.parse_args()
@@ -112,6 +115,15 @@ def main():
                     [synth_reals(1, cfg.size, seed=600 + j).to(dev) for j in mine], first=True)
 
     i0 = cfg.warmup_iter + 1
+    use_graphs = (args.graphs or world == 1) and not args.no_graphs
+    if use_graphs:
+        try:
+            tr.enable_graphs(True)
+            tr.prepare_graphs(reals[0])                    # untimed, like the Fisher sweep: steady state = graphs captured
+        except Exception as e:                             # noqa: BLE001 — a capture problem must not cost the measurement
+            print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); issuing launches eagerly', file=sys.stderr)
+            use_graphs = False
+            tr.enable_graphs(False)
 
     def run(n, start):
         for k in range(n):
@@ -142,12 +154,13 @@ def main():
         'data': 'synthetic',
         'config': {'workload': f'FFHQ-256 StyleGAN2 G+D RICK iteration (D step, R1/16, G step, PLR/4, EMA, masks on), '
                                f'batch {cfg.batch}/GPU, {cfg.size}px, channel_multiplier 2, random-init weights',
-                   'global_batch': cfg.batch * world, 'parallelism': f'dp{world}',
+                   'global_batch': cfg.batch * world, 'parallelism': f'dp{world}', 'hip_graphs': use_graphs,
                    'first_iteration': i0 + args.warmup},
     }
 
     if rank == 0 and not args.no_roofline:
         # instrumented repeat of 4 non-reg + reg iterations: HIP events around every conv-family launch
+        tr.enable_graphs(False)                            # events bracket individual launches: eager issue
         with launch_profiler() as prof:
             run(16, i0 + args.warmup + args.steps)
             torch.cuda.synchronize()

@@ -200,6 +200,13 @@ int rick_filter_reduce_f32(const float *x, float *out, int64_t outer, int64_t ou
 int rick_masked_adam_f32(float *p, float *g, float *m, float *v, const uint8_t *mask, int64_t n,
                          float lr, float beta1, float beta2, float eps, float bc1, float bc2,
                          void *stream);
+/* The same update with the step counters and bias corrections kept in DEVICE memory, so that a whole train step
+ * (incl. the optimiser) can be captured once into a hipGraph and replayed: rick_adam_prepare_f32 increments
+ * steps[first .. first+count) (int32, all equal) and writes bc = {1 - beta1^t, 1 - beta2^t} for the new count t;
+ * rick_masked_adam_dev_f32 is rick_masked_adam_f32 reading the two corrections from `bc`. */
+int rick_adam_prepare_f32(int *steps, int first, int count, float beta1, float beta2, float *bc, void *stream);
+int rick_masked_adam_dev_f32(float *p, float *g, float *m, float *v, const uint8_t *mask, int64_t n,
+                             float lr, float beta1, float beta2, float eps, const float *bc, void *stream);
 /* ema[i] = ema[i]*decay + p[i]*(1-decay) */
 int rick_ema_f32(float *ema, const float *p, int64_t n, float decay, void *stream);
 

@@ -51,6 +51,7 @@ def load_adam_state_dict(optim, sd):
         optim.steps[i] = int(round(float(st['step'])))
         optim.m[lo:hi].copy_(st['exp_avg'].reshape(-1))
         optim.v[lo:hi].copy_(st['exp_avg_sq'].reshape(-1))
+    optim.sync_steps_to_device()
     g0 = groups[0]
     optim.lr, optim.betas, optim.eps = g0['lr'], tuple(g0['betas']), g0['eps']
 

@@ -554,7 +554,12 @@ extern "C" int rick_filter_reduce_f32(const float *x, float *out, int64_t outer,
 __global__ __launch_bounds__(256) void masked_adam_kernel(float *__restrict__ p, float *__restrict__ g,
                                                           float *__restrict__ m, float *__restrict__ v,
                                                           const uint8_t *__restrict__ mask, int64_t n, float lr,
-                                                          float beta1, float beta2, float eps, float bc1, float bc2) {
+                                                          float beta1, float beta2, float eps, float bc1, float bc2,
+                                                          const float *__restrict__ bc_dev) {
+    if (bc_dev) {   // bias corrections kept on the device (rick_adam_prepare_f32): the launch is replayable in a hipGraph
+        bc1 = bc_dev[0];
+        bc2 = bc_dev[1];
+    }
     const int64_t stride = (int64_t)gridDim.x * 256;
     const float step_size = lr / bc1;
     const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
@@ -580,7 +585,34 @@ extern "C" int rick_masked_adam_f32(float *p, float *g, float *m, float *v, cons
     if (!p || !g || !m || !v || n < 0) return RICK_EINVAL;
     if (n == 0) return 0;
     hipLaunchKernelGGL(masked_adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, mask, n,
-                       lr, beta1, beta2, eps, bc1, bc2);
+                       lr, beta1, beta2, eps, bc1, bc2, (const float *)nullptr);
+    RICK_LAUNCH_STATUS();
+}
+
+// steps[first .. first+count) += 1 and bc = {1 - beta1^t, 1 - beta2^t} with t = the new step count of steps[first]
+// (every parameter of the range has the same count).  Keeping the step counter on the device makes an optimiser
+// step a pure function of device state, so a captured hipGraph of the whole train step can be replayed.
+__global__ void adam_prepare_kernel(int *__restrict__ steps, int first, int count, float beta1, float beta2,
+                                    float *__restrict__ bc) {
+    const int t = steps[first] + 1;
+    __syncthreads();
+    for (int j = threadIdx.x; j < count; j += blockDim.x) steps[first + j] += 1;
+    if (threadIdx.x == 0) {
+        bc[0] = (float)(1.0 - pow((double)beta1, (double)t));
+        bc[1] = (float)(1.0 - pow((double)beta2, (double)t));
+    }
+}
+extern "C" int rick_adam_prepare_f32(int *steps, int first, int count, float beta1, float beta2, float *bc, void *stream) {
+    if (!steps || !bc || first < 0 || count < 1) return RICK_EINVAL;
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, steps, first, count, beta1, beta2, bc);
+    RICK_LAUNCH_STATUS();
+}
+extern "C" int rick_masked_adam_dev_f32(float *p, float *g, float *m, float *v, const uint8_t *mask, int64_t n,
+                                        float lr, float beta1, float beta2, float eps, const float *bc, void *stream) {
+    if (!p || !g || !m || !v || !bc || n < 0) return RICK_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(masked_adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, mask, n,
+                       lr, beta1, beta2, eps, 1.f, 1.f, bc);
     RICK_LAUNCH_STATUS();
 }
 

@@ -47,6 +47,7 @@ class DataParallelGrads:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_elems = max(1, bucket_bytes // 4)
         self._state = {}       # id(flat) -> dict(buckets, pending, works, hooks)
+        self.hooks_enabled = True   # False: no launches from autograd hooks (backward replayed from a hipGraph)
 
     # ------------------------------------------------------------------ bucket bookkeeping
     def attach(self, *flats):
@@ -94,6 +95,8 @@ class DataParallelGrads:
 
     def _make_hook(self, st, i):
         def hook(_param):
+            if not self.hooks_enabled:
+                return
             b = st['owner'][i]
             st['pending'][b] -= 1
             if st['pending'][b] == 0 and not st['launched'][b]:

@@ -283,16 +283,18 @@ class Generator(nn.Module, _FisherMixin):
             latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
                                 styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
         feats = []
-        out = self.conv1(self.input(latent), latent[:, 0], noise=noise[0])
+        # one unbind instead of 20 selects: its backward is a single stack, not zeros + slice-copy + add per use
+        lat = latent.unbind(1)
+        out = self.conv1(self.input(latent), lat[0], noise=noise[0])
         feats.append(out)
-        skip = self.to_rgb1(out, latent[:, 1])
+        skip = self.to_rgb1(out, lat[1])
         i = 1
         for blk, to_rgb in enumerate(self.to_rgbs):
-            out = self.convs[2 * blk](out, latent[:, i], noise=noise[2 * blk + 1])
+            out = self.convs[2 * blk](out, lat[i], noise=noise[2 * blk + 1])
             feats.append(out)
-            out = self.convs[2 * blk + 1](out, latent[:, i + 1], noise=noise[2 * blk + 2])
+            out = self.convs[2 * blk + 1](out, lat[i + 1], noise=noise[2 * blk + 2])
             feats.append(out)
-            skip = to_rgb(out, latent[:, i + 2], skip)
+            skip = to_rgb(out, lat[i + 2], skip)
             i += 2
         image = skip.contiguous()
         if return_latents:

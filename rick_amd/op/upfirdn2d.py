@@ -41,6 +41,19 @@ def _fir(x, taps, up_xy, down_xy, pad4):
     return y
 
 
+def _flipped(taps):
+    """flip(taps) for the adjoint, cached ON the FIR tensor object (the networks' filters are constant buffers:
+    without the cache every blur backward launches a flip and a copy of a 16-element tensor).  The flipped tensor
+    points back at its source, so double backward reuses the pair."""
+    ent = getattr(taps, '_rick_flipped', None)
+    if ent is None or ent[0] != taps._version:
+        f = torch.flip(taps, [0, 1]).contiguous()
+        f._rick_flipped = (f._version, taps)
+        ent = (taps._version, f)
+        taps._rick_flipped = ent
+    return ent[1]
+
+
 class _UpFirDn(Function):
     """y = upfirdn2d(x; taps, up, down, pad).  backward(g) = _UpFirDn(g; flip(taps), down, up, adj_pad)."""
 
@@ -53,15 +66,14 @@ class _UpFirDn(Function):
         # pads of the adjoint operator (same expressions as op/upfirdn2d.py:111-114)
         adj = (kw - pad4[0] - 1, w * up_xy[0] - ow * down_xy[0] + pad4[0] - up_xy[0] + 1,
                kh - pad4[2] - 1, h * up_xy[1] - oh * down_xy[1] + pad4[2] - up_xy[1] + 1)
-        ctx.save_for_backward(taps)
+        ctx.flipped = _flipped(taps)         # a constant of the op (no gradient flows to the FIR taps)
         ctx.adjoint = (down_xy, up_xy, adj)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        (taps,) = ctx.saved_tensors
         a_up, a_down, a_pad = ctx.adjoint
-        gx = _UpFirDn.apply(g, torch.flip(taps, [0, 1]).contiguous(), a_up, a_down, a_pad)
+        gx = _UpFirDn.apply(g, ctx.flipped, a_up, a_down, a_pad)
         return gx, None, None, None, None
 
 

@@ -117,17 +117,35 @@ class MaskedFlatAdam:
         self.fp, self.lr, self.betas, self.eps = flat, lr, betas, eps
         self.m = torch.zeros_like(flat.flat)
         self.v = torch.zeros_like(flat.flat)
-        self.steps = [0] * len(flat.params)
+        self.steps = [0] * len(flat.params)          # host mirror of steps_dev (checkpoints, run grouping)
+        # step counters and bias corrections also live on the device (rick_adam_prepare_f32), so an optimiser step
+        # depends on device state only and a captured hipGraph of a whole train step can be replayed
+        self.steps_dev = torch.zeros(len(flat.params), device=flat.flat.device, dtype=torch.int32)
+        self.bc = torch.ones(8, 2, device=flat.flat.device, dtype=torch.float32)      # one row per run of equal step count
         self.mask = None            # uint8 flat: bit0 freeze, bit1 prune
+        self.last_runs = []         # [(first param, last param)] of the most recent step()
 
     def set_mask(self, mask):
-        self.mask = mask
+        if self.mask is not None and self.mask.shape == mask.shape:
+            self.mask.copy_(mask)   # in place: launches captured in a graph keep reading the same buffer
+        else:
+            self.mask = mask
+
+    def sync_steps_to_device(self):
+        self.steps_dev.copy_(torch.tensor(self.steps, dtype=torch.int32))
+
+    def note_replayed_step(self):
+        """A captured step() was replayed: the device counters advanced, mirror it on the host."""
+        for i0, i1 in self.last_runs:
+            for i in range(i0, i1 + 1):
+                self.steps[i] += 1
 
     def step(self):
         fp = self.fp
         idx = fp.opt_idx
         active = {i: fp.params[i].requires_grad for i in idx}
         k, n = 0, len(idx)
+        runs = []
         while k < n:
             i = idx[k]
             if not active[i]:
@@ -139,13 +157,19 @@ class MaskedFlatAdam:
                 kk += 1
                 self.steps[idx[kk]] += 1
             lo, hi = int(fp.offsets[i]), int(fp.offsets[idx[kk] + 1])
-            t = self.steps[i]
             b1, b2 = self.betas
             mk = None if self.mask is None else self.mask[lo:hi]
-            check(lib.rick_masked_adam_f32(ptr(fp.flat[lo:hi]), ptr(fp.grad[lo:hi]), ptr(self.m[lo:hi]),
-                                           ptr(self.v[lo:hi]), ptr(mk), hi - lo, self.lr, b1, b2, self.eps,
-                                           1.0 - b1 ** t, 1.0 - b2 ** t, stream_ptr()), 'rick_masked_adam_f32')
+            if len(runs) >= self.bc.shape[0]:
+                raise RuntimeError('MaskedFlatAdam: too many runs of distinct step counts')
+            bc = self.bc[len(runs)]
+            check(lib.rick_adam_prepare_f32(ptr(self.steps_dev), i, idx[kk] - i + 1, b1, b2, ptr(bc), stream_ptr()),
+                  'rick_adam_prepare_f32')
+            check(lib.rick_masked_adam_dev_f32(ptr(fp.flat[lo:hi]), ptr(fp.grad[lo:hi]), ptr(self.m[lo:hi]),
+                                               ptr(self.v[lo:hi]), ptr(mk), hi - lo, self.lr, b1, b2, self.eps, ptr(bc),
+                                               stream_ptr()), 'rick_masked_adam_dev_f32')
+            runs.append((i, idx[kk]))
             k = kk + 1
+        self.last_runs = runs
         op.bump_weights_epoch(fp.params)
 
 
@@ -346,6 +370,8 @@ class RickTrainer:
         self.idx_freeze_g = self.idx_freeze_d = None
         self.zero_idx_g = self.zero_idx_d = None
         self.losses = {}
+        self.use_graphs = False
+        self._gs, self._inject, self._layer_idx, self._real = {}, {}, None, None
         if dp is not None:
             dp.attach(self.g_flat, self.d_flat)
 
@@ -379,79 +405,192 @@ class RickTrainer:
         if self.dp is not None:
             self.dp.prepare(flat)          # bucket counts follow the stage's requires_grad flags
 
+    # ---- hipGraph replay of whole steps ------------------------------------------------------------------
+    # One RICK iteration is ~2 500 kernel launches issued from Python autograd; measured on MI355X the host needs
+    # longer to ENQUEUE an iteration (34.8 ms) than the GPU needs to run it, so the loop was host-bound.  With
+    # `use_graphs` every step type (D, R1, G, path length) is captured once — forward, backward, weight re-packing
+    # and the masked Adam with its device-side step counters — and replayed afterwards; per-step host randomness
+    # (style-mixing index) is written into device scalars before the replay.  With data parallelism the capture is
+    # split around the gradient all-reduce (forward/backward graph -> RCCL -> optimiser graph).
+    def enable_graphs(self, on=True):
+        self.use_graphs = bool(on)
+        if self.dp is not None:
+            self.dp.hooks_enabled = not self.use_graphs      # a replayed backward runs no Python hooks
+        if on:
+            for opt in (self.g_optim, self.d_optim):         # the mask buffer must exist before a launch is captured
+                if opt.mask is None:
+                    opt.mask = torch.zeros(opt.fp.total, dtype=torch.uint8, device=self.device)
+
+    def prepare_graphs(self, real_img):
+        """Capture all four step graphs up front (two eager warm-up calls + the capturing call of each step type), so
+        that no capture lands inside a timed region.  These are real training steps."""
+        if not self.use_graphs:
+            return
+        if self._real is None:
+            self._real = torch.empty_like(real_img)
+        self._real.copy_(real_img)
+        for _ in range(3):
+            self.d_step(self._real, None, graph=True)
+            self.r1_step(self._real, graph=True)
+            self.g_step(None, graph=True)
+            self.plr_step(None, graph=True)
+            self.ema_step()
+
+    def _draw_inject(self, key):
+        """Host side of mixing_noise + Generator.forward's random inject_index (:130-135, model_probe_tune.py:555-560):
+        with probability `mixing` two latents, switched at a uniform layer index in [1, n_latent-1]; otherwise one
+        latent for every layer (inject = n_latent).  Written to a device scalar the captured graph reads."""
+        n_latent = self.g.n_latent
+        k = random.randint(1, n_latent - 1) if (self.cfg.mixing > 0 and random.random() < self.cfg.mixing) else n_latent
+        t = self._inject.get(key)
+        if t is None:
+            t = self._inject[key] = torch.zeros((), dtype=torch.int64, device=self.device)
+            self._layer_idx = torch.arange(n_latent, device=self.device).view(1, -1, 1)
+        t.fill_(k)
+
+    def _graph_latents(self, key, batch):
+        """[batch, n_latent, 512] W-space latents with the style switch applied on the device (same values as the
+        reference's cat of repeated w1 / w2 rows)."""
+        z = torch.randn(2 * batch, self.cfg.latent, device=self.device)
+        w = self.g.style(z).view(2, batch, 1, -1)
+        return torch.where(self._layer_idx < self._inject[key], w[0], w[1])
+
+    def _run(self, key, fb, flat, optim, pre=None):
+        """fb(): forward + backward into flat.grad;  then gradient exchange and optimiser step."""
+        if pre is not None:
+            pre()
+        st = None
+        if key is not None and self.use_graphs:
+            st = self._gs.setdefault(key, {'n': 0})
+            st['n'] += 1
+        if st is None or st['n'] <= 2:                        # eager (also the warm-up of a graph: caches, allocator)
+            fb()
+            self._reduce(flat)
+            optim.step()
+            return
+        if 'graphs' not in st:
+            op.bump_weights_epoch()                           # every pack refresh the step needs lands inside its graph
+            torch.cuda.synchronize()
+            before = list(optim.steps)
+            if self.dp is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fb()
+                    optim.step()
+                st['graphs'] = (g,)
+            else:
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    fb()
+                with torch.cuda.graph(g2):
+                    optim.step()
+                st['graphs'] = (g1, g2)
+            st['runs'] = list(optim.last_runs)
+            optim.steps[:] = before                           # capture executes nothing: the replay below is this step
+        gs = st['graphs']
+        gs[0].replay()
+        if len(gs) == 2:
+            self.dp.all_reduce(flat)
+            gs[1].replay()
+        optim.last_runs = st['runs']
+        optim.note_replayed_step()
+
     # ---- steps (each returns the loss tensor; no host sync)
-    def d_step(self, real_img, noise, i=10 ** 9, g_noise=None):
+    def d_step(self, real_img, noise, i=10 ** 9, g_noise=None, graph=False):
         self._set_d_stage(i)
-        with torch.no_grad():
-            fake_img, _ = self.g(noise, noise=g_noise)
-        # one pass over cat(fake, real): identical to the reference's two calls (per-call minibatch-stddev
-        # statistics are kept), half the launches and twice the GEMM rows per launch
-        pred, _ = self.d(torch.cat([fake_img, real_img], 0), calls=2)
-        fake_pred, real_pred = pred.chunk(2, 0)
-        d_loss = d_logistic_loss(real_pred, fake_pred)
-        self._zero_grad(self.d_flat)
-        d_loss.backward()
-        self._reduce(self.d_flat)
-        self.d_optim.step()
-        self.losses.update(d=d_loss.detach(), real_score=real_pred.detach().mean(), fake_score=fake_pred.detach().mean())
-        return d_loss
+        key = 'd' if graph else None
+        batch = real_img.shape[0]
 
-    def r1_step(self, real_img, i=10 ** 9):
-        cfg = self.cfg
-        self._set_d_stage(i)
-        real_img = real_img.detach().requires_grad_(True)
-        with op.second_order():
-            real_pred, _ = self.d(real_img)
-            real_pred = real_pred.view(real_img.size(0), -1).mean(dim=1).unsqueeze(1)
-            r1_loss = d_r1_loss(real_pred, real_img)
+        def fb():
+            with torch.no_grad():
+                if graph:
+                    fake_img, _ = self.g([self._graph_latents(key, batch)], input_is_latent=True, noise=g_noise)
+                else:
+                    fake_img, _ = self.g(noise, noise=g_noise)
+            # one pass over cat(fake, real): identical to the reference's two calls (per-call minibatch-stddev
+            # statistics are kept), half the launches and twice the GEMM rows per launch
+            pred, _ = self.d(torch.cat([fake_img, real_img], 0), calls=2)
+            fake_pred, real_pred = pred.chunk(2, 0)
+            d_loss = d_logistic_loss(real_pred, fake_pred)
             self._zero_grad(self.d_flat)
-            (cfg.r1 / 2 * r1_loss * cfg.d_reg_every + 0 * real_pred[0]).backward()
-        self._reduce(self.d_flat)
-        self.d_optim.step()
-        self.losses['r1'] = r1_loss.detach()
-        return r1_loss
+            d_loss.backward()
+            self.losses.update(d=d_loss.detach(), real_score=real_pred.detach().mean(), fake_score=fake_pred.detach().mean())
+        self._run(key, fb, self.d_flat, self.d_optim, pre=(lambda: self._draw_inject(key)) if graph else None)
+        return self.losses['d']
 
-    def g_step(self, noise, g_noise=None):
-        fake_img, _ = self.g(noise, noise=g_noise)
-        with self._d_frozen():
-            fake_pred, _ = self.d(fake_img)
-            g_loss = g_nonsaturating_loss(fake_pred)
-            self._zero_grad(self.g_flat)
-            g_loss.backward()
-        self._reduce(self.g_flat)
-        self.g_optim.step()
-        self.losses['g'] = g_loss.detach()
-        return g_loss
-
-    def plr_step(self, noise, pl_noise=None, g_noise=None):
+    def r1_step(self, real_img, i=10 ** 9, graph=False):
         cfg = self.cfg
+        self._set_d_stage(i)
+
+        def fb():
+            real = real_img.detach().requires_grad_(True)
+            with op.second_order():
+                real_pred, _ = self.d(real)
+                real_pred = real_pred.view(real.size(0), -1).mean(dim=1).unsqueeze(1)
+                r1_loss = d_r1_loss(real_pred, real)
+                self._zero_grad(self.d_flat)
+                (cfg.r1 / 2 * r1_loss * cfg.d_reg_every + 0 * real_pred[0]).backward()
+            self.losses['r1'] = r1_loss.detach()
+        self._run('r1' if graph else None, fb, self.d_flat, self.d_optim)
+        return self.losses['r1']
+
+    def g_step(self, noise, g_noise=None, graph=False):
+        key = 'g' if graph else None
+        batch = self.cfg.batch
+
+        def fb():
+            if graph:
+                fake_img, _ = self.g([self._graph_latents(key, batch)], input_is_latent=True, noise=g_noise)
+            else:
+                fake_img, _ = self.g(noise, noise=g_noise)
+            with self._d_frozen():
+                fake_pred, _ = self.d(fake_img)
+                g_loss = g_nonsaturating_loss(fake_pred)
+                self._zero_grad(self.g_flat)
+                g_loss.backward()
+            self.losses['g'] = g_loss.detach()
+        self._run(key, fb, self.g_flat, self.g_optim, pre=(lambda: self._draw_inject(key)) if graph else None)
+        return self.losses['g']
+
+    def plr_step(self, noise, pl_noise=None, g_noise=None, graph=False):
         # the path-length gradient is taken w.r.t. the latents, which only carry a graph if the mapping
         # network's parameters require grad (in the reference every parameter does)
         style_params = list(self.g.style.parameters())
         for p in style_params:
             p.requires_grad = True
         try:
-            return self._plr_step(noise, pl_noise, g_noise)
+            return self._plr_step(noise, pl_noise, g_noise, graph)
         finally:
             for p in style_params:
                 p.requires_grad = False
-                p.grad = None
+                if not graph:
+                    p.grad = None
 
-    def _plr_step(self, noise, pl_noise, g_noise):
+    def _plr_step(self, noise, pl_noise, g_noise, graph):
         cfg = self.cfg
-        with op.second_order():
-            fake_img, latents = self.g(noise, return_latents=True, noise=g_noise)
-            path_loss, self.mean_path_length, path_lengths = g_path_regularize(
-                fake_img, latents, self.mean_path_length, noise=pl_noise)
-            self._zero_grad(self.g_flat)
-            weighted = cfg.path_regularize * cfg.g_reg_every * path_loss
-            if cfg.path_batch_shrink:
-                weighted = weighted + 0 * fake_img[0, 0, 0, 0]
-            weighted.backward()
-        self._reduce(self.g_flat)
-        self.g_optim.step()
-        self.losses.update(path=path_loss.detach(), path_length=path_lengths.detach().mean())
-        return path_loss
+        key = 'plr' if graph else None
+        batch = max(1, cfg.batch // cfg.path_batch_shrink)
+        if not torch.is_tensor(self.mean_path_length):      # persistent device scalar, updated in place (graph-safe)
+            self.mean_path_length = torch.full((), float(self.mean_path_length), device=self.device)
+
+        def fb():
+            with op.second_order():
+                if graph:
+                    fake_img, latents = self.g([self._graph_latents(key, batch)], input_is_latent=True,
+                                               return_latents=True, noise=g_noise)
+                else:
+                    fake_img, latents = self.g(noise, return_latents=True, noise=g_noise)
+                path_loss, new_mean, path_lengths = g_path_regularize(fake_img, latents, self.mean_path_length,
+                                                                      noise=pl_noise)
+                self._zero_grad(self.g_flat)
+                weighted = cfg.path_regularize * cfg.g_reg_every * path_loss
+                if cfg.path_batch_shrink:
+                    weighted = weighted + 0 * fake_img[0, 0, 0, 0]
+                weighted.backward()
+            self.mean_path_length.copy_(new_mean)
+            self.losses.update(path=path_loss.detach(), path_length=path_lengths.detach().mean())
+        self._run(key, fb, self.g_flat, self.g_optim, pre=(lambda: self._draw_inject(key)) if graph else None)
+        return self.losses['path']
 
     def ema_step(self):
         """accumulate(g_ema, g), accumulate(d_ema, d) (:697-698) over ALL named parameters."""
@@ -499,12 +638,18 @@ class RickTrainer:
         cfg = self.cfg
         if fisher_inputs is not None and i - cfg.warmup_iter >= 0 and (i - cfg.warmup_iter) % cfg.fisher_freq == 0:
             self.fisher_sweep(*fisher_inputs, first=(i == cfg.warmup_iter))
-        self.d_step(real_img, mixing_noise(cfg.batch, cfg.latent, cfg.mixing, self.device), i)
+        graph = self.use_graphs and i >= cfg.warmup_iter      # the warm-up stage has its own requires_grad pattern
+        if graph:
+            if self._real is None:
+                self._real = torch.empty_like(real_img)
+            self._real.copy_(real_img)                        # captured launches read this buffer
+            real_img = self._real
+        nz = (lambda b: None) if graph else (lambda b: mixing_noise(b, cfg.latent, cfg.mixing, self.device))
+        self.d_step(real_img, nz(cfg.batch), i, graph=graph)
         if i % cfg.d_reg_every == 0:
-            self.r1_step(real_img, i)
+            self.r1_step(real_img, i, graph=graph)
         if i >= cfg.warmup_iter:
-            self.g_step(mixing_noise(cfg.batch, cfg.latent, cfg.mixing, self.device))
+            self.g_step(nz(cfg.batch), graph=graph)
             if i % cfg.g_reg_every == 0:
-                pb = max(1, cfg.batch // cfg.path_batch_shrink)
-                self.plr_step(mixing_noise(pb, cfg.latent, cfg.mixing, self.device))
+                self.plr_step(nz(max(1, cfg.batch // cfg.path_batch_shrink)), graph=graph)
         self.ema_step()

@@ -339,3 +339,47 @@ def test_eval_sampling_loop_matches_oracle():
     assert imgs.shape == (7, 3, size, size) and feats.shape == (7,)
     assert rel(imgs, ref) < 1e-4
     assert rel(feats, ref.mean(dim=(1, 2, 3))) < 1e-4
+
+
+def test_graph_replay_matches_eager_steps():
+    """RickTrainer.enable_graphs: captured + replayed D / R1 / G / path-length steps (forward, backward, re-packing,
+    masked Adam with device-side step counters) leave exactly the state the eagerly issued steps leave."""
+    from rick_amd.train import RickTrainer, TrainConfig, build_mask
+    size, B = 32, 2
+    real = [synth_reals(B, size=size, seed=70 + k).to(DEV) for k in range(6)]
+    lat = {k: synth_tensor(f'graph/lat/{k}', (B if k != 'plr' else 1, 8, 512)).to(DEV) for k in ('d', 'g', 'plr')}
+    lat['plr'].requires_grad_(True)                            # the path-length gradient is taken w.r.t. the latents
+    pl_noise = synth_tensor('graph/pl', (1, 3, size, size)).to(DEV)
+
+    def run(use_graphs):
+        g, d = build(size)
+        tr = RickTrainer(TrainConfig(size=size, batch=B, warmup_iter=0), g, d, *build(size))
+        noises = [getattr(g.noises, f'noise_{i}') for i in range(g.num_layers)]
+        tr.d_optim.set_mask(build_mask(tr.d_flat, {'convs.1.conv1.0.weight': np.array([1, 5])},
+                                       {'convs.2.skip.1.weight': np.array([0, 3])}))
+        tr.enable_graphs(use_graphs)
+        tr._draw_inject('d')                                   # creates the device scalars the graphs read
+        tr._graph_latents = lambda key, batch: lat[key]       # fixed latents: no RNG in the comparison
+        static_real = torch.empty_like(real[0])
+        for k in range(6):
+            static_real.copy_(real[k])
+            tr.d_step(static_real, None, g_noise=noises, graph=True)
+            tr.r1_step(static_real, graph=True)
+            tr.g_step(None, g_noise=noises, graph=True)
+            tr.plr_step(None, pl_noise=pl_noise, g_noise=noises, graph=True)
+            tr.ema_step()
+        torch.cuda.synchronize()
+        if use_graphs:
+            assert set(tr._gs) == {'d', 'r1', 'g', 'plr'} and all('graphs' in v for v in tr._gs.values())
+        for opt in (tr.g_optim, tr.d_optim):
+            assert opt.steps_dev.cpu().tolist() == opt.steps
+        return tr
+    a, b = run(False), run(True)
+    for fa, fb in ((a.g_flat, b.g_flat), (a.d_flat, b.d_flat), (a.g_ema_flat, b.g_ema_flat)):
+        assert torch.equal(fa.flat, fb.flat)
+    assert torch.equal(a.d_optim.v, b.d_optim.v) and torch.equal(a.g_optim.m, b.g_optim.m)
+    assert a.d_optim.steps == b.d_optim.steps and max(a.d_optim.steps) == 12
+    assert torch.equal(a.mean_path_length, b.mean_path_length)
+    for k in ('d', 'g', 'r1', 'path'):
+        assert torch.equal(a.losses[k], b.losses[k])
+    assert float(dict(b.d.named_parameters())['convs.2.skip.1.weight'][[0, 3]].abs().max()) == 0.0
