@@ -728,23 +728,56 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_multi_kernel(const float *_
 }
 
 // out[n, pix(gy,gx), co] = alpha * oscale[n,co] * sum_s ws[s][n,gy,gx][co]
+// VEC4 (Co % 4 == 0): one float4 of 4 consecutive channels per thread and split, 32-bit index math (the guard in
+// check_geom keeps N*OH*OW*Co below 2^31).
+template <bool VEC4>
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
                                                                   const float *__restrict__ oscale, rick_conv_geom g,
                                                                   int nsplit) {
-    const int64_t per = (int64_t)g.N * g.GH * g.GW * g.Co;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
-        const int co = (int)(i % g.Co);
-        int64_t pos = i / g.Co;
-        const int gx = (int)(pos % g.GW);
+    constexpr int W = VEC4 ? 4 : 1;
+    const unsigned per = (unsigned)g.N * g.GH * g.GW * g.Co;
+    const unsigned cow = (unsigned)g.Co / W;
+    for (unsigned iw = blockIdx.x * 256 + threadIdx.x; iw < per / W; iw += gridDim.x * 256) {
+        const unsigned cq = iw % cow;
+        unsigned pos = iw / cow;
+        const unsigned gx = pos % g.GW;
         pos /= g.GW;
-        const int gy = (int)(pos % g.GH);
-        const int n = (int)(pos / g.GH);
-        float s = 0.f;
-        for (int sp = 0; sp < nsplit; sp++) s += ws[sp * per + i];
-        s *= g.alpha;
-        if (oscale) s *= oscale[(int64_t)n * g.Co + co];
-        out[(((int64_t)n * g.OH + gy * g.os + g.oy0) * g.OW + gx * g.os + g.ox0) * g.Co + co] = s;
+        const unsigned gy = pos % g.GH;
+        const unsigned n = pos / g.GH;
+        const unsigned co = cq * W;
+        const int64_t o = (((int64_t)n * g.OH + gy * g.os + g.oy0) * g.OW + gx * g.os + g.ox0) * g.Co + co;
+        if (VEC4) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 *src = reinterpret_cast<const float4 *>(ws) + iw;
+            for (int sp = 0; sp < nsplit; sp++) {
+                const float4 v = src[(size_t)sp * (per / 4)];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            float4 sc = make_float4(g.alpha, g.alpha, g.alpha, g.alpha);
+            if (oscale) {
+                const float4 os4 = *reinterpret_cast<const float4 *>(oscale + (size_t)n * g.Co + co);
+                sc = make_float4(os4.x, os4.y, os4.z, os4.w);
+                s.x *= g.alpha; s.y *= g.alpha; s.z *= g.alpha; s.w *= g.alpha;
+            }
+            *reinterpret_cast<float4 *>(out + o) = make_float4(s.x * sc.x, s.y * sc.y, s.z * sc.z, s.w * sc.w);
+        } else {
+            float s = 0.f;
+            for (int sp = 0; sp < nsplit; sp++) s += ws[(size_t)sp * per + iw];
+            s *= g.alpha;
+            if (oscale) s *= oscale[(size_t)n * g.Co + co];
+            out[o] = s;
+        }
     }
+}
+
+static void launch_splitk_reduce(const float *ws, float *out, const float *oscale, const rick_conv_geom *g, int nsplit,
+                                 hipStream_t st) {
+    const int64_t per = (int64_t)g->N * g->GH * g->GW * g->Co;
+    const bool vec = (g->Co & 3) == 0 && (((uintptr_t)ws | (uintptr_t)out | (uintptr_t)(oscale ? oscale : out)) % 16) == 0;
+    int64_t nb = cdiv64(vec ? per / 4 : per, 256);
+    if (nb > 8192) nb = 8192;
+    if (vec) hipLaunchKernelGGL(igemm_splitk_reduce_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, nsplit);
+    else hipLaunchKernelGGL(igemm_splitk_reduce_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, nsplit);
 }
 
 static int check_geom(const rick_conv_geom *g) {
@@ -818,12 +851,7 @@ extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *
         if (vec) launch_igemm<1, true>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
         else launch_igemm<1, false>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
     }
-    if (t.nsplit > 1) {
-        const int64_t per = (int64_t)g->N * g->GH * g->GW * g->Co;
-        int64_t nb = cdiv64(per, 256);
-        if (nb > 4096) nb = 4096;
-        hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, t.nsplit);
-    }
+    if (t.nsplit > 1) launch_splitk_reduce(ws, out, oscale, g, t.nsplit, st);
     RICK_LAUNCH_STATUS();
 }
 
@@ -907,13 +935,7 @@ extern "C" int rick_conv_igemm_multi_f32(const float *x, const void *packed_w, f
         else launch_igemm_multi<1, false>(lds, st, x, wp, out, iscale, oscale, ws, m);
     }
     for (int c = 0; c < ngeom; c++)
-        if (m.t[c].nsplit > 1) {
-            const int64_t per = (int64_t)geoms[c].N * geoms[c].GH * geoms[c].GW * geoms[c].Co;
-            int64_t nb = cdiv64(per, 256);
-            if (nb > 4096) nb = 4096;
-            hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, ws + m.ws_off[c], out, oscale,
-                               geoms[c], m.t[c].nsplit);
-        }
+        if (m.t[c].nsplit > 1) launch_splitk_reduce(ws + m.ws_off[c], out, oscale, &geoms[c], m.t[c].nsplit, st);
     RICK_LAUNCH_STATUS();
 }
 
