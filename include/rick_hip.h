@@ -194,6 +194,17 @@ int rick_sq_accumulate_f32(float *acc, const float *g, int64_t n, void *stream);
 int rick_filter_reduce_f32(const float *x, float *out, int64_t outer, int64_t outer_stride,
                            int64_t nfilters, int64_t filter_stride, int64_t inner,
                            float scale, void *stream);
+/* Style demodulation of the modulated convolution (model_probe_tune.py:246-252; w is [O, I, K] contiguous):
+ *   rick_wsq_f32          wsq[o,i] = scale^2 * sum_k w[o,i,k]^2
+ *   rick_demod_f32        d[b,o]   = rsqrt(sum_i s[b,i]^2 wsq[o,i] + eps)                      (B <= 32)
+ *   rick_demod_bwd_s_f32  gs[b,i]  = 2 s[b,i] sum_o t[b,o] wsq[o,i],   t = -0.5 d^3 gd
+ *   rick_demod_bwd_w_f32  gw[o,i,k] = 2 scale^2 w[o,i,k] sum_b t[b,o] s[b,i]^2 */
+int rick_wsq_f32(const float *w, float *wsq, int O, int I, int K, float scale, void *stream);
+int rick_demod_f32(const float *s, const float *wsq, float *d, int B, int I, int O, float eps, void *stream);
+int rick_demod_bwd_s_f32(const float *s, const float *wsq, const float *d, const float *gd, float *gs, int B, int I, int O,
+                         void *stream);
+int rick_demod_bwd_w_f32(const float *w, const float *s, const float *d, const float *gd, float *gw, int B, int I, int O,
+                         int K, float scale, void *stream);
 /* Masked Adam over a flat parameter buffer (mask bits: 1 = freeze (grad := 0),
  * 2 = prune (param := 0, grad := 0); mask may be NULL), torch.optim.Adam semantics
  * (no weight decay, no amsgrad), bias corrections passed in. */

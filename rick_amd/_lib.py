@@ -63,6 +63,10 @@ SIGNATURES = {
     'rick_sq_accumulate_f32': (c_int, [c_fp, c_fp, c_i64, c_fp]),
     'rick_filter_reduce_f32': (c_int, [c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_fp]),
     'rick_masked_adam_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f, c_f, c_f, c_f, c_f, c_f, c_fp]),
+    'rick_wsq_f32': (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_f, c_fp]),
+    'rick_demod_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_f, c_fp]),
+    'rick_demod_bwd_s_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
+    'rick_demod_bwd_w_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_f, c_fp]),
     'rick_adam_prepare_f32': (c_int, [c_fp, c_int, c_int, c_f, c_f, c_fp, c_fp]),
     'rick_masked_adam_dev_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f, c_f, c_f, c_f, c_fp, c_fp]),
     'rick_ema_f32': (c_int, [c_fp, c_fp, c_i64, c_f, c_fp]),

@@ -145,7 +145,9 @@ class ModulatedConv2d(nn.Module):
         if self.kernel_size == 1 and self.out_channel <= 4 and not self.demodulate:
             Wn = (self.scale * w.view(1, self.out_channel, self.in_channel)) * s.unsqueeze(1)   # [B, 3, Ci]
             return op.thin_fwd(x, Wn)                                # planar [B, 3, H, W]
-        d = _mc.demod_coeff(w, s, self.scale, self.eps) if self.demodulate else None
+        d = None
+        if self.demodulate:     # composed tensor algebra when a second derivative is needed, 2 + 2 launches otherwise
+            d = (_mc.demod_coeff if op.second_order_enabled() else _mc.demod_coeff_fused)(w, s, self.scale, self.eps)
         key = (self.weight, 'mod')
         if op.second_order_enabled():
             y = _mc.modulated_conv_composed(x, w, s, None, self.scale, self.upsample, key)

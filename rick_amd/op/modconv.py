@@ -18,6 +18,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
+from .._lib import check, lib, ptr, require_cuda_f32, stream_ptr
 from .conv import _conv_launch, _convT_launch, _pack, _wgrad_launch, conv2d, conv_transpose2d
 from .misc import _chan_scale_raw, _hw_dot_raw, chan_scale
 
@@ -36,6 +37,52 @@ def modulated_conv_composed(x, w, s, d, wscale, upsample, key=None):
     else:
         y = conv2d(xs, w, stride=1, padding=w.shape[2] // 2, wscale=wscale, key=key)
     return chan_scale(y, d) if d is not None else y
+
+
+class _DemodFused(Function):
+    """demod_coeff as two launches forward (wsq, d) and two backward (gs; gw), first order only — the tensor-algebra
+    form above costs ~8 launches forward and ~16 backward per layer, which is what this latency-bound corner of
+    the network is made of.  Under op.second_order() the composed form is used instead."""
+
+    @staticmethod
+    def forward(ctx, w, s, wscale, eps):
+        O, I, kh, kw = w.shape
+        w = w.contiguous()
+        s = s.contiguous()
+        B = s.shape[0]
+        wsq = torch.empty((O, I), device=w.device, dtype=w.dtype)
+        d = torch.empty((B, O), device=w.device, dtype=w.dtype)
+        check(lib.rick_wsq_f32(ptr(w), ptr(wsq), O, I, kh * kw, float(wscale), stream_ptr()), 'rick_wsq_f32')
+        check(lib.rick_demod_f32(ptr(s), ptr(wsq), ptr(d), B, I, O, float(eps), stream_ptr()), 'rick_demod_f32')
+        ctx.save_for_backward(w, s, wsq, d)
+        ctx.wscale = float(wscale)
+        return d
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gd):
+        w, s, wsq, d = ctx.saved_tensors
+        O, I, kh, kw = w.shape
+        B = s.shape[0]
+        gd = gd.contiguous()
+        gw = gs = None
+        if ctx.needs_input_grad[1]:
+            gs = torch.empty_like(s)
+            check(lib.rick_demod_bwd_s_f32(ptr(s), ptr(wsq), ptr(d), ptr(gd), ptr(gs), B, I, O, stream_ptr()),
+                  'rick_demod_bwd_s_f32')
+        if ctx.needs_input_grad[0]:
+            gw = torch.empty_like(w)
+            check(lib.rick_demod_bwd_w_f32(ptr(w), ptr(s), ptr(d), ptr(gd), ptr(gw), B, I, O, kh * kw, ctx.wscale,
+                                           stream_ptr()), 'rick_demod_bwd_w_f32')
+        return gw, gs, None, None
+
+
+def demod_coeff_fused(w, s, wscale, eps=1e-8):
+    """Same values as demod_coeff; first-order differentiable; needs B <= 32 (falls back to the composed form)."""
+    require_cuda_f32(w, s)
+    if s.shape[0] > 32:
+        return demod_coeff(w, s, wscale, eps)
+    return _DemodFused.apply(w, s, wscale, eps)
 
 
 class _ModConvFused(Function):

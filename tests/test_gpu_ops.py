@@ -352,3 +352,28 @@ def test_fisher_and_optimizer_kernels():
     ed = e.to(DEV)
     _lib.check(lib.rick_ema_f32(ptr(ed), ptr(pd), n, 0.997784, sp()), 'ema')
     assert rel_err(ed, e.double() * 0.997784 + pd.double().cpu() * (1 - 0.997784)) < 1e-6
+
+
+@pytest.mark.parametrize('B,O,I,k', [(4, 512, 512, 3), (3, 24, 16, 3), (1, 128, 256, 3), (8, 64, 36, 1), (32, 8, 8, 3)])
+def test_demod_fused_matches_composed(B, O, I, k):
+    """rick_wsq / rick_demod / rick_demod_bwd_*: values and first-order gradients of the fused demodulation equal the
+    tensor-algebra form (model_probe_tune.py:246-252) evaluated in fp64."""
+    from rick_amd.op.modconv import demod_coeff, demod_coeff_fused
+    gen = torch.Generator().manual_seed(B * 1000 + O + I)
+    w = torch.randn(O, I, k, k, generator=gen)
+    s = torch.randn(B, I, generator=gen) * 0.7 + 1.0
+    gd = torch.randn(B, O, generator=gen)
+    scale = 1.0 / (I * k * k) ** 0.5
+    w64, s64 = w.double().requires_grad_(True), s.double().requires_grad_(True)
+    d_ref = demod_coeff(w64, s64, scale)
+    gw_ref, gs_ref = torch.autograd.grad(d_ref, [w64, s64], gd.double())
+    wd, sd = w.to(DEV).requires_grad_(True), s.to(DEV).requires_grad_(True)
+    d = demod_coeff_fused(wd, sd, scale)
+    gw, gs = torch.autograd.grad(d, [wd, sd], gd.to(DEV))
+    assert rel_err(d, d_ref.detach()) < 2e-6
+    assert rel_err(gs, gs_ref) < 5e-6
+    assert rel_err(gw, gw_ref) < 5e-6
+    # only one of the two gradients requested
+    d2 = demod_coeff_fused(wd.detach(), sd, scale)
+    (gs2,) = torch.autograd.grad(d2, [sd], gd.to(DEV))
+    assert torch.equal(gs2, gs)
