@@ -128,9 +128,25 @@ int rick_conv_pack_weights_multi(const rick_pack_desc *descs_device, int n, int 
  * (rick_conv_igemm_workspace_bytes bytes, 0 = not needed, may then be NULL) and a deterministic
  * second-stage kernel applies alpha / oscale. */
 int64_t rick_conv_igemm_workspace_bytes(const rick_conv_geom *g);
+/* Optional tail fused into the convolution's epilogue — replaces a separate rick_bias_act_f32 pass (one read and
+ * one write of the whole activation) after EqualConv2d + FusedLeakyReLU (model_probe_tune.py:595-641) and after the
+ * non-upsampling StyledConv (conv -> NoiseInjection -> FusedLeakyReLU, :314-348):
+ *   out = gain * lrelu_slope(conv + bias[co] + noise_w[0] * noise[n % noise_nb][oy][ox])
+ * in exactly that operation order (bit-identical to the two-pass form).  Needs Co % 4 == 0. */
+typedef struct {
+    const float *bias;      /* [Co] or NULL */
+    const float *noise;     /* [noise_nb][OH*OW] or NULL */
+    const float *noise_w;   /* device scalar, required with noise */
+    int noise_nb;           /* 1 (shared map) or N */
+    int act;                /* 0: none, 1: LeakyReLU(slope) * gain */
+    float slope, gain;
+} rick_conv_epilogue;
 int rick_conv_igemm_f32(const float *x, const void *packed_w, float *out,
                         const float *iscale, const float *oscale,
                         const rick_conv_geom *g, void *workspace, void *stream);
+/* rick_conv_igemm_f32 with the fused tail (epilogue may be NULL). */
+int rick_conv_igemm_act_f32(const float *x, const void *packed_w, float *out, const float *iscale, const float *oscale,
+                            const rick_conv_geom *g, const rick_conv_epilogue *epilogue, void *workspace, void *stream);
 
 /* Several geometries over the same tensors and weights (the 4 output-parity classes of a stride-2
  * transposed convolution) in one launch.  ngeom <= 4; all share Ci, Co, split. */

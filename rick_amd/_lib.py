@@ -30,6 +30,12 @@ class ConvGeom(ctypes.Structure):
                 ('split', c_int), ('alpha', c_f)]
 
 
+class ConvEpilogue(ctypes.Structure):
+    """rick_conv_epilogue (include/rick_hip.h)."""
+    _fields_ = [('bias', c_fp), ('noise', c_fp), ('noise_w', c_fp), ('noise_nb', c_int), ('act', c_int),
+                ('slope', c_f), ('gain', c_f)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/rick_hip.h
 SIGNATURES = {
     'rick_abi_version': (c_int, []),
@@ -45,6 +51,8 @@ SIGNATURES = {
     'rick_conv_pack_weights_multi': (c_int, [c_fp, c_int, c_int, c_int, c_fp]),
     'rick_conv_igemm_workspace_bytes': (c_i64, [ctypes.POINTER(ConvGeom)]),
     'rick_conv_igemm_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(ConvGeom), c_fp, c_fp]),
+    'rick_conv_igemm_act_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(ConvGeom),
+                                        ctypes.POINTER(ConvEpilogue), c_fp, c_fp]),
     'rick_conv_igemm_multi_workspace_bytes': (c_i64, [ctypes.POINTER(ConvGeom), c_int]),
     'rick_conv_igemm_multi_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(ConvGeom), c_int, c_fp, c_fp]),
     'rick_conv_wgrad_workspace_bytes': (c_i64, [ctypes.POINTER(ConvGeom)]),

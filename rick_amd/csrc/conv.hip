@@ -296,7 +296,8 @@ template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT>
 __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const unsigned char *__restrict__ wpk,
                                            float *__restrict__ out, const float *__restrict__ iscale,
                                            const float *__restrict__ oscale, float *__restrict__ ws,
-                                           const rick_conv_geom &g, const ConvTiling &t, const int bid, const int nwg) {
+                                           const rick_conv_geom &g, const ConvTiling &t, const int bid, const int nwg,
+                                           const rick_conv_epilogue &epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *wbuf = smem;                               // [2][16 KB]
     unsigned char *ph = smem + 2 * CV_WSTEP_BYTES;            // [NPP + 1][64 B]
@@ -615,8 +616,10 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     // ---- epilogue.  Instantiated twice (with / without output scales) so the scale loads of a j-column
     // are unconditional in their variant: hipcc otherwise sinks each into its own branch + vmcnt(0).
     const bool covec = (g.Co & 3) == 0;
-    auto epilogue = [&](auto HAS_OS) {
+    const float nwv = epi.noise ? epi.noise_w[0] : 0.f;
+    auto epilogue = [&](auto HAS_OS, auto HAS_EP) {
         constexpr bool OS = decltype(HAS_OS)::value;
+        constexpr bool EP = decltype(HAS_EP)::value;   // fused bias (+ noise) + LeakyReLU tail (rick_conv_epilogue)
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const int pos = wn * (NJ * 16) + j * 16 + l15;
@@ -654,12 +657,31 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                         sc[i] = make_float4(o.x * g.alpha, o.y * g.alpha, o.z * g.alpha, o.w * g.alpha);
                     }
                 }
+                float nv = 0.f;
+                if (EP && epi.noise)
+                    nv = nwv * epi.noise[(int64_t)(epi.noise_nb == 1 ? 0 : n) * g.OH * g.OW +
+                                         (int64_t)(gy * g.os + g.oy0) * g.OW + gx * g.os + g.ox0];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int co = cot * CV_BM + wm * 64 + i * 16 + kg * 4;
-                    if (co < g.Co)
-                        *reinterpret_cast<float4 *>(orow + co) = make_float4(
-                            acc[i][j][0] * sc[i].x, acc[i][j][1] * sc[i].y, acc[i][j][2] * sc[i].z, acc[i][j][3] * sc[i].w);
+                    if (co < g.Co) {
+                        float4 v = make_float4(acc[i][j][0] * sc[i].x, acc[i][j][1] * sc[i].y, acc[i][j][2] * sc[i].z,
+                                               acc[i][j][3] * sc[i].w);
+                        if (EP) {   // same operation order as rick_bias_act_f32: + bias, + noise, LeakyReLU, gain
+                            if (epi.bias) {
+                                const float4 bv = *reinterpret_cast<const float4 *>(epi.bias + co);
+                                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                            }
+                            v.x += nv; v.y += nv; v.z += nv; v.w += nv;
+                            if (epi.act) {
+                                v.x = (v.x > 0.f ? v.x : v.x * epi.slope) * epi.gain;
+                                v.y = (v.y > 0.f ? v.y : v.y * epi.slope) * epi.gain;
+                                v.z = (v.z > 0.f ? v.z : v.z * epi.slope) * epi.gain;
+                                v.w = (v.w > 0.f ? v.w : v.w * epi.slope) * epi.gain;
+                            }
+                        }
+                        *reinterpret_cast<float4 *>(orow + co) = v;
+                    }
                 }
                 continue;
             }
@@ -682,8 +704,11 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             }
         }
     };
-    if (oscale) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
+    const bool has_ep = epi.bias || epi.noise || epi.act;   // (host: only with Co % 4 == 0)
+    if (oscale && has_ep) epilogue(std::true_type{}, std::true_type{});
+    else if (oscale) epilogue(std::true_type{}, std::false_type{});
+    else if (has_ep) epilogue(std::false_type{}, std::true_type{});
+    else epilogue(std::false_type{}, std::false_type{});
 }
 
 template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT>
@@ -691,8 +716,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restr
                                                             const unsigned char *__restrict__ wpk,
                                                             float *__restrict__ out, const float *__restrict__ iscale,
                                                             const float *__restrict__ oscale, float *__restrict__ ws,
-                                                            const rick_conv_geom g, const ConvTiling t) {
-    igemm_body<SPLIT, VEC, DEEP, NJ, NT>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x);
+                                                            const rick_conv_geom g, const ConvTiling t,
+                                                            const rick_conv_epilogue epi) {
+    igemm_body<SPLIT, VEC, DEEP, NJ, NT>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x, epi);
 }
 
 // Several geometries (the output-parity classes of a transposed convolution) in ONE launch: block ranges
@@ -723,8 +749,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_multi_kernel(const float *_
         }
     // every parity class of a transposed conv has a patch of <= 160 pixels (tile + at most one halo row/col)
     // (the host only uses this kernel when every class qualifies for the two-ahead prefetch)
+    const rick_conv_epilogue none = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f};
     igemm_body<SPLIT, VEC, true, 4, 0>(x, wpk, out, iscale, oscale, ws + m.ws_off[c], m.g[c], m.t[c], (int)blockIdx.x - start,
-                                 m.blk_end[c] - start);
+                                       m.blk_end[c] - start, none);
 }
 
 // out[n, pix(gy,gx), co] = alpha * oscale[n,co] * sum_s ws[s][n,gy,gx][co]
@@ -733,8 +760,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_multi_kernel(const float *_
 template <bool VEC4>
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
                                                                   const float *__restrict__ oscale, rick_conv_geom g,
-                                                                  int nsplit) {
+                                                                  int nsplit, rick_conv_epilogue epi) {
     constexpr int W = VEC4 ? 4 : 1;
+    const float nwv = epi.noise ? epi.noise_w[0] : 0.f;
     const unsigned per = (unsigned)g.N * g.GH * g.GW * g.Co;
     const unsigned cow = (unsigned)g.Co / W;
     for (unsigned iw = blockIdx.x * 256 + threadIdx.x; iw < per / W; iw += gridDim.x * 256) {
@@ -759,7 +787,23 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float *_
                 sc = make_float4(os4.x, os4.y, os4.z, os4.w);
                 s.x *= g.alpha; s.y *= g.alpha; s.z *= g.alpha; s.w *= g.alpha;
             }
-            *reinterpret_cast<float4 *>(out + o) = make_float4(s.x * sc.x, s.y * sc.y, s.z * sc.z, s.w * sc.w);
+            float4 v = make_float4(s.x * sc.x, s.y * sc.y, s.z * sc.z, s.w * sc.w);
+            if (epi.bias) {
+                const float4 bv = *reinterpret_cast<const float4 *>(epi.bias + co);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            if (epi.noise) {
+                const float nv = nwv * epi.noise[(size_t)(epi.noise_nb == 1 ? 0 : n) * g.OH * g.OW +
+                                                 (size_t)(gy * g.os + g.oy0) * g.OW + gx * g.os + g.ox0];
+                v.x += nv; v.y += nv; v.z += nv; v.w += nv;
+            }
+            if (epi.act) {
+                v.x = (v.x > 0.f ? v.x : v.x * epi.slope) * epi.gain;
+                v.y = (v.y > 0.f ? v.y : v.y * epi.slope) * epi.gain;
+                v.z = (v.z > 0.f ? v.z : v.z * epi.slope) * epi.gain;
+                v.w = (v.w > 0.f ? v.w : v.w * epi.slope) * epi.gain;
+            }
+            *reinterpret_cast<float4 *>(out + o) = v;
         } else {
             float s = 0.f;
             for (int sp = 0; sp < nsplit; sp++) s += ws[(size_t)sp * per + iw];
@@ -770,14 +814,16 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float *_
     }
 }
 
+static const rick_conv_epilogue kNoEpilogue = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f};
+
 static void launch_splitk_reduce(const float *ws, float *out, const float *oscale, const rick_conv_geom *g, int nsplit,
-                                 hipStream_t st) {
+                                 hipStream_t st, const rick_conv_epilogue &epi = kNoEpilogue) {
     const int64_t per = (int64_t)g->N * g->GH * g->GW * g->Co;
     const bool vec = (g->Co & 3) == 0 && (((uintptr_t)ws | (uintptr_t)out | (uintptr_t)(oscale ? oscale : out)) % 16) == 0;
     int64_t nb = cdiv64(vec ? per / 4 : per, 256);
     if (nb > 8192) nb = 8192;
-    if (vec) hipLaunchKernelGGL(igemm_splitk_reduce_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, nsplit);
-    else hipLaunchKernelGGL(igemm_splitk_reduce_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, nsplit);
+    if (vec) hipLaunchKernelGGL(igemm_splitk_reduce_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, nsplit, epi);
+    else hipLaunchKernelGGL(igemm_splitk_reduce_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, nsplit, kNoEpilogue);
 }
 
 static int check_geom(const rick_conv_geom *g) {
@@ -805,31 +851,48 @@ extern "C" int64_t rick_conv_igemm_workspace_bytes(const rick_conv_geom *g) {
 template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT = 0>
 static void launch_igemm_k(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
                            const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
-                           const ConvTiling &t) {
+                           const ConvTiling &t, const rick_conv_epilogue &epi) {
     (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT>), dim3(nwg), dim3(256), lds, st, x, wp, out, iscale,
-                       oscale, ws, *g, t);
+                       oscale, ws, *g, t, epi);
 }
 
 template <int SPLIT, bool VEC>
 static void launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
                          const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
-                         const ConvTiling &t) {
+                         const ConvTiling &t, const rick_conv_epilogue &epi) {
     // production path (bf16x3, vector loads), 3x3 stride-1 layers with a long channel loop and a full grid: the
     // straight-line 9-tap k-loop (measured +3..8 % there; slower on split-K, short-K and stride-2 launches)
     static const int no_unroll = getenv("RICK_IGEMM_NOUNROLL") ? atoi(getenv("RICK_IGEMM_NOUNROLL")) : 0;
     const bool u9 = SPLIT == 2 && VEC && g->ntaps == 9 && !no_unroll && !t.debug && igemm_tile_positions(g) == CV_BN &&
                     t.NPP <= IG_DEEP_NPP && t.nsplit == 1 && t.nchunks >= 8;
-    if (igemm_tile_positions(g) == 64) launch_igemm_k<SPLIT, VEC, false, 2>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
-    else if (u9) launch_igemm_k<2, true, false, 4, 9>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
-    else if (t.NPP <= IG_DEEP_NPP) launch_igemm_k<SPLIT, VEC, true, 4>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
-    else launch_igemm_k<SPLIT, VEC, false, 4>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
+    if (igemm_tile_positions(g) == 64) launch_igemm_k<SPLIT, VEC, false, 2>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
+    else if (u9) launch_igemm_k<2, true, false, 4, 9>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
+    else if (t.NPP <= IG_DEEP_NPP) launch_igemm_k<SPLIT, VEC, true, 4>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
+    else launch_igemm_k<SPLIT, VEC, false, 4>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
 }
+
+extern "C" int rick_conv_igemm_act_f32(const float *x, const void *packed_w, float *out, const float *iscale,
+                                       const float *oscale, const rick_conv_geom *g, const rick_conv_epilogue *epilogue,
+                                       void *workspace, void *stream);
 
 extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *out, const float *iscale,
                                    const float *oscale, const rick_conv_geom *g, void *workspace, void *stream) {
+    return rick_conv_igemm_act_f32(x, packed_w, out, iscale, oscale, g, nullptr, workspace, stream);
+}
+
+extern "C" int rick_conv_igemm_act_f32(const float *x, const void *packed_w, float *out, const float *iscale,
+                                       const float *oscale, const rick_conv_geom *g, const rick_conv_epilogue *epilogue,
+                                       void *workspace, void *stream) {
     if (!x || !packed_w || !out || check_geom(g)) return RICK_EINVAL;
+    rick_conv_epilogue epi = kNoEpilogue;
+    if (epilogue) {
+        epi = *epilogue;
+        if (epi.noise && (!epi.noise_w || (epi.noise_nb != 1 && epi.noise_nb != g->N))) return RICK_EINVAL;
+        // the tail is applied on float4 channel groups: Co % 4 == 0, 16-byte aligned bias
+        if ((epi.bias || epi.noise || epi.act) && ((g->Co & 3) || ((uintptr_t)(epi.bias ? epi.bias : x) % 16))) return RICK_EINVAL;
+    }
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed_w | (uintptr_t)(iscale ? iscale : x) | (uintptr_t)(oscale ? oscale : x)) % 16)
         return RICK_EINVAL;
     ConvTiling t;
@@ -845,13 +908,13 @@ extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *
     const unsigned char *wp = (const unsigned char *)packed_w;
     const bool vec = (g->Ci & 3) == 0;
     if (g->split == 2) {
-        if (vec) launch_igemm<2, true>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
-        else launch_igemm<2, false>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
+        if (vec) launch_igemm<2, true>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
+        else launch_igemm<2, false>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
     } else {
-        if (vec) launch_igemm<1, true>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
-        else launch_igemm<1, false>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t);
+        if (vec) launch_igemm<1, true>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
+        else launch_igemm<1, false>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
     }
-    if (t.nsplit > 1) launch_splitk_reduce(ws, out, oscale, g, t.nsplit, st);
+    if (t.nsplit > 1) launch_splitk_reduce(ws, out, oscale, g, t.nsplit, st, epi);
     RICK_LAUNCH_STATUS();
 }
 

@@ -326,6 +326,19 @@ class ConvLayer(nn.Sequential):
                 raise NotImplementedError('ScaledLeakyReLU variant is not used by the reference networks')
             layers.append(FusedLeakyReLU(out_channel))
         super().__init__(*layers)
+        self._fusable = activate and out_channel % 4 == 0 and not (in_channel <= 4 and kernel_size == 1)
+
+    def forward(self, x):
+        # conv -> bias + LeakyReLU as ONE launch (tail in the MFMA kernel's epilogue) when only first derivatives are
+        # needed; the child modules (and their state_dict keys) stay exactly the reference's
+        if not self._fusable or op.second_order_enabled():
+            return super().forward(x)
+        mods = list(self)
+        for m in mods[:-2]:
+            x = m(x)
+        conv, act = mods[-2], mods[-1]
+        return op.conv2d_bias_act(x, conv.weight, act.bias, conv.stride, conv.padding, wscale=conv.scale,
+                                  key=(conv.weight, 'w'), negative_slope=act.negative_slope, gain=act.scale)
 
 
 class ResBlock(nn.Module):

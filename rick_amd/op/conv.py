@@ -22,8 +22,9 @@ import ctypes
 import numpy as np
 import torch
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
-from .._lib import MAX_TAPS, ConvGeom, check, lib, ptr, require_cuda_f32, stream_ptr
+from .._lib import MAX_TAPS, ConvEpilogue, ConvGeom, check, lib, ptr, require_cuda_f32, stream_ptr
 
 _SPLIT = 2          # 2: bf16 hi/lo split, 3 MFMAs per product (fp32-grade); 1: plain bf16
 _weights_epoch = 0  # bumped by optimisers that update parameters through raw pointers
@@ -236,7 +237,18 @@ def conv_out_size(i, k, s, p):
 
 
 # ------------------------------------------------------------------------------ raw launches
-def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0):
+def _epilogue(bias, noise, noise_w, slope, gain):
+    """rick_conv_epilogue for `gain * lrelu(conv + bias + noise_w * noise)`; noise is [1 or N, 1, OH, OW]."""
+    e = ConvEpilogue()
+    e.bias = ptr(bias)
+    e.noise = ptr(noise)
+    e.noise_w = ptr(noise_w) if noise is not None else None
+    e.noise_nb = noise.shape[0] if noise is not None else 1
+    e.act, e.slope, e.gain = 1, float(slope), float(gain)
+    return e
+
+
+def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0, epi=None):
     x = _nhwc(x)
     N, I, IH, IW = x.shape
     key = ('c', N, I, IH, IW, O, kh, kw, s, p, alpha, _SPLIT)
@@ -254,6 +266,10 @@ def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0):
     g, gref, nbytes, OH, OW, flops, tag = ent
     y = _empty_nhwc(N, O, OH, OW, x)
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
+    if epi is not None:
+        check(_launch('igemm', flops, lib.rick_conv_igemm_act_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), gref,
+                      ctypes.byref(epi), ptr(ws), stream_ptr(), tag=tag), 'rick_conv_igemm_act_f32')
+        return y
     check(_launch('igemm', flops, lib.rick_conv_igemm_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), gref,
                   ptr(ws), stream_ptr(), tag=tag), 'rick_conv_igemm_f32')
     return y
@@ -407,6 +423,47 @@ class _WGrad(Function):
         if ctx.needs_input_grad[1]:
             gb = _ConvT.apply(a, gg.transpose(0, 1), s, p, alpha, (b.shape[2], b.shape[3]), None)
         return ga, gb, None, None, None, None, None
+
+
+class _ConvBiasAct(Function):
+    """EqualConv2d followed by FusedLeakyReLU (every ConvLayer of D, model_probe_tune.py:595-641) with the bias +
+    LeakyReLU tail applied in the convolution's epilogue: the separate activation pass (one read + one write of the
+    feature map) disappears from the forward; values are bit-identical to conv -> fused_leaky_relu.  First order only
+    (under op.second_order() the layers run the composed, twice-differentiable ops)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, s, p, wscale, key, slope, gain):
+        O, I, kh, kw = w.shape
+        if x.shape[1] != I:
+            raise RuntimeError(f'conv: input has {x.shape[1]} channels, weight expects {I}')
+        bias = bias.contiguous()
+        y = _conv_launch(x, _pack(w, wscale, key and (key[0], key[1] + '/conv')), O, kh, kw, s, p,
+                         epi=_epilogue(bias, None, None, slope, gain))
+        ctx.save_for_backward(x, w, y)
+        ctx.cfg = (s, p, wscale, key, slope, gain)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from .fused_act import _ActAdjoint
+        x, w, y = ctx.saved_tensors
+        s, p, wscale, key, slope, gain = ctx.cfg
+        O, I, kh, kw = w.shape
+        gz, gb, _ = _ActAdjoint.apply(g, y, None, slope, gain, ctx.needs_input_grad[2], False)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            wpT = _pack(w.transpose(0, 1), wscale, key and (key[0], key[1] + '/T/convT'))
+            gx = _convT_launch(gz, wpT, I, kh, kw, s, p, (x.shape[2], x.shape[3]))
+        if ctx.needs_input_grad[1]:
+            gw = _wgrad_launch(gz, x, kh, kw, s, p, wscale)
+        return gx, gw, (gb if ctx.needs_input_grad[2] else None), None, None, None, None, None, None
+
+
+def conv2d_bias_act(x, w, bias, stride=1, padding=0, wscale=1.0, key=None, negative_slope=0.2, gain=2 ** 0.5):
+    """gain * leaky_relu(conv2d(x, w * wscale) + bias) in one launch (needs Co % 4 == 0; first-order autograd)."""
+    require_cuda_f32(x, w, bias)
+    return _ConvBiasAct.apply(x, w, bias, stride, padding, wscale, key, negative_slope, gain)
 
 
 def conv2d(x, w, stride=1, padding=0, wscale=1.0, key=None):

@@ -377,3 +377,24 @@ def test_demod_fused_matches_composed(B, O, I, k):
     d2 = demod_coeff_fused(wd.detach(), sd, scale)
     (gs2,) = torch.autograd.grad(d2, [sd], gd.to(DEV))
     assert torch.equal(gs2, gs)
+
+
+@pytest.mark.parametrize('N,I,O,H,k,s,p', [(2, 16, 24, 9, 3, 1, 1), (4, 512, 512, 8, 3, 1, 1), (3, 32, 64, 17, 3, 2, 0),
+                                           (2, 64, 128, 16, 1, 1, 0), (8, 128, 128, 32, 3, 1, 1)])
+def test_conv_bias_act_fused_equals_two_pass(N, I, O, H, k, s, p):
+    """rick_conv_igemm_act_f32: the fused tail is bit-identical to conv2d -> fused_leaky_relu (also through the
+    split-K second stage), and so are the input / weight / bias gradients."""
+    from rick_amd import op
+    gen = torch.Generator().manual_seed(N * 100 + I + O + H)
+    x = torch.randn(N, I, H, H, generator=gen).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.randn(O, I, k, k, generator=gen).to(DEV).requires_grad_(True)
+    b = torch.randn(O, generator=gen).to(DEV).requires_grad_(True)
+    scale = 1.0 / (I * k * k) ** 0.5
+    y1 = op.fused_leaky_relu(op.conv2d(x, w, s, p, wscale=scale), b)
+    y2 = op.conv2d_bias_act(x, w, b, s, p, wscale=scale)
+    assert torch.equal(y1, y2)
+    g = torch.randn(y1.shape, generator=gen).to(DEV)
+    g1 = torch.autograd.grad(y1, [x, w, b], g)
+    g2 = torch.autograd.grad(y2, [x, w, b], g)
+    for a, c in zip(g1, g2):
+        assert torch.equal(a, c)
