@@ -12,7 +12,7 @@ the reference's own `upfirdn2d_native`, op/upfirdn2d.py:146-149).  Everything el
 Inputs are never stored when they can be regenerated from rick_amd.synth (closed-form,
 seeded by key name); only outputs are.
 
-usage: python tools/make_golden.py [--only ops|layers|small|full|latents|fid]
+usage: python tools/make_golden.py [--only ops|layers|small|full|latents|fid|ada]
 """
 import argparse
 import importlib.util
@@ -265,6 +265,29 @@ def gen_full(mpt):
     print('full256.npz', len(out), 'arrays')
 
 
+def gen_ada():
+    """ADA augmentation: the reference's non_leaking.py run on CPU.  Seeded sampler outputs
+    (G, C) and the full augment() image path for explicit (G, C), incl. a case that needs reflect padding."""
+    import non_leaking as nl
+    out = {}
+    for seed, (n, h, w), p in ((3, (4, 32, 32), 0.8), (11, (3, 24, 40), 0.5), (29, (2, 16, 16), 1.0)):
+        torch.manual_seed(seed)
+        out[f'samp{seed}/G'] = nl.sample_affine(p, n, h, w).numpy()
+        out[f'samp{seed}/C'] = nl.sample_color(p, n).numpy()
+        out[f'samp{seed}/meta'] = np.array([n, h, w, p], dtype=np.float64)
+    gen = torch.Generator().manual_seed(5)
+    for tag, (n, h, w), p, seed in (('a', (2, 32, 32), 0.8, 17), ('b', (3, 24, 40), 0.6, 23), ('c', (1, 64, 64), 1.0, 31)):
+        img = torch.rand(n, 3, h, w, generator=gen) * 2 - 1
+        torch.manual_seed(seed)
+        res, (G, C) = nl.augment(img, p)
+        res2, _ = nl.augment(img, p, (G, C))            # explicit matrices reproduce the sampled run
+        assert torch.equal(res, res2)
+        out[f'aug{tag}/img'], out[f'aug{tag}/G'], out[f'aug{tag}/C'] = img.numpy(), G.numpy(), C.numpy()
+        out[f'aug{tag}/out'] = res.numpy()
+    np.savez_compressed(os.path.join(OUT, 'ada.npz'), **out)
+    print('ada.npz:', {k: v.shape for k, v in out.items() if k.endswith('/out')})
+
+
 def gen_fid():
     """FID statistics.  gan_training/metrics/fid_score.py imports cv2 / an Inception wrapper
     that are absent here, so the two pure-NumPy/SciPy pieces are taken out of the reference FILE with `ast` and
@@ -305,7 +328,7 @@ def main():
         return
     torch.manual_seed(1)
     op, mpt = import_reference()
-    todo = [a.only] if a.only else ['latents', 'ops', 'layers', 'small', 'full']
+    todo = [a.only] if a.only else ['latents', 'ops', 'layers', 'small', 'full', 'ada']
     if 'latents' in todo:
         gen_latents()
     if 'ops' in todo:
@@ -316,6 +339,8 @@ def main():
         gen_small(mpt)
     if 'full' in todo:
         gen_full(mpt)
+    if 'ada' in todo:
+        gen_ada()
     if not a.only:
         gen_fid()
 
