@@ -552,19 +552,18 @@ class RickTrainer:
         self._run(key, fb, self.g_flat, self.g_optim, pre=(lambda: self._draw_inject(key)) if graph else None)
         return self.losses['g']
 
+    def _mixed_latents(self, noise):
+        """W-space latents [B, n_latent, 512] for a list of 1 or 2 z tensors — Generator.forward's own mixing
+        (random inject_index, model_probe_tune.py:555-560)."""
+        n_latent = self.g.n_latent
+        w = [self.g.style(z) for z in noise]
+        if len(w) < 2:
+            return w[0].unsqueeze(1).repeat(1, n_latent, 1)
+        k = random.randint(1, n_latent - 1)
+        return torch.cat([w[0].unsqueeze(1).repeat(1, k, 1), w[1].unsqueeze(1).repeat(1, n_latent - k, 1)], 1)
+
     def plr_step(self, noise, pl_noise=None, g_noise=None, graph=False):
-        # the path-length gradient is taken w.r.t. the latents, which only carry a graph if the mapping
-        # network's parameters require grad (in the reference every parameter does)
-        style_params = list(self.g.style.parameters())
-        for p in style_params:
-            p.requires_grad = True
-        try:
-            return self._plr_step(noise, pl_noise, g_noise, graph)
-        finally:
-            for p in style_params:
-                p.requires_grad = False
-                if not graph:
-                    p.grad = None
+        return self._plr_step(noise, pl_noise, g_noise, graph)
 
     def _plr_step(self, noise, pl_noise, g_noise, graph):
         cfg = self.cfg
@@ -574,12 +573,15 @@ class RickTrainer:
             self.mean_path_length = torch.full((), float(self.mean_path_length), device=self.device)
 
         def fb():
+            # The path-length gradient is taken w.r.t. the latents.  The optimiser owns no parameter of the mapping
+            # network (train_dynamic_update_prune.py:908-917), so the latents enter as a detached leaf: the
+            # reference's backward through the 8-layer MLP only produces gradients that are discarded, here it
+            # (and its double backward) is not run.  Conv-weight gradients are unchanged.
+            with torch.no_grad():
+                lat = self._graph_latents(key, batch) if graph else self._mixed_latents(noise)
+            lat = lat.detach().requires_grad_(True)
             with op.second_order():
-                if graph:
-                    fake_img, latents = self.g([self._graph_latents(key, batch)], input_is_latent=True,
-                                               return_latents=True, noise=g_noise)
-                else:
-                    fake_img, latents = self.g(noise, return_latents=True, noise=g_noise)
+                fake_img, latents = self.g([lat], input_is_latent=True, return_latents=True, noise=g_noise)
                 path_loss, new_mean, path_lengths = g_path_regularize(fake_img, latents, self.mean_path_length,
                                                                       noise=pl_noise)
                 self._zero_grad(self.g_flat)
