@@ -19,7 +19,7 @@ def adam_state_dict(optim):
     for j, i in enumerate(fp.opt_idx):
         if optim.steps[i] == 0:
             continue
-        lo, hi = int(fp.offsets[i]), int(fp.offsets[i + 1])
+        lo, hi = fp.segment(fp.names[i])
         shape = fp.params[i].shape
         state[j] = {'step': torch.tensor(float(optim.steps[i])),
                     'exp_avg': optim.m[lo:hi].view(shape).detach().clone(),
@@ -45,7 +45,7 @@ def load_adam_state_dict(optim, sd):
         optim.steps[i] = 0
         if st is None:
             continue
-        lo, hi = int(fp.offsets[i]), int(fp.offsets[i + 1])
+        lo, hi = fp.segment(fp.names[i])
         if st['exp_avg'].numel() != hi - lo:
             raise RuntimeError(f'optimizer state of parameter {fp.names[i]} has the wrong size')
         optim.steps[i] = int(round(float(st['step'])))

@@ -438,77 +438,89 @@ extern "C" int rick_add_scale_f32(const float *a, const float *b, float *y, int6
 // x[B, P, C] (NHWC, P = H*W), group = B (model_probe_tune.py:748-756 with group == batch):
 //   sd[p,c] = sqrt(mean_b (x - mean_b x)^2 + 1e-8);  stat = mean_{p,c} sd
 //   out[b,p,0:C] = x[b,p,:], out[b,p,C] = stat.
-// Single block (the tensor is B x 16 x 512): wavefront-shuffle block reduction.
-__global__ __launch_bounds__(256) void mbstd_fwd_kernel(const float *__restrict__ x, float *__restrict__ out,
-                                                        float *__restrict__ stat, int B, int P, int C, int groups) {
-    __shared__ float red[8];
+// One 1024-thread block per statistics group (the tensor is B x 16 x 512: latency-bound, so the work is spread over
+// 16 wavefronts and the groups over blocks); wavefront-shuffle + fixed-order LDS reduction (deterministic).
+#define MBSTD_THREADS 1024
+__device__ __forceinline__ float block_sum_1024(float v, float *red /*[17]*/) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < MBSTD_THREADS / 64; w++) t += red[w];
+        red[16] = t;
+    }
+    __syncthreads();
+    return red[16];
+}
+
+__global__ __launch_bounds__(MBSTD_THREADS) void mbstd_fwd_kernel(const float *__restrict__ x, float *__restrict__ out,
+                                                                  float *__restrict__ stat, int B, int P, int C, int groups) {
+    __shared__ float red[17];
     const int PC = P * C, C1 = C + 1, gs = B / groups;
-    for (int gi = 0; gi < groups; gi++) {
-        const float *xg = x + (int64_t)gi * gs * PC;
-        float local = 0.f;
-        for (int i = threadIdx.x; i < PC; i += 256) {
-            float mean = 0.f;
-            for (int b = 0; b < gs; b++) mean += xg[(int64_t)b * PC + i];
-            mean /= gs;
-            float var = 0.f;
-            for (int b = 0; b < gs; b++) {
-                const float d = xg[(int64_t)b * PC + i] - mean;
-                var += d * d;
-            }
-            local += sqrtf(var / gs + 1e-8f);
+    const int gi = blockIdx.x;
+    const float *xg = x + (int64_t)gi * gs * PC;
+    float local = 0.f;
+    for (int i = threadIdx.x; i < PC; i += MBSTD_THREADS) {
+        float mean = 0.f;
+        for (int b = 0; b < gs; b++) mean += xg[(int64_t)b * PC + i];
+        mean /= gs;
+        float var = 0.f;
+        for (int b = 0; b < gs; b++) {
+            const float d = xg[(int64_t)b * PC + i] - mean;
+            var += d * d;
         }
-        const float tot = block_sum_256(local, red) / PC;
-        if (threadIdx.x == 0) stat[gi] = tot;
-        float *og = out + (int64_t)gi * gs * P * C1;
-        for (int64_t i = threadIdx.x; i < (int64_t)gs * P * C1; i += 256) {
-            const int c = (int)(i % C1);
-            const int64_t bp = i / C1;
-            og[i] = c < C ? xg[bp * C + c] : tot;
-        }
-        __syncthreads();
+        local += sqrtf(var / gs + 1e-8f);
+    }
+    const float tot = block_sum_1024(local, red) / PC;
+    if (threadIdx.x == 0) stat[gi] = tot;
+    float *og = out + (int64_t)gi * gs * P * C1;
+    for (int i = threadIdx.x; i < gs * P * C1; i += MBSTD_THREADS) {
+        const int c = i % C1;
+        const int bp = i / C1;
+        og[i] = c < C ? xg[(int64_t)bp * C + c] : tot;
     }
 }
 
 // gx[b,p,c] = gout[b,p,c] + G/(P*C) * (x[b,p,c]-mean[p,c]) / (gs * sd[p,c]),  G = sum_{b,p in group} gout[b,p,C]
-__global__ __launch_bounds__(256) void mbstd_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gout,
-                                                        float *__restrict__ gx, int B, int P, int C, int groups) {
-    __shared__ float red[8];
+__global__ __launch_bounds__(MBSTD_THREADS) void mbstd_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gout,
+                                                                  float *__restrict__ gx, int B, int P, int C, int groups) {
+    __shared__ float red[17];
     const int PC = P * C, C1 = C + 1, gs = B / groups;
-    for (int gi = 0; gi < groups; gi++) {
-        const float *xg = x + (int64_t)gi * gs * PC;
-        const float *gg = gout + (int64_t)gi * gs * P * C1;
-        float *gxg = gx + (int64_t)gi * gs * PC;
-        float gl = 0.f;
-        for (int i = threadIdx.x; i < gs * P; i += 256) gl += gg[(int64_t)i * C1 + C];
-        const float G = block_sum_256(gl, red) / PC;
-        for (int i = threadIdx.x; i < PC; i += 256) {
-            const int p = i / C, c = i - p * C;
-            float mean = 0.f;
-            for (int b = 0; b < gs; b++) mean += xg[(int64_t)b * PC + i];
-            mean /= gs;
-            float var = 0.f;
-            for (int b = 0; b < gs; b++) {
-                const float d = xg[(int64_t)b * PC + i] - mean;
-                var += d * d;
-            }
-            const float sd = sqrtf(var / gs + 1e-8f);
-            for (int b = 0; b < gs; b++) {
-                const float d = xg[(int64_t)b * PC + i] - mean;
-                gxg[(int64_t)b * PC + i] = gg[((int64_t)b * P + p) * C1 + c] + G * d / (gs * sd);
-            }
+    const int gi = blockIdx.x;
+    const float *xg = x + (int64_t)gi * gs * PC;
+    const float *gg = gout + (int64_t)gi * gs * P * C1;
+    float *gxg = gx + (int64_t)gi * gs * PC;
+    float gl = 0.f;
+    for (int i = threadIdx.x; i < gs * P; i += MBSTD_THREADS) gl += gg[(int64_t)i * C1 + C];
+    const float G = block_sum_1024(gl, red) / PC;
+    for (int i = threadIdx.x; i < PC; i += MBSTD_THREADS) {
+        const int p = i / C, c = i - p * C;
+        float mean = 0.f;
+        for (int b = 0; b < gs; b++) mean += xg[(int64_t)b * PC + i];
+        mean /= gs;
+        float var = 0.f;
+        for (int b = 0; b < gs; b++) {
+            const float d = xg[(int64_t)b * PC + i] - mean;
+            var += d * d;
         }
-        __syncthreads();
+        const float sd = sqrtf(var / gs + 1e-8f);
+        for (int b = 0; b < gs; b++) {
+            const float d = xg[(int64_t)b * PC + i] - mean;
+            gxg[(int64_t)b * PC + i] = gg[((int64_t)b * P + p) * C1 + c] + G * d / (gs * sd);
+        }
     }
 }
 
 extern "C" int rick_mbstd_fwd_f32(const float *x, float *out, float *stat, int B, int P, int C, int groups, void *stream) {
     if (!x || !out || !stat || B <= 0 || P <= 0 || C <= 0 || groups <= 0 || B % groups) return RICK_EINVAL;
-    hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, out, stat, B, P, C, groups);
+    hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(groups), dim3(MBSTD_THREADS), 0, (hipStream_t)stream, x, out, stat, B, P, C, groups);
     RICK_LAUNCH_STATUS();
 }
 extern "C" int rick_mbstd_bwd_f32(const float *x, const float *gout, float *gx, int B, int P, int C, int groups, void *stream) {
     if (!x || !gout || !gx || B <= 0 || P <= 0 || C <= 0 || groups <= 0 || B % groups) return RICK_EINVAL;
-    hipLaunchKernelGGL(mbstd_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, gout, gx, B, P, C, groups);
+    hipLaunchKernelGGL(mbstd_bwd_kernel, dim3(groups), dim3(MBSTD_THREADS), 0, (hipStream_t)stream, x, gout, gx, B, P, C, groups);
     RICK_LAUNCH_STATUS();
 }
 

@@ -70,6 +70,9 @@ def requires_grad(model, flag=True, only=None):
 
 
 # ------------------------------------------------------------------ flat params / Adam / EMA
+FLAT_ALIGN = 64      # floats
+
+
 class FlatParams:
     """Re-homes the parameters of a network into ONE flat fp32 buffer (each parameter becomes a view)
     with a matching flat gradient buffer (``p.grad`` are views too).  `opt_filter` marks the parameters an
@@ -83,10 +86,18 @@ class FlatParams:
         self.names = [n for n, _ in named_params]
         self.params = [p for _, p in named_params]
         sizes = [p.numel() for p in self.params]
-        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        # every parameter starts on a 256-byte boundary (a bias that follows the 1-element noise strength would
+        # otherwise be misaligned for the float4 kernels); offsets[i + 1] is the START of parameter i + 1, the
+        # padding in between stays zero (zero gradient: Adam, EMA and the all-reduce leave it zero)
+        self.sizes = sizes
+        starts, pos = [], 0
+        for n in sizes:
+            starts.append(pos)
+            pos += (n + FLAT_ALIGN - 1) // FLAT_ALIGN * FLAT_ALIGN
+        self.offsets = np.array(starts + [pos], dtype=np.int64)
         self.total = int(self.offsets[-1])
         dev = self.params[0].device
-        self.flat = torch.empty(self.total, device=dev, dtype=torch.float32)
+        self.flat = torch.zeros(self.total, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(self.total, device=dev, dtype=torch.float32)
         for p, o, n in zip(self.params, self.offsets, sizes):
             self.flat[o:o + n].copy_(p.data.reshape(-1))
@@ -104,7 +115,7 @@ class FlatParams:
 
     def segment(self, name):
         i = self.index[name]
-        return int(self.offsets[i]), int(self.offsets[i + 1])
+        return int(self.offsets[i]), int(self.offsets[i]) + self.sizes[i]
 
 
 class MaskedFlatAdam:

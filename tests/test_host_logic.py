@@ -89,7 +89,9 @@ def test_flat_params_and_masks_cpu():
     named = [(n, p) for n, p in g.named_parameters() if g_optim_filter(n)]
     before = {n: p.detach().clone() for n, p in named}
     flat = FlatParams(named)
-    assert flat.total == sum(p.numel() for _, p in named)
+    from rick_amd.train import FLAT_ALIGN
+    assert flat.total == sum(-(-p.numel() // FLAT_ALIGN) * FLAT_ALIGN for _, p in named)      # 256-byte aligned starts
+    assert all(int(o) % FLAT_ALIGN == 0 for o in flat.offsets)
     for n, p in named:
         assert torch.equal(p.detach(), before[n])
         lo, hi = flat.segment(n)
@@ -151,7 +153,9 @@ def _dp_worker(rank, world, port, q):
     dp.all_reduce(flat)
     vec = [torch.full((5,), float(rank + 1)), torch.full((3,), 10.0 * (rank + 1))]
     dp.all_reduce_vectors(vec)
-    q.put((rank, res[0].numpy(), res[1].numpy(), vec[0].numpy(), vec[1].numpy(), flat.grad.clone().numpy()))
+    def dense(gr):          # gradient of every parameter, concatenated (the flat buffer pads each one to 256 bytes)
+        return torch.cat([gr[slice(*flat.segment(n))] for n in flat.names]).numpy()
+    q.put((rank, dense(res[0]), dense(res[1]), vec[0].numpy(), vec[1].numpy(), dense(flat.grad.clone())))
     torch.distributed.destroy_process_group()
 
 
