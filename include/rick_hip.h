@@ -144,6 +144,13 @@ typedef struct {
 int rick_conv_igemm_f32(const float *x, const void *packed_w, float *out,
                         const float *iscale, const float *oscale,
                         const rick_conv_geom *g, void *workspace, void *stream);
+/* rick_upfirdn2d_f32 with the same tail fused after the FIR (the blur that follows every upsampling StyledConv,
+ * model_probe_tune.py:263-268,344-348): channels-last 4x4 taps, up = 1, minor % 64 == 0 only (else non-zero). */
+int rick_upfirdn2d_act_f32(const float *input, const float *kernel, float *out,
+                           int64_t major, int in_h, int in_w, int minor, int kh, int kw,
+                           int up_x, int up_y, int down_x, int down_y,
+                           int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                           const rick_conv_epilogue *tail, void *stream);
 /* rick_conv_igemm_f32 with the fused tail (epilogue may be NULL). */
 int rick_conv_igemm_act_f32(const float *x, const void *packed_w, float *out, const float *iscale, const float *oscale,
                             const rick_conv_geom *g, const rick_conv_epilogue *epilogue, void *workspace, void *stream);

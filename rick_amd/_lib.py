@@ -40,6 +40,7 @@ class ConvEpilogue(ctypes.Structure):
 SIGNATURES = {
     'rick_abi_version': (c_int, []),
     'rick_upfirdn2d_f32': (c_int, [c_fp, c_fp, c_fp, c_i64] + [c_int] * 13 + [c_fp]),
+    'rick_upfirdn2d_act_f32': (c_int, [c_fp, c_fp, c_fp, c_i64] + [c_int] * 13 + [ctypes.POINTER(ConvEpilogue), c_fp]),
     'rick_bias_act_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f,
                                   c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_fp]),
     'rick_bias_act_bwd_blocks': (c_int, [c_i64, c_int]),

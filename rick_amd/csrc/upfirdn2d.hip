@@ -138,10 +138,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_kernel(const float *__rest
 // decimation are all 4x4 kernels with up == 1 and down in {1, 2} on >= 64 channels.  Compile-time tile,
 // tap count and strides: 16 unrolled fmaf per output float4, y-outer / x-inner exactly like the generic
 // kernel and the C oracle (bit-identical results).
-template <int DOWN, int TOH, int TOW>
+template <int DOWN, int TOH, int TOW, bool TAIL>
 __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__restrict__ in,
                                                                 const float *__restrict__ kern,
-                                                                float *__restrict__ out, UfdParams p) {
+                                                                float *__restrict__ out, UfdParams p,
+                                                                rick_conv_epilogue tail) {
     constexpr int TIH = (TOH - 1) * DOWN + 4, TIW = (TOW - 1) * DOWN + 4, CB4 = 16;
     __shared__ float4 sx[TIH * TIW * CB4];
     // blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of tiles (row-major), so the
@@ -197,8 +198,26 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
                 v.z = __builtin_fmaf(xv.z, kv, v.z);
                 v.w = __builtin_fmaf(xv.w, kv, v.w);
             }
-        if (oy < p.out_h && ox < p.out_w)
+        if (oy < p.out_h && ox < p.out_w) {
+            if (TAIL) {   // fused NoiseInjection + bias + LeakyReLU (same operation order as rick_bias_act_f32)
+                if (tail.bias) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(tail.bias + c0 + c4 * 4);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                }
+                if (tail.noise) {
+                    const float nv = tail.noise_w[0] *
+                                     tail.noise[(tail.noise_nb == 1 ? 0 : n) * p.out_h * p.out_w + (int64_t)oy * p.out_w + ox];
+                    v.x += nv; v.y += nv; v.z += nv; v.w += nv;
+                }
+                if (tail.act) {
+                    v.x = (v.x > 0.f ? v.x : v.x * tail.slope) * tail.gain;
+                    v.y = (v.y > 0.f ? v.y : v.y * tail.slope) * tail.gain;
+                    v.z = (v.z > 0.f ? v.z : v.z * tail.slope) * tail.gain;
+                    v.w = (v.w > 0.f ? v.w : v.w * tail.slope) * tail.gain;
+                }
+            }
             *reinterpret_cast<float4 *>(dst + ((int64_t)oy * p.out_w + ox) * p.minor + c4 * 4) = v;
+        }
     }
 }
 
@@ -207,10 +226,31 @@ static int tile_in_extent(int tile_out, int down, int k, int up) {
     return ((tile_out - 1) * down + k - 1) / up + 2;
 }
 
+static int upfirdn2d_impl(const float *input, const float *kernel, float *out, int64_t major, int in_h, int in_w, int minor,
+                          int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                          int pad_y1, const rick_conv_epilogue *tail, void *stream);
+
 extern "C" int rick_upfirdn2d_f32(const float *input, const float *kernel, float *out,
                                   int64_t major, int in_h, int in_w, int minor, int kh, int kw,
                                   int up_x, int up_y, int down_x, int down_y,
                                   int pad_x0, int pad_x1, int pad_y0, int pad_y1, void *stream) {
+    return upfirdn2d_impl(input, kernel, out, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1,
+                          pad_y0, pad_y1, nullptr, stream);
+}
+
+extern "C" int rick_upfirdn2d_act_f32(const float *input, const float *kernel, float *out,
+                                      int64_t major, int in_h, int in_w, int minor, int kh, int kw,
+                                      int up_x, int up_y, int down_x, int down_y,
+                                      int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                      const rick_conv_epilogue *tail, void *stream) {
+    if (!tail) return RICK_EINVAL;
+    return upfirdn2d_impl(input, kernel, out, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1,
+                          pad_y0, pad_y1, tail, stream);
+}
+
+static int upfirdn2d_impl(const float *input, const float *kernel, float *out, int64_t major, int in_h, int in_w, int minor,
+                          int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                          int pad_y1, const rick_conv_epilogue *tail, void *stream) {
     if (!input || !kernel || !out || major <= 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kh <= 0 ||
         kw <= 0 || up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0)
         return RICK_EINVAL;
@@ -224,17 +264,25 @@ extern "C" int rick_upfirdn2d_f32(const float *input, const float *kernel, float
     hipStream_t st = (hipStream_t)stream;
     if (minor % 64 == 0 && kh == 4 && kw == 4 && up_x == 1 && up_y == 1 && down_x == down_y && (down_x == 1 || down_x == 2) &&
         major <= 65535 && minor / 64 <= 65535 && (((uintptr_t)input | (uintptr_t)out) % 16 == 0)) {
+        const rick_conv_epilogue none = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f};
+        if (tail) {
+            if (tail->noise && (!tail->noise_w || (tail->noise_nb != 1 && tail->noise_nb != major))) return RICK_EINVAL;
+            if (tail->bias && ((uintptr_t)tail->bias % 16)) return RICK_EINVAL;
+        }
         if (down_x == 1) {
             p.tiles_x = cdiv(p.out_w, 8);
             dim3 grid(p.tiles_x * cdiv(p.out_h, 8), minor / 64, (unsigned)major);
-            hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<1, 8, 8>), grid, dim3(256), 0, st, input, kernel, out, p);
+            if (tail) hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<1, 8, 8, true>), grid, dim3(256), 0, st, input, kernel, out, p, *tail);
+            else hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<1, 8, 8, false>), grid, dim3(256), 0, st, input, kernel, out, p, none);
         } else {
             p.tiles_x = cdiv(p.out_w, 8);
             dim3 grid(p.tiles_x * cdiv(p.out_h, 4), minor / 64, (unsigned)major);
-            hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<2, 4, 8>), grid, dim3(256), 0, st, input, kernel, out, p);
+            if (tail) hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<2, 4, 8, true>), grid, dim3(256), 0, st, input, kernel, out, p, *tail);
+            else hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<2, 4, 8, false>), grid, dim3(256), 0, st, input, kernel, out, p, none);
         }
         RICK_LAUNCH_STATUS();
     }
+    if (tail) return RICK_EINVAL;   // the fused tail exists on the channels-last 4x4 path only
     if (minor % 4 == 0) {
         const int cb4 = (minor >= 64 ? 64 : minor) / 4;
         if (minor % (cb4 * 4) != 0) goto planar_like;    // e.g. minor = 72: fall through to generic

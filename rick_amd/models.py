@@ -139,7 +139,9 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
 
-    def forward(self, x, style):
+    def forward(self, x, style, tail=None):
+        """tail = (bias, noise, noise_weight, negative_slope, gain): apply StyledConv's NoiseInjection + FusedLeakyReLU
+        as part of this layer (fused into the blur launch of the upsampling variant; first-order mode only)."""
         s = self.modulation(style)                                   # [B, Ci]
         w = self.weight[0]                                           # [Co, Ci, k, k]
         if self.kernel_size == 1 and self.out_channel <= 4 and not self.demodulate:
@@ -155,7 +157,10 @@ class ModulatedConv2d(nn.Module):
                 y = self.blur(y)
             return op.chan_scale(y, d) if d is not None else y
         y = _mc.modulated_conv_fused(x, w, s, d, self.scale, self.upsample, key)
-        return self.blur(y) if self.upsample else y
+        if tail is not None and self.upsample:
+            return op.upfirdn2d_noise_bias_act(y, self.blur.kernel, self.blur.pad, *tail)
+        y = self.blur(y) if self.upsample else y
+        return y if tail is None else fused_noise_bias_act(y, *tail)
 
 
 class NoiseInjection(nn.Module):
@@ -191,12 +196,13 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
 
     def forward(self, x, style, noise=None):
-        out = self.conv(x, style)
         if noise is None:
-            b, _, h, w = out.shape
-            noise = torch.empty(b, 1, h, w, device=out.device, dtype=out.dtype).normal_()
-        return fused_noise_bias_act(out, self.activate.bias, noise, self.noise.weight,
-                                    self.activate.negative_slope, self.activate.scale)
+            r = x.shape[2] * 2 if self.conv.upsample else x.shape[2]
+            noise = torch.empty(x.shape[0], 1, r, r * x.shape[3] // x.shape[2], device=x.device, dtype=x.dtype).normal_()
+        tail = (self.activate.bias, noise, self.noise.weight, self.activate.negative_slope, self.activate.scale)
+        if op.second_order_enabled():
+            return fused_noise_bias_act(self.conv(x, style), *tail)
+        return self.conv(x, style, tail)
 
 
 class ToRGB(nn.Module):

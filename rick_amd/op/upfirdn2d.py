@@ -12,7 +12,10 @@ kernel (major = N, minor = C); anything else (e.g. the 3-channel RGB skip) runs 
 (major = N*C, minor = 1).  The result is returned in the layout that ran.
 """
 import torch
+import ctypes
+
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from .._lib import check, lib, ptr, require_cuda_f32, stream_ptr
 
@@ -84,3 +87,51 @@ def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
     if input.ndim != 4 or kernel.ndim != 2:
         raise RuntimeError('upfirdn2d expects input [N,C,H,W] and kernel [kh,kw]')
     return _UpFirDn.apply(input, kernel.contiguous(), (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
+
+
+class _FirAct(Function):
+    """upfirdn2d (4x4 taps, up = down = 1, channels-last) followed by NoiseInjection + bias + LeakyReLU in the SAME
+    launch (rick_upfirdn2d_act_f32): the blur after an upsampling StyledConv and its activation tail
+    (model_probe_tune.py:263-268, 343-346) without the intermediate feature map round trip.  Bit-identical to
+    upfirdn2d -> fused_noise_bias_act.  First order only."""
+
+    @staticmethod
+    def forward(ctx, x, taps, pad4, bias, noise, nw, slope, gain):
+        from .conv import _epilogue
+        n, c, h, w = x.shape
+        kh, kw = taps.shape
+        oh, ow = h + pad4[2] + pad4[3] - kh + 1, w + pad4[0] + pad4[1] - kw + 1
+        x = x.contiguous(memory_format=torch.channels_last)
+        bias = bias.contiguous()
+        noise = noise.contiguous()
+        nw = nw.contiguous()
+        y = torch.empty((n, c, oh, ow), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+        tail = _epilogue(bias, noise, nw, slope, gain)
+        check(lib.rick_upfirdn2d_act_f32(ptr(x), ptr(taps), ptr(y), n, h, w, c, kh, kw, 1, 1, 1, 1, pad4[0], pad4[1],
+                                         pad4[2], pad4[3], ctypes.byref(tail), stream_ptr()), 'rick_upfirdn2d_act_f32')
+        ctx.save_for_backward(y, noise)
+        ctx.flipped = _flipped(taps)
+        ctx.cfg = (slope, gain, (kw - pad4[0] - 1, w - ow + pad4[0], kh - pad4[2] - 1, h - oh + pad4[2]))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from .fused_act import _ActAdjoint
+        y, noise = ctx.saved_tensors
+        slope, gain, adj = ctx.cfg
+        gz, gb, gw = _ActAdjoint.apply(g, y, noise, slope, gain, ctx.needs_input_grad[3], ctx.needs_input_grad[5])
+        gx = _fir(gz, ctx.flipped, (1, 1), (1, 1), adj) if ctx.needs_input_grad[0] else None
+        return (gx, None, None, gb if ctx.needs_input_grad[3] else None, None,
+                gw if ctx.needs_input_grad[5] else None, None, None)
+
+
+def upfirdn2d_noise_bias_act(input, kernel, pad, bias, noise, noise_weight, negative_slope=0.2, gain=2 ** 0.5):
+    """gain * lrelu(upfirdn2d(input, kernel, pad=pad) + bias + noise_weight * noise) — one launch when the fused
+    path applies (4x4 taps, C % 64 == 0), the two separate ops otherwise.  First-order autograd."""
+    require_cuda_f32(input, kernel, bias, noise, noise_weight)
+    if kernel.shape == (4, 4) and input.shape[1] % 64 == 0 and input.shape[0] <= 65535:
+        return _FirAct.apply(input, kernel.contiguous(), (pad[0], pad[1], pad[0], pad[1]), bias, noise, noise_weight,
+                             float(negative_slope), float(gain))
+    from .fused_act import fused_noise_bias_act
+    return fused_noise_bias_act(upfirdn2d(input, kernel, pad=pad), bias, noise, noise_weight, negative_slope, gain)

@@ -398,3 +398,24 @@ def test_conv_bias_act_fused_equals_two_pass(N, I, O, H, k, s, p):
     g2 = torch.autograd.grad(y2, [x, w, b], g)
     for a, c in zip(g1, g2):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize('N,C,H,pad,nb', [(2, 64, 9, (1, 1), 2), (4, 128, 33, (1, 1), 1), (3, 512, 17, (2, 2), 3), (2, 24, 9, (1, 1), 2)])
+def test_blur_noise_bias_act_fused_equals_two_pass(N, C, H, pad, nb):
+    """rick_upfirdn2d_act_f32 (blur + NoiseInjection + bias + LeakyReLU in one launch) is bit-identical to
+    upfirdn2d -> fused_noise_bias_act, forward and backward; C = 24 takes the documented two-op fallback."""
+    from rick_amd import op
+    gen = torch.Generator().manual_seed(N * 100 + C + H)
+    k = torch.tensor([1., 3., 3., 1.])
+    k = (torch.outer(k, k) / 64 * 4).to(DEV)
+    x = torch.randn(N, C, H, H, generator=gen).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = torch.randn(C, generator=gen).to(DEV).requires_grad_(True)
+    nw = torch.tensor([0.3], device=DEV, requires_grad=True)
+    oh = H + 2 * pad[0] - 3
+    noise = torch.randn(nb if nb == 1 else N, 1, oh, oh, generator=gen).to(DEV)
+    y1 = op.fused_noise_bias_act(op.upfirdn2d(x, k, pad=pad), b, noise, nw)
+    y2 = op.upfirdn2d_noise_bias_act(x, k, pad, b, noise, nw)
+    assert torch.equal(y1, y2)
+    g = torch.randn(y1.shape, generator=gen).to(DEV)
+    for a, c in zip(torch.autograd.grad(y1, [x, b, nw], g), torch.autograd.grad(y2, [x, b, nw], g)):
+        assert torch.equal(a, c)
