@@ -337,9 +337,27 @@ extern "C" int rick_hw_dot_blocks(int64_t P) {
     return (int)(nb < 1 ? 1 : nb);
 }
 
-template <bool VEC4>
+// ACT: b holds the OUTPUT y of a fused conv + noise + bias + LeakyReLU tail; the factor is the pre-tail value
+// reconstructed on the fly,  lrelu^-1(y) - noise_w * noise[n,p] - bias[c]  (demodulation gradient of the fused
+// StyledConv: sum_p gz * conv_out without keeping conv_out).
+struct HwDotAct {
+    const float *bias, *noise, *noise_w;
+    int noise_nb;
+    float inv_gain, inv_gain_slope;
+};
+
+__device__ __forceinline__ float4 hwdot_unact(float4 y, float4 bias, float nv, const HwDotAct &t) {
+    float4 r;
+    r.x = (y.x > 0.f ? y.x * t.inv_gain : y.x * t.inv_gain_slope) - nv - bias.x;
+    r.y = (y.y > 0.f ? y.y * t.inv_gain : y.y * t.inv_gain_slope) - nv - bias.y;
+    r.z = (y.z > 0.f ? y.z * t.inv_gain : y.z * t.inv_gain_slope) - nv - bias.z;
+    r.w = (y.w > 0.f ? y.w * t.inv_gain : y.w * t.inv_gain_slope) - nv - bias.w;
+    return r;
+}
+
+template <bool VEC4, bool ACT>
 __global__ __launch_bounds__(256) void hw_dot_kernel(const float *__restrict__ a, const float *__restrict__ b,
-                                                     float *__restrict__ partials, int64_t P, int C) {
+                                                     float *__restrict__ partials, int64_t P, int C, HwDotAct t) {
     extern __shared__ float lds[];   // [256 * 4]
     constexpr int W = VEC4 ? 4 : 1;
     const int n = blockIdx.y, N = gridDim.y, nb = gridDim.x;
@@ -357,6 +375,16 @@ __global__ __launch_bounds__(256) void hw_dot_kernel(const float *__restrict__ a
             int64_t p = p0 + lane_r;
             const int64_t step = (int64_t)rpb * C;
             const float *ap = an + p * C + (int64_t)(cbase + lane_c) * W, *bp = bn + p * C + (int64_t)(cbase + lane_c) * W;
+            float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float nwv = 0.f;
+            const float *nz = nullptr;
+            if (ACT) {
+                if (t.bias) bias4 = *reinterpret_cast<const float4 *>(t.bias + (cbase + lane_c) * 4);
+                if (t.noise) {
+                    nwv = t.noise_w[0];
+                    nz = t.noise + (int64_t)(t.noise_nb == 1 ? 0 : n) * P;
+                }
+            }
             if (VEC4)
                 for (; p + 3 * rpb < p1; p += 4 * rpb) {   // 8 independent 16-byte loads in flight per thread
                     float4 av[4], bv[4];
@@ -364,6 +392,10 @@ __global__ __launch_bounds__(256) void hw_dot_kernel(const float *__restrict__ a
                     for (int u = 0; u < 4; u++) {
                         av[u] = *reinterpret_cast<const float4 *>(ap + u * step);
                         bv[u] = *reinterpret_cast<const float4 *>(bp + u * step);
+                    }
+                    if (ACT) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) bv[u] = hwdot_unact(bv[u], bias4, nz ? nwv * nz[p + u * rpb] : 0.f, t);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
@@ -376,7 +408,8 @@ __global__ __launch_bounds__(256) void hw_dot_kernel(const float *__restrict__ a
             for (; p < p1; p += rpb) {
                 if (VEC4) {
                     const float4 av = *reinterpret_cast<const float4 *>(ap);
-                    const float4 bv = *reinterpret_cast<const float4 *>(bp);
+                    float4 bv = *reinterpret_cast<const float4 *>(bp);
+                    if (ACT) bv = hwdot_unact(bv, bias4, nz ? nwv * nz[p] : 0.f, t);
                     acc[0] += av.x * bv.x; acc[1] += av.y * bv.y; acc[2] += av.z * bv.z; acc[3] += av.w * bv.w;
                 } else {
                     acc[0] += ap[0] * bp[0];
@@ -402,10 +435,26 @@ extern "C" int rick_hw_dot_f32(const float *a, const float *b, float *d, int N, 
     if (!a || !b || !d || !partials || N <= 0 || P <= 0 || C <= 0 || N > 65535) return RICK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nb = rick_hw_dot_blocks(P);
+    const HwDotAct none = {nullptr, nullptr, nullptr, 1, 1.f, 1.f};
     if (C % 4 == 0 && (((uintptr_t)a | (uintptr_t)b) % 16 == 0))
-        hipLaunchKernelGGL(hw_dot_kernel<true>, dim3(nb, N), dim3(256), 1024 * sizeof(float), st, a, b, partials, P, C);
+        hipLaunchKernelGGL((hw_dot_kernel<true, false>), dim3(nb, N), dim3(256), 1024 * sizeof(float), st, a, b, partials, P, C, none);
     else
-        hipLaunchKernelGGL(hw_dot_kernel<false>, dim3(nb, N), dim3(256), 1024 * sizeof(float), st, a, b, partials, P, C);
+        hipLaunchKernelGGL((hw_dot_kernel<false, false>), dim3(nb, N), dim3(256), 1024 * sizeof(float), st, a, b, partials, P, C, none);
+    launch_colsum(partials, d, nb, N * C, N * C, 0, st);
+    RICK_LAUNCH_STATUS();
+}
+
+extern "C" int rick_hw_dot_act_f32(const float *g, const float *y, float *d, int N, int64_t P, int C, const float *bias,
+                                   const float *noise, const float *noise_w, int noise_nb, float slope, float gain,
+                                   float *partials, void *stream) {
+    if (!g || !y || !d || !partials || N <= 0 || P <= 0 || C <= 0 || N > 65535 || (C & 3) || gain == 0.f || slope == 0.f)
+        return RICK_EINVAL;
+    if ((((uintptr_t)g | (uintptr_t)y | (uintptr_t)(bias ? bias : g)) % 16) || (noise && (!noise_w || (noise_nb != 1 && noise_nb != N))))
+        return RICK_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = rick_hw_dot_blocks(P);
+    const HwDotAct t = {bias, noise, noise_w, noise_nb, 1.f / gain, 1.f / (gain * slope)};
+    hipLaunchKernelGGL((hw_dot_kernel<true, true>), dim3(nb, N), dim3(256), 1024 * sizeof(float), st, g, y, partials, P, C, t);
     launch_colsum(partials, d, nb, N * C, N * C, 0, st);
     RICK_LAUNCH_STATUS();
 }

@@ -156,9 +156,11 @@ class ModulatedConv2d(nn.Module):
             if self.upsample:
                 y = self.blur(y)
             return op.chan_scale(y, d) if d is not None else y
+        if tail is not None and not self.upsample and self.out_channel % 4 == 0:
+            return _mc.modulated_conv_fused(x, w, s, d, self.scale, False, key, tail)     # tail in the conv epilogue
         y = _mc.modulated_conv_fused(x, w, s, d, self.scale, self.upsample, key)
         if tail is not None and self.upsample:
-            return op.upfirdn2d_noise_bias_act(y, self.blur.kernel, self.blur.pad, *tail)
+            return op.upfirdn2d_noise_bias_act(y, self.blur.kernel, self.blur.pad, *tail)  # tail in the blur launch
         y = self.blur(y) if self.upsample else y
         return y if tail is None else fused_noise_bias_act(y, *tail)
 

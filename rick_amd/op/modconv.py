@@ -19,7 +19,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .._lib import check, lib, ptr, require_cuda_f32, stream_ptr
-from .conv import _conv_launch, _convT_launch, _pack, _wgrad_launch, conv2d, conv_transpose2d
+from .conv import _conv_launch, _convT_launch, _epilogue, _pack, _wgrad_launch, conv2d, conv_transpose2d
 from .misc import _chan_scale_raw, _hw_dot_raw, chan_scale
 
 
@@ -86,29 +86,44 @@ def demod_coeff_fused(w, s, wscale, eps=1e-8):
 
 
 class _ModConvFused(Function):
+    """Fused modulated convolution.  With `tail` = (bias, noise, noise_weight, slope, gain) and a plain (non-upsampling)
+    layer, StyledConv's NoiseInjection + bias + LeakyReLU run in the MFMA kernel's epilogue as well, and the output is
+    the activation; the backward then starts with the activation adjoint and reconstructs the pre-tail values it needs
+    for the demodulation gradient from the saved activation (rick_hw_dot_act_f32)."""
+
     @staticmethod
-    def forward(ctx, x, w, s, d, wscale, upsample, key):
+    def forward(ctx, x, w, s, d, wscale, upsample, key, bias, noise, nw, slope, gain):
         O, I, kh, kw = w.shape
         s = s.contiguous()
         d = d.contiguous() if d is not None else None
+        tail = bias is not None
         wp = _pack(w, wscale, key and (key[0], key[1] + ('/convT' if upsample else '/conv')))
         if upsample:
+            if tail:
+                raise RuntimeError('the fused tail of an upsampling layer belongs to its blur (upfirdn2d_noise_bias_act)')
             oh, ow = (x.shape[2] - 1) * 2 + kh, (x.shape[3] - 1) * 2 + kw
             y = _convT_launch(x, wp, O, kh, kw, 2, 0, (oh, ow), iscale=s, oscale=d)
+        elif tail:
+            bias, noise, nw = bias.contiguous(), noise.contiguous(), nw.contiguous()
+            y = _conv_launch(x, wp, O, kh, kw, 1, kh // 2, iscale=s, oscale=d, epi=_epilogue(bias, noise, nw, slope, gain))
         else:
             y = _conv_launch(x, wp, O, kh, kw, 1, kh // 2, iscale=s, oscale=d)
-        ctx.save_for_backward(x, w, s, d, y)
-        ctx.cfg = (wscale, upsample, key)
+        ctx.save_for_backward(x, w, s, d, y, *((bias, noise, nw) if tail else ()))
+        ctx.cfg = (wscale, upsample, key, tail, slope, gain)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        x, w, s, d, y = ctx.saved_tensors
-        wscale, upsample, key = ctx.cfg
+        x, w, s, d, y = ctx.saved_tensors[:5]
+        wscale, upsample, key, tail, slope, gain = ctx.cfg
         O, I, kh, kw = w.shape
         g = g.contiguous(memory_format=torch.channels_last)
-        gx = gs = gw = gd = None
+        gx = gs = gw = gd = gb = gnw = None
+        if tail:
+            from .fused_act import _ActAdjoint
+            bias, noise, nw = ctx.saved_tensors[5:]
+            g, gb, gnw = _ActAdjoint.apply(g, y, noise, slope, gain, ctx.needs_input_grad[7], ctx.needs_input_grad[9])
         wT = w.transpose(0, 1)
         wpT = _pack(wT, wscale, key and (key[0], key[1] + '/T'))
         # unscaled data gradient: gx' = W^T (g * d)
@@ -126,9 +141,27 @@ class _ModConvFused(Function):
             else:
                 gw = _wgrad_launch(g, x, kh, kw, 1, kh // 2, wscale, ascale=d, bscale=s)
         if d is not None and ctx.needs_input_grad[3]:
-            gd = _hw_dot_raw(g, y) / d          # y = d * y'  ->  sum g*y' = (sum g*y) / d,  d > 0
-        return gx, gw, gs, gd, None, None, None
+            # conv_out = d * y'  ->  sum g*y' = (sum g*conv_out) / d,  d > 0
+            if tail:
+                gd = _hw_dot_act_raw(g, y, bias, noise, nw, slope, gain) / d
+            else:
+                gd = _hw_dot_raw(g, y) / d
+        return (gx, gw, gs, gd, None, None, None, gb if ctx.needs_input_grad[7] else None, None,
+                gnw if ctx.needs_input_grad[9] else None, None, None)
 
 
-def modulated_conv_fused(x, w, s, d, wscale, upsample, key=None):
-    return _ModConvFused.apply(x, w, s, d, float(wscale), bool(upsample), key)
+def _hw_dot_act_raw(g, y, bias, noise, nw, slope, gain):
+    n, c, h, w = g.shape
+    out = torch.empty((n, c), device=g.device, dtype=g.dtype)
+    part = torch.empty(lib.rick_hw_dot_blocks(h * w) * n * c, device=g.device, dtype=g.dtype)
+    check(lib.rick_hw_dot_act_f32(ptr(g), ptr(y), ptr(out), n, h * w, c, ptr(bias), ptr(noise), ptr(nw), noise.shape[0],
+                                  float(slope), float(gain), ptr(part), stream_ptr()), 'rick_hw_dot_act_f32')
+    return out
+
+
+def modulated_conv_fused(x, w, s, d, wscale, upsample, key=None, tail=None):
+    """tail = (bias, noise, noise_weight, negative_slope, gain) fuses StyledConv's activation tail (plain layers only)."""
+    if tail is None:
+        return _ModConvFused.apply(x, w, s, d, float(wscale), bool(upsample), key, None, None, None, 0.2, 1.0)
+    bias, noise, nw, slope, gain = tail
+    return _ModConvFused.apply(x, w, s, d, float(wscale), bool(upsample), key, bias, noise, nw, float(slope), float(gain))

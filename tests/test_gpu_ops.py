@@ -419,3 +419,33 @@ def test_blur_noise_bias_act_fused_equals_two_pass(N, C, H, pad, nb):
     g = torch.randn(y1.shape, generator=gen).to(DEV)
     for a, c in zip(torch.autograd.grad(y1, [x, b, nw], g), torch.autograd.grad(y2, [x, b, nw], g)):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize('B,I,O,H,nb', [(2, 16, 24, 9, 2), (4, 512, 512, 8, 1), (3, 64, 128, 32, 3), (4, 128, 128, 64, 4)])
+def test_modconv_fused_tail_equals_two_pass(B, I, O, H, nb):
+    """Plain StyledConv with NoiseInjection + bias + LeakyReLU in the conv epilogue: forward bit-identical to
+    modulated_conv_fused -> fused_noise_bias_act; gradients identical except the demodulation gradient, which is
+    rebuilt from the saved activation (rick_hw_dot_act_f32) and agrees to rounding."""
+    from rick_amd import op
+    from rick_amd.op.modconv import modulated_conv_fused
+    gen = torch.Generator().manual_seed(B * 100 + I + O + H)
+    mk = lambda *s: torch.randn(*s, generator=gen).to(DEV)         # noqa: E731
+    x = mk(B, I, H, H).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = mk(O, I, 3, 3).requires_grad_(True)
+    s = (mk(B, I) * 0.5 + 1).requires_grad_(True)
+    d = (torch.rand(B, O, generator=gen).to(DEV) + 0.5).requires_grad_(True)
+    b = mk(O).requires_grad_(True)
+    nw = torch.tensor([0.4], device=DEV, requires_grad=True)
+    noise = mk(nb if nb == 1 else B, 1, H, H)
+    scale = 1.0 / (I * 9) ** 0.5
+    y1 = op.fused_noise_bias_act(modulated_conv_fused(x, w, s, d, scale, False), b, noise, nw)
+    y2 = modulated_conv_fused(x, w, s, d, scale, False, None, (b, noise, nw, 0.2, 2 ** 0.5))
+    assert torch.equal(y1, y2)
+    g = mk(*y1.shape)
+    g1 = torch.autograd.grad(y1, [x, w, s, d, b, nw], g)
+    g2 = torch.autograd.grad(y2, [x, w, s, d, b, nw], g)
+    for k, (a, c) in enumerate(zip(g1, g2)):
+        if k == 3:
+            assert rel_err(c, a) < 2e-5
+        else:
+            assert torch.equal(a, c), k
