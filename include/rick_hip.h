@@ -197,6 +197,9 @@ int rick_chan_scale_f32(const float *x, const float *s, float *y, int N, int64_t
 int rick_hw_dot_blocks(int64_t P);
 int rick_hw_dot_f32(const float *a, const float *b, float *d, int N, int64_t P, int C,
                     float *partials, void *stream);
+/* rick_hw_dot_f32 that also writes scaled[n,p,c] = a[n,p,c] * scale[n,c] in the same pass (C % 4 == 0). */
+int rick_hw_dot_scale_f32(const float *a, const float *b, float *d, const float *scale, float *scaled, int N,
+                          int64_t P, int C, float *partials, void *stream);
 /* d[n,c] = sum_p g[n,p,c] * (lrelu^-1(y[n,p,c]) - noise_w[0]*noise[n % noise_nb][p] - bias[c]) where y is the output
  * of a fused tail gain*lrelu_slope(v + bias + noise_w*noise): the sum over pixels of g times the PRE-tail value v,
  * without keeping v (demodulation gradient of the fused StyledConv).  C % 4 == 0; partials as rick_hw_dot_f32. */

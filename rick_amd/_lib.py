@@ -66,6 +66,7 @@ SIGNATURES = {
     'rick_chan_scale_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_fp]),
     'rick_hw_dot_blocks': (c_int, [c_i64]),
     'rick_hw_dot_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_fp, c_fp]),
+    'rick_hw_dot_scale_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_fp, c_fp]),
     'rick_hw_dot_act_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_fp, c_fp]),
     'rick_add_scale_f32': (c_int, [c_fp, c_fp, c_fp, c_i64, c_f, c_fp]),
     'rick_mbstd_fwd_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),

@@ -344,6 +344,8 @@ struct HwDotAct {
     const float *bias, *noise, *noise_w;
     int noise_nb;
     float inv_gain, inv_gain_slope;
+    const float *scale;   // SCALE variant: [N][C] factor of the extra output
+    float *scaled;        // SCALE variant: scaled[n,p,c] = a[n,p,c] * scale[n,c] written in the same pass
 };
 
 __device__ __forceinline__ float4 hwdot_unact(float4 y, float4 bias, float nv, const HwDotAct &t) {
@@ -355,7 +357,7 @@ __device__ __forceinline__ float4 hwdot_unact(float4 y, float4 bias, float nv, c
     return r;
 }
 
-template <bool VEC4, bool ACT>
+template <bool VEC4, bool ACT, bool SCALE = false>
 __global__ __launch_bounds__(256) void hw_dot_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                      float *__restrict__ partials, int64_t P, int C, HwDotAct t) {
     extern __shared__ float lds[];   // [256 * 4]
@@ -378,6 +380,12 @@ __global__ __launch_bounds__(256) void hw_dot_kernel(const float *__restrict__ a
             float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
             float nwv = 0.f;
             const float *nz = nullptr;
+            float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            float *cp = nullptr;
+            if (SCALE) {
+                sc4 = *reinterpret_cast<const float4 *>(t.scale + (int64_t)n * C + (cbase + lane_c) * 4);
+                cp = t.scaled + (int64_t)n * P * C + p * C + (int64_t)(cbase + lane_c) * 4;
+            }
             if (ACT) {
                 if (t.bias) bias4 = *reinterpret_cast<const float4 *>(t.bias + (cbase + lane_c) * 4);
                 if (t.noise) {
@@ -401,9 +409,13 @@ __global__ __launch_bounds__(256) void hw_dot_kernel(const float *__restrict__ a
                     for (int u = 0; u < 4; u++) {
                         acc[0] += av[u].x * bv[u].x; acc[1] += av[u].y * bv[u].y;
                         acc[2] += av[u].z * bv[u].z; acc[3] += av[u].w * bv[u].w;
+                        if (SCALE)
+                            *reinterpret_cast<float4 *>(cp + u * step) =
+                                make_float4(av[u].x * sc4.x, av[u].y * sc4.y, av[u].z * sc4.z, av[u].w * sc4.w);
                     }
                     ap += 4 * step;
                     bp += 4 * step;
+                    if (SCALE) cp += 4 * step;
                 }
             for (; p < p1; p += rpb) {
                 if (VEC4) {
@@ -411,6 +423,10 @@ __global__ __launch_bounds__(256) void hw_dot_kernel(const float *__restrict__ a
                     float4 bv = *reinterpret_cast<const float4 *>(bp);
                     if (ACT) bv = hwdot_unact(bv, bias4, nz ? nwv * nz[p] : 0.f, t);
                     acc[0] += av.x * bv.x; acc[1] += av.y * bv.y; acc[2] += av.z * bv.z; acc[3] += av.w * bv.w;
+                    if (SCALE) {
+                        *reinterpret_cast<float4 *>(cp) = make_float4(av.x * sc4.x, av.y * sc4.y, av.z * sc4.z, av.w * sc4.w);
+                        cp += step;
+                    }
                 } else {
                     acc[0] += ap[0] * bp[0];
                 }
@@ -435,11 +451,25 @@ extern "C" int rick_hw_dot_f32(const float *a, const float *b, float *d, int N, 
     if (!a || !b || !d || !partials || N <= 0 || P <= 0 || C <= 0 || N > 65535) return RICK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nb = rick_hw_dot_blocks(P);
-    const HwDotAct none = {nullptr, nullptr, nullptr, 1, 1.f, 1.f};
+    const HwDotAct none = {nullptr, nullptr, nullptr, 1, 1.f, 1.f, nullptr, nullptr};
     if (C % 4 == 0 && (((uintptr_t)a | (uintptr_t)b) % 16 == 0))
         hipLaunchKernelGGL((hw_dot_kernel<true, false>), dim3(nb, N), dim3(256), 1024 * sizeof(float), st, a, b, partials, P, C, none);
     else
         hipLaunchKernelGGL((hw_dot_kernel<false, false>), dim3(nb, N), dim3(256), 1024 * sizeof(float), st, a, b, partials, P, C, none);
+    launch_colsum(partials, d, nb, N * C, N * C, 0, st);
+    RICK_LAUNCH_STATUS();
+}
+
+// d[n,c] = sum_p a*b  and  scaled[n,p,c] = a[n,p,c] * scale[n,c] in ONE pass over a (modulated-conv backward: the style
+// gradient and the style-scaled data gradient both come from the unscaled data gradient).
+extern "C" int rick_hw_dot_scale_f32(const float *a, const float *b, float *d, const float *scale, float *scaled, int N,
+                                     int64_t P, int C, float *partials, void *stream) {
+    if (!a || !b || !d || !scale || !scaled || !partials || N <= 0 || P <= 0 || C <= 0 || N > 65535 || (C & 3)) return RICK_EINVAL;
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)scale | (uintptr_t)scaled) % 16) return RICK_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = rick_hw_dot_blocks(P);
+    const HwDotAct t = {nullptr, nullptr, nullptr, 1, 1.f, 1.f, scale, scaled};
+    hipLaunchKernelGGL((hw_dot_kernel<true, false, true>), dim3(nb, N), dim3(256), 1024 * sizeof(float), st, a, b, partials, P, C, t);
     launch_colsum(partials, d, nb, N * C, N * C, 0, st);
     RICK_LAUNCH_STATUS();
 }
@@ -453,7 +483,7 @@ extern "C" int rick_hw_dot_act_f32(const float *g, const float *y, float *d, int
         return RICK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nb = rick_hw_dot_blocks(P);
-    const HwDotAct t = {bias, noise, noise_w, noise_nb, 1.f / gain, 1.f / (gain * slope)};
+    const HwDotAct t = {bias, noise, noise_w, noise_nb, 1.f / gain, 1.f / (gain * slope), nullptr, nullptr};
     hipLaunchKernelGGL((hw_dot_kernel<true, true>), dim3(nb, N), dim3(256), 1024 * sizeof(float), st, g, y, partials, P, C, t);
     launch_colsum(partials, d, nb, N * C, N * C, 0, st);
     RICK_LAUNCH_STATUS();

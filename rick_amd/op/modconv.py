@@ -131,10 +131,13 @@ class _ModConvFused(Function):
             gxu = _conv_launch(g, wpT, I, kh, kw, 2, 0, iscale=d)
         else:
             gxu = _convT_launch(g, wpT, I, kh, kw, 1, kh // 2, (x.shape[2], x.shape[3]), iscale=d)
-        if ctx.needs_input_grad[2]:
-            gs = _hw_dot_raw(gxu, x)
-        if ctx.needs_input_grad[0]:
-            gx = _chan_scale_raw(gxu, s)
+        if ctx.needs_input_grad[2] and ctx.needs_input_grad[0] and I % 4 == 0:
+            gs, gx = _hw_dot_scale_raw(gxu, x, s)          # one pass over gxu: style gradient + scaled data gradient
+        else:
+            if ctx.needs_input_grad[2]:
+                gs = _hw_dot_raw(gxu, x)
+            if ctx.needs_input_grad[0]:
+                gx = _chan_scale_raw(gxu, s)
         if ctx.needs_input_grad[1]:
             if upsample:   # convT: gw[o,i,k] = sum x[pos,i] g[pos*2+k, o]  (a = x, b = g), transposed back
                 gw = _wgrad_launch(x, g, kh, kw, 2, 0, wscale, ascale=s, bscale=d).transpose(0, 1)
@@ -148,6 +151,19 @@ class _ModConvFused(Function):
                 gd = _hw_dot_raw(g, y) / d
         return (gx, gw, gs, gd, None, None, None, gb if ctx.needs_input_grad[7] else None, None,
                 gnw if ctx.needs_input_grad[9] else None, None, None)
+
+
+def _hw_dot_scale_raw(a, b, scale):
+    """(sum_hw a*b [N,C], a * scale[n,c]) from one read of a."""
+    a = a.contiguous(memory_format=torch.channels_last)
+    b = b.contiguous(memory_format=torch.channels_last)
+    n, c, h, w = a.shape
+    out = torch.empty((n, c), device=a.device, dtype=a.dtype)
+    scaled = torch.empty_like(a)
+    part = torch.empty(lib.rick_hw_dot_blocks(h * w) * n * c, device=a.device, dtype=a.dtype)
+    check(lib.rick_hw_dot_scale_f32(ptr(a), ptr(b), ptr(out), ptr(scale), ptr(scaled), n, h * w, c, ptr(part), stream_ptr()),
+          'rick_hw_dot_scale_f32')
+    return out, scaled
 
 
 def _hw_dot_act_raw(g, y, bias, noise, nw, slope, gain):
