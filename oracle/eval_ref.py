@@ -28,3 +28,22 @@ def frechet_distance_ref(mu1, sigma1, mu2, sigma2, eps=1e-6):
             raise ValueError('Imaginary component {}'.format(np.max(np.abs(covmean.imag))))
         covmean = covmean.real
     return diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean)
+
+
+def polynomial_mmd2_ref(codes_g, codes_r, degree=3, gamma=None, coef0=1):
+    """Unbiased MMD^2 with k(x, y) = (gamma <x, y> + coef0)^degree (gan_metrics/kid_score.py:276-346, mmd_est='unbiased')."""
+    x, y = np.asarray(codes_g, dtype=np.float64), np.asarray(codes_r, dtype=np.float64)
+    gam = 1.0 / x.shape[1] if gamma is None else gamma
+    k_xx, k_yy, k_xy = (gam * x @ x.T + coef0) ** degree, (gam * y @ y.T + coef0) ** degree, (gam * x @ y.T + coef0) ** degree
+    m = x.shape[0]
+    return ((k_xx.sum() - np.trace(k_xx)) + (k_yy.sum() - np.trace(k_yy))) / (m * (m - 1)) - 2 * k_xy.sum() / (m * m)
+
+
+def kid_ref(codes_g, codes_r, n_subsets, subset_size, rng):
+    """polynomial_mmd_averages (:255-273): subsets drawn generator-first with rng.choice(n, subset_size, replace=False)."""
+    mmds = np.zeros(n_subsets)
+    for i in range(n_subsets):
+        g = codes_g[rng.choice(len(codes_g), subset_size, replace=False)]
+        r = codes_r[rng.choice(len(codes_r), subset_size, replace=False)]
+        mmds[i] = polynomial_mmd2_ref(g, r)
+    return mmds

@@ -89,3 +89,37 @@ def test_fid_loop_on_device_matches_oracle():
     fm, fs = activation_statistics_ref(feature_fn(ref_img).numpy())
     ref = frechet_distance_ref(fm, fs, rm, rs)
     assert abs(fid - ref) <= 2e-3 * abs(ref), (fid, ref)
+
+
+def _kid_case(g):
+    return (g['kid/codes_g'], g['kid/codes_r'], int(g['kid/n_subsets']), int(g['kid/subset_size']), int(g['kid/seed']),
+            g['kid/mmds'])
+
+
+def test_oracle_kid_vs_reference_golden(golden):
+    """gan_metrics/kid_score.py polynomial_mmd_averages, seeded through NumPy's global generator, vs the restatement."""
+    from oracle.eval_ref import kid_ref
+    cg, cr, ns, ss, seed, mmds = _kid_case(golden('fid'))
+    got = kid_ref(cg, cr, ns, ss, np.random.RandomState(seed))
+    assert np.abs(got - mmds).max() <= 1e-9 * np.abs(mmds).max()
+
+
+def _check_kid(golden, dev):
+    from rick_amd.evaluate import kid_from_features
+    cg, cr, ns, ss, seed, mmds = _kid_case(golden('fid'))
+    mean, std, got = kid_from_features(torch.from_numpy(cg).to(dev), torch.from_numpy(cr).to(dev), n_subsets=ns,
+                                       subset_size=ss, rng=np.random.RandomState(seed))
+    assert np.abs(got.cpu().numpy() - mmds).max() <= 1e-9 * np.abs(mmds).max()
+    assert abs(float(mean) - mmds.mean()) <= 1e-9 * abs(mmds.mean()) and abs(float(std) - mmds.std()) <= 1e-8 * mmds.std()
+
+
+def test_kid_host(golden):
+    _check_kid(golden, 'cpu')
+    from rick_amd.evaluate import kid_from_features
+    with pytest.raises(RuntimeError):
+        kid_from_features(torch.zeros(10, 4), torch.zeros(10, 4), n_subsets=1, subset_size=11)
+
+
+@pytest.mark.gpu
+def test_kid_gpu(golden):
+    _check_kid(golden, 'cuda')

@@ -314,6 +314,24 @@ def gen_fid():
         out[f'{tag}/act0'], out[f'{tag}/act1'] = act0, act1
         out[f'{tag}/mu0'], out[f'{tag}/sigma0'], out[f'{tag}/mu1'], out[f'{tag}/sigma1'] = m0, s0, m1, s1
         out[f'{tag}/fid'] = np.float64(frechet(m0, s0, m1, s1))
+    # KID (gan_metrics/kid_score.py): the reference's own polynomial_mmd_averages / polynomial_mmd / _mmd2_and_variance,
+    # cut out of the file (its module imports torchvision and PIL), seeded through NumPy's global generator
+    import io
+    import sys as _sys
+    from sklearn.metrics.pairwise import polynomial_kernel
+    from tqdm import tqdm
+    ksrc = open(os.path.join(REF, 'gan_metrics', 'kid_score.py')).read()
+    want = {'_sqn', 'polynomial_mmd_averages', 'polynomial_mmd', '_mmd2_and_variance'}
+    kfns = [n for n in ast.parse(ksrc).body if isinstance(n, ast.FunctionDef) and n.name in want]
+    kns = {'np': np, 'polynomial_kernel': polynomial_kernel, 'tqdm': tqdm, 'sys': _sys}
+    exec(compile(ast.Module(body=kfns, type_ignores=[]), 'kid_score.py', 'exec'), kns)
+    # activations are collected in np.empty((n, dims)) — float64 — exactly like the FID path (kid_score.py:199,229)
+    cg = (rng.randn(300, 48) * 0.8 + 0.2).astype(np.float32).astype(np.float64)
+    cr = (rng.randn(260, 48)).astype(np.float32).astype(np.float64)
+    np.random.seed(12)
+    mmds, _vars = kns['polynomial_mmd_averages'](cg, cr, n_subsets=6, subset_size=100, output=io.StringIO())
+    out['kid/codes_g'], out['kid/codes_r'], out['kid/mmds'] = cg, cr, mmds
+    out['kid/seed'], out['kid/n_subsets'], out['kid/subset_size'] = np.int64(12), np.int64(6), np.int64(100)
     np.savez_compressed(os.path.join(OUT, 'fid.npz'), **out)
     print('fid.npz:', {k: float(v) for k, v in out.items() if k.endswith('/fid')})
 
