@@ -235,7 +235,7 @@ static int igemm_tile_positions(const rick_conv_geom *g) { return (g->is >= 2 &&
 // plan minimises  waves x (k-steps per block + fixed block cost)  over the split factor — e.g. 128 output tiles
 // with 16 chunks run best as 4 splits (exactly one wave of 512 blocks: measured 69 us vs 82 us for 6 splits).
 static void igemm_plan_split(ConvTiling *t, int ntaps) {
-    static const int fixed = getenv("RICK_SPLITK_FIXED") ? atoi(getenv("RICK_SPLITK_FIXED")) : 12;
+    static const int fixed = getenv("RICK_SPLITK_FIXED") ? atoi(getenv("RICK_SPLITK_FIXED")) : 32;
     const int base = t->ntx * t->nty * t->ntn * t->ncot;
     if (t->nchunks < 2) return;
     int best_cps = t->nchunks, best_cost = 1 << 30;
