@@ -47,3 +47,19 @@ def kid_ref(codes_g, codes_r, n_subsets, subset_size, rng):
         r = codes_r[rng.choice(len(codes_r), subset_size, replace=False)]
         mmds[i] = polynomial_mmd2_ref(g, r)
     return mmds
+
+
+def precision_recall_ref(feats_real, feats_fake, k=3):
+    """gan_metrics/precision_recall.py:50-66,185-246: k-NN ball manifolds of both sets, precision = fake-in-real,
+    recall = real-in-fake."""
+    def dist(a, b):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        d2 = (a ** 2).sum(1, keepdims=True) - 2 * a @ b.T + (b ** 2).sum(1, keepdims=True).T
+        return np.sqrt(np.maximum(d2, 0))
+
+    def radii(x):
+        return np.sort(dist(x, x), axis=1)[:, k]
+
+    def metric(ref, ref_radii, subj):
+        return float((dist(ref, subj) < ref_radii[:, None]).any(0).mean())
+    return metric(feats_real, radii(feats_real), feats_fake), metric(feats_fake, radii(feats_fake), feats_real)

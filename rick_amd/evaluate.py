@@ -159,3 +159,36 @@ def kid_from_features(codes_g, codes_r, n_subsets=100, subset_size=1000, degree=
         kt_yy = k_yy.sum() - torch.diagonal(k_yy).sum()
         mmds[i] = (kt_xx + kt_yy) / (m * (m - 1)) - 2 * k_xy.sum() / (m * m)
     return mmds.mean(), mmds.std(unbiased=False), mmds
+
+
+@torch.no_grad()
+def precision_recall_from_features(feats_real, feats_fake, k=3, block=4096):
+    """Improved precision / recall (gan_metrics/precision_recall.py:50-66, 185-246) on the device.
+
+    Each set defines a manifold = union of balls around its features with radius = distance to the k-th nearest
+    neighbour in the same set; precision = share of fake features inside the real manifold, recall = share of real
+    features inside the fake one.  The reference builds the N x N distance matrices with NumPy on the host and loops
+    over rows; here they are fp64 GEMM blocks on the device (`block` columns at a time) reduced with kthvalue / any.
+    Returns (precision, recall) as 0-dim device tensors."""
+    xr, xf = feats_real.to(torch.float64), feats_fake.to(torch.float64)
+    if xr.shape[1] != xf.shape[1]:
+        raise RuntimeError('precision_recall_from_features: feature dimensions differ')
+    if min(xr.shape[0], xf.shape[0]) <= k:
+        raise RuntimeError('precision_recall_from_features: need more than k samples per set')
+
+    def dist(a, b):                       # [len(a), len(b)] Euclidean distances, negative round-off clamped like the reference
+        d2 = (a * a).sum(1, keepdim=True) - 2 * (a @ b.t()) + (b * b).sum(1).unsqueeze(0)
+        return d2.clamp_min(0).sqrt()
+
+    def radii(x):                         # k-th neighbour = (k+1)-th smallest of the row (the closest one is the point itself)
+        out = torch.empty(x.shape[0], dtype=torch.float64, device=x.device)
+        for lo in range(0, x.shape[0], block):
+            out[lo:lo + block] = dist(x[lo:lo + block], x).kthvalue(k + 1, dim=1).values
+        return out
+
+    def covered(ref, ref_radii, subj):    # share of subjects inside at least one ball of the reference manifold
+        hit = 0
+        for lo in range(0, subj.shape[0], block):
+            hit = hit + (dist(ref, subj[lo:lo + block]) < ref_radii.unsqueeze(1)).any(0).sum()
+        return hit.to(torch.float64) / subj.shape[0]
+    return covered(xr, radii(xr), xf), covered(xf, radii(xf), xr)

@@ -123,3 +123,31 @@ def test_kid_host(golden):
 @pytest.mark.gpu
 def test_kid_gpu(golden):
     _check_kid(golden, 'cuda')
+
+
+@pytest.mark.parametrize('k', [3, 5])
+def test_oracle_precision_recall_vs_reference_golden(golden, k):
+    from oracle.eval_ref import precision_recall_ref
+    g = golden('fid')
+    assert np.allclose(precision_recall_ref(g['pr/real'], g['pr/fake'], k), g[f'pr/k{k}'], rtol=0, atol=1e-12)
+
+
+def _check_pr(golden, dev):
+    from rick_amd.evaluate import precision_recall_from_features
+    g = golden('fid')
+    for k in (3, 5):
+        p, r = precision_recall_from_features(torch.from_numpy(g['pr/real']).to(dev), torch.from_numpy(g['pr/fake']).to(dev),
+                                              k=k, block=64)          # several column blocks
+        assert np.allclose([float(p), float(r)], g[f'pr/k{k}'], rtol=0, atol=1e-12)
+
+
+def test_precision_recall_host(golden):
+    _check_pr(golden, 'cpu')
+    from rick_amd.evaluate import precision_recall_from_features
+    with pytest.raises(RuntimeError):
+        precision_recall_from_features(torch.zeros(3, 4), torch.zeros(8, 4), k=3)
+
+
+@pytest.mark.gpu
+def test_precision_recall_gpu(golden):
+    _check_pr(golden, 'cuda')

@@ -332,6 +332,22 @@ def gen_fid():
     mmds, _vars = kns['polynomial_mmd_averages'](cg, cr, n_subsets=6, subset_size=100, output=io.StringIO())
     out['kid/codes_g'], out['kid/codes_r'], out['kid/mmds'] = cg, cr, mmds
     out['kid/seed'], out['kid/n_subsets'], out['kid/subset_size'] = np.int64(12), np.int64(6), np.int64(100)
+    # improved precision / recall (gan_metrics/precision_recall.py): the reference's own distance / radius / coverage
+    # functions, cut out of the file (the module imports torchvision and PIL)
+    from collections import namedtuple
+    psrc = open(os.path.join(REF, 'gan_metrics', 'precision_recall.py')).read()
+    pwant = {'compute_pairwise_distances', 'distances2radii', 'get_kth_value', 'compute_metric'}
+    pfns = [n for n in ast.parse(psrc).body if isinstance(n, ast.FunctionDef) and n.name in pwant]
+    pns = {'np': np, 'trange': lambda n, desc='': range(n)}
+    exec(compile(ast.Module(body=pfns, type_ignores=[]), 'precision_recall.py', 'exec'), pns)
+    Manifold = namedtuple('Manifold', ['features', 'radii'])
+    fr = (rng.randn(180, 24)).astype(np.float32)
+    ff = (rng.randn(150, 24) * 0.9 + 0.35).astype(np.float32)
+    for kk in (3, 5):
+        mr = Manifold(fr, pns['distances2radii'](pns['compute_pairwise_distances'](fr), k=kk))
+        mf = Manifold(ff, pns['distances2radii'](pns['compute_pairwise_distances'](ff), k=kk))
+        out[f'pr/k{kk}'] = np.array([pns['compute_metric'](mr, ff), pns['compute_metric'](mf, fr)])
+    out['pr/real'], out['pr/fake'] = fr, ff
     np.savez_compressed(os.path.join(OUT, 'fid.npz'), **out)
     print('fid.npz:', {k: float(v) for k, v in out.items() if k.endswith('/fid')})
 
