@@ -1441,16 +1441,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     }
 }
 
+// Split-K plan of the weight gradient: blocks = co-tiles x chunks x splits, one 400-register block per CU, so the grid
+// runs in waves of 256 blocks.  Minimise  waves x (tiles per block + fixed block cost)  plus a small charge per split
+// for the partial tiles the second stage has to read (measured: 512x512 @64^2, batch 4 runs best as 4 splits of 64
+// tiles = one wave, not 8 x 32).  Multiples of 8 splits get the XCD-aware block mapping and win ties.
 static void wgrad_plan(const rick_conv_geom *g, ConvTiling *t, int *nsplit, int *tps) {
     make_tiling(g, WG_TILE, t);
     const int ntiles = t->ntx * t->nty * t->ntn;
-    int want = 256 / (t->ncot * t->nchunks);   // one block per CU (only one 400-register block is resident)
-    if (want < 1) want = 1;
-    if (want >= 4 && ntiles >= 8) want = (want + 4) / 8 * 8;   // multiple of 8: one set of splits per XCD
-    if (want > ntiles) want = ntiles;
-    *tps = cdiv(ntiles, want);
-    *nsplit = cdiv(ntiles, *tps);
-    if (want % 8 == 0 && *nsplit != want) *nsplit = want;      // keep the multiple of 8 (some splits get fewer tiles)
+    const int cc = t->ncot * t->nchunks;
+    int best_tps = ntiles, best_cost = 1 << 30;
+    const int smax = ntiles < 64 ? ntiles : 64;
+    for (int s = 1; s <= smax; s++) {
+        const int tp = cdiv(ntiles, s), se = cdiv(ntiles, tp);
+        const int waves = cdiv(cc * se, 256);
+        const int cost = 2 * waves * (tp + 8) + se - ((se & 7) == 0 ? 1 : 0);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best_tps = tp;
+        }
+    }
+    *tps = best_tps;
+    *nsplit = cdiv(ntiles, best_tps);
 }
 
 extern "C" int64_t rick_conv_wgrad_workspace_bytes(const rick_conv_geom *g) {
