@@ -192,3 +192,58 @@ def precision_recall_from_features(feats_real, feats_fake, k=3, block=4096):
             hit = hit + (dist(ref, subj[lo:lo + block]) < ref_radii.unsqueeze(1)).any(0).sum()
         return hit.to(torch.float64) / subj.shape[0]
     return covered(xr, radii(xr), xf), covered(xf, radii(xf), xr)
+
+
+class Evaluator:
+    """Device-resident counterpart of ``gan_training.eval.Evaluator`` (eval.py:13-66).
+
+    The reference keeps the real images in ``real_imgs.npy``, generates ``inception_nsamples`` fakes onto the host and
+    hands both image sets to three separate metric modules, each of which runs its own Inception / VGG forward pass.
+    Here the real side is reduced ONCE to features (``real_feats [n, dims]``, any device tensor), every generated batch
+    goes through ``feature_fn`` while it is still on the GPU, and FID / KID / precision-recall are all computed from the
+    same two feature matrices.  ``feature_fn`` is the plug point for the pretrained networks (weights are downloads in
+    the reference; the reference uses Inception pool3 for FID / KID and VGG-16 fc2 for precision-recall — pass
+    ``pr_feature_fn`` / ``real_pr_feats`` to keep that split)."""
+
+    def __init__(self, generator, feature_fn, real_feats, n_sample_store=25, latent=512, inception_nsamples=5000,
+                 fid_sample_size=5000, pr_feature_fn=None, real_pr_feats=None, k=3):
+        self.generator, self.feature_fn, self.real_feats = generator, feature_fn, real_feats
+        self.n_sample_store, self.latent = n_sample_store, latent
+        self.inception_nsamples, self.sample_size, self.k = inception_nsamples, fid_sample_size, k
+        self.pr_feature_fn, self.real_pr_feats = pr_feature_fn, real_pr_feats
+
+    @torch.no_grad()
+    def compute_inception_score(self, fid=True, kid=False, pr=False, latents=None, kid_subsets=100, kid_subset_size=1000,
+                                rng=None):
+        """-> dict with 'fid', 'kid', 'precision', 'recall' (the keys the reference fills, eval.py:44-66)."""
+        g = self.generator
+        dev = next(g.parameters()).device
+        was_training = g.training
+        g.eval()
+        feats, pr_feats, done = [], [], 0
+        while done < self.inception_nsamples:                       # eval.py:34-41: batches of n_sample_store
+            if latents is not None:
+                z = latents[done:done + self.n_sample_store].to(dev)
+            else:
+                z = torch.randn(self.n_sample_store, self.latent, device=dev)
+            img, _ = g([z])
+            feats.append(self.feature_fn(img).reshape(img.shape[0], -1))
+            if pr and self.pr_feature_fn is not None:
+                pr_feats.append(self.pr_feature_fn(img).reshape(img.shape[0], -1))
+            done += img.shape[0]
+        if was_training:
+            g.train()
+        fake = torch.cat(feats, 0)[:self.sample_size]
+        real = self.real_feats.to(dev)
+        score = {}
+        if fid:
+            st_r, st_f = FeatureStats(real.shape[1], dev).update(real), FeatureStats(fake.shape[1], dev).update(fake)
+            score['fid'] = frechet_distance(*st_r.finalize(), *st_f.finalize())
+        if kid:                                                     # eval.py:52-54: the first 2000 of each side
+            score['kid'] = kid_from_features(real[:2000], fake[:2000], n_subsets=kid_subsets, subset_size=kid_subset_size,
+                                             rng=rng)[0]
+        if pr:
+            fr = self.real_pr_feats.to(dev) if self.real_pr_feats is not None else real
+            ff = torch.cat(pr_feats, 0)[:self.sample_size] if pr_feats else fake
+            score['precision'], score['recall'] = precision_recall_from_features(fr, ff, k=self.k)
+        return score

@@ -151,3 +151,39 @@ def test_precision_recall_host(golden):
 @pytest.mark.gpu
 def test_precision_recall_gpu(golden):
     _check_pr(golden, 'cuda')
+
+
+@pytest.mark.gpu
+def test_evaluator_scores_match_oracle():
+    """Evaluator.compute_inception_score (fid + kid + precision/recall from one sampling pass) vs the oracle metrics
+    evaluated on the features of the oracle's images."""
+    from oracle.eval_ref import activation_statistics_ref, frechet_distance_ref, kid_ref, precision_recall_ref
+    from oracle.model_ref import generator_ref
+    from rick_amd.evaluate import Evaluator
+    from rick_amd.models import Generator
+    from rick_amd.synth import synth_latents, synth_state_dict
+    from tests.shapes import generator_shapes
+    size, n = 32, 75
+    g = Generator(size, 512, 8, channel_multiplier=2)
+    g.load_state_dict(synth_state_dict(generator_shapes(size)), strict=False)
+    g = g.to('cuda')
+    fwd = g.forward
+    g.forward = lambda styles, **kw: fwd(styles, randomize_noise=False, **kw)
+    z = synth_latents(n, seed=9)
+    proj = torch.randn(3 * 4 * 4, 12, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+
+    def feature_fn(img):
+        return torch.nn.functional.adaptive_avg_pool2d(img.double(), 4).flatten(1) @ proj.to(img.device)
+    real = torch.randn(90, 12, generator=torch.Generator().manual_seed(4), dtype=torch.float64) * 0.05
+    ev = Evaluator(g, feature_fn, real, n_sample_store=25, inception_nsamples=n, fid_sample_size=n)
+    got = ev.compute_inception_score(fid=True, kid=True, pr=True, latents=z, kid_subsets=4, kid_subset_size=40,
+                                     rng=np.random.RandomState(2))
+    sg = {k: v.double() for k, v in synth_state_dict(generator_shapes(size)).items()}
+    ref_img, _ = generator_ref(sg, [z.double()], size=size, randomize_noise=False)
+    fake = feature_fn(ref_img).numpy()
+    fid_ref = frechet_distance_ref(*activation_statistics_ref(real.numpy()), *activation_statistics_ref(fake))
+    assert abs(float(got['fid']) - fid_ref) <= 5e-3 * abs(fid_ref)
+    kid = kid_ref(real.numpy(), fake, 4, 40, np.random.RandomState(2)).mean()
+    assert abs(float(got['kid']) - kid) <= 5e-3 * abs(kid) + 1e-9
+    p, r = precision_recall_ref(real.numpy(), fake, 3)
+    assert abs(float(got['precision']) - p) <= 0.03 and abs(float(got['recall']) - r) <= 0.03     # counts of 75 / 90 points
