@@ -32,32 +32,52 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(size=256, batch=2):
-    """One non-reg iteration (D step fwd+bwd, G step fwd+bwd) of the CPU oracle at BASELINE configs[0]'s batch 2."""
+def cpu_baseline(size=256, batch=2, timed=2):
+    """Non-reg iterations (D step fwd+bwd, G step fwd+bwd) of the CPU oracle at BASELINE configs[0]'s batch 2 on ALL
+    host cores: one warm-up iteration (oneDNN primitive creation, allocator), then `timed` timed ones."""
     from oracle.model_ref import discriminator_ref, generator_ref
     from oracle.train_ref import d_logistic_loss_ref, g_nonsaturating_loss_ref
     from rick_amd.synth import synth_latents, synth_reals, synth_state_dict
     from tests.shapes import discriminator_shapes, generator_shapes
-    cores = min(os.cpu_count() or 1, 32)      # oneDNN scales poorly past one socket's worth of threads here
+    cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     sg = synth_state_dict(generator_shapes(size))
     sd = synth_state_dict(discriminator_shapes(size))
     pg = [v.requires_grad_(True) for k, v in sg.items() if not k.startswith('noises.')]
     pd = [v.requires_grad_(True) for k, v in sd.items()]
     z, real = synth_latents(batch, seed=11), synth_reals(batch, size=size, seed=11)
-    t0 = time.perf_counter()
-    with torch.no_grad():
+
+    def iteration():
+        with torch.no_grad():
+            fake, _ = generator_ref(sg, [z], size=size)
+        fp, _ = discriminator_ref(sd, fake, size=size)
+        rp, _ = discriminator_ref(sd, real, size=size)
+        torch.autograd.grad(d_logistic_loss_ref(rp, fp), pd)
         fake, _ = generator_ref(sg, [z], size=size)
-    fp, _ = discriminator_ref(sd, fake, size=size)
-    rp, _ = discriminator_ref(sd, real, size=size)
-    torch.autograd.grad(d_logistic_loss_ref(rp, fp), pd)
-    fake, _ = generator_ref(sg, [z], size=size)
-    fp, _ = discriminator_ref(sd, fake, size=size)
-    torch.autograd.grad(g_nonsaturating_loss_ref(fp), pg, allow_unused=True)
-    dt = time.perf_counter() - t0
+        fp, _ = discriminator_ref(sd, fake, size=size)
+        torch.autograd.grad(g_nonsaturating_loss_ref(fp), pg, allow_unused=True)
+
+    iteration()
+    times = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        iteration()
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2] if len(times) % 2 else sum(times) / len(times)
     return {'value': batch / dt, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'1 non-reg iteration (D step + G step, fwd+bwd, no optimiser) at batch {batch}, {size}px, '
-                      f'fp32 oneDNN, {dt:.1f} s'}
+            'sample': f'1 warm-up + {timed} timed non-reg iterations (D step + G step, fwd+bwd, no optimiser) at batch '
+                      f'{batch}, {size}px, fp32 oneDNN on {cores} host threads: ' + ', '.join(f'{t:.1f}' for t in times) + ' s'}
+
+
+def load_traffic():
+    """HBM bytes per conv_igemm launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json,
+    produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes over the bench iteration, FETCH_SIZE
+    doubled as the guide prescribes for 16-B/lane reads on gfx950).  None when the file is absent."""
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get('conv_igemm', {}).get('hbm_bytes_per_launch')
 
 
 def main():
@@ -70,6 +90,8 @@ def main():
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-step-times', action='store_true')
+    ap.add_argument('--no-fisher', action='store_true', help='skip the (untimed) Fisher sweep; masks stay empty (profiling runs)')
     ap.add_argument('--no-graphs', action='store_true', help='issue every launch from Python instead of replaying captured hipGraphs')
     ap.add_argument('--graphs', action='store_true', help='replay captured step graphs also with N > 1 (default: N = 1 only; '
                     'with data parallelism the eager path overlaps the bucketed all-reduce with backward)')
@@ -111,8 +133,9 @@ def main():
     reals = [synth_reals(cfg.batch, cfg.size, seed=100 * rank + j).to(dev) for j in range(4)]
     # steady state: a Fisher sweep has run, masks are active (untimed; it recurs every fisher_freq iterations)
     mine = [j for j in range(cfg.num_fisher_img) if j % world == rank]
-    tr.fisher_sweep([synth_latents(1, seed=500 + j).to(dev) for j in mine],
-                    [synth_reals(1, cfg.size, seed=600 + j).to(dev) for j in mine], first=True)
+    if not args.no_fisher:
+        tr.fisher_sweep([synth_latents(1, seed=500 + j).to(dev) for j in mine],
+                        [synth_reals(1, cfg.size, seed=600 + j).to(dev) for j in mine], first=True)
 
     i0 = cfg.warmup_iter + 1
     use_graphs = (args.graphs or world == 1) and not args.no_graphs
@@ -158,11 +181,40 @@ def main():
                    'first_iteration': i0 + args.warmup},
     }
 
-    if rank == 0 and not args.no_roofline:
-        # instrumented repeat of 4 non-reg + reg iterations: HIP events around every conv-family launch
-        tr.enable_graphs(False)                            # events bracket individual launches: eager issue
+    # ---- per-step-type times (untimed extra pass, every rank runs it so collectives stay matched): HIP events on the
+    # launch stream after every step of 16 more iterations = one full R1 period (4 path-length steps, 1 R1 step)
+    if not args.no_step_times:
+        tr.step_events = []
+        run(16, i0 + args.warmup + args.steps)
+        torch.cuda.synchronize()
+        ev, tr.step_events = tr.step_events, None
+        per, iters, cur, t_begin = {}, [], [], None
+        for (name, e), (_, prev) in zip(ev[1:], ev[:-1]):
+            if name == 'begin':
+                continue
+            per.setdefault(name, []).append(prev.elapsed_time(e))
+        for name, e in ev:
+            if name == 'begin':
+                t_begin, cur = e, []
+            else:
+                cur.append(name)
+                if name == 'ema':
+                    iters.append((t_begin.elapsed_time(e), tuple(cur)))
+        med = lambda v: sorted(v)[len(v) // 2]                                         # noqa: E731
+        nonreg = [t for t, names in iters if 'r1' not in names and 'plr' not in names]
+        out['step_ms'] = {k: med(v) for k, v in per.items()}
+        out['nonreg_iteration'] = {'median_ms': med(nonreg), 'images_per_s': cfg.batch * world / (1e-3 * med(nonreg)),
+                                   'n': len(nonreg), 'note': 'D step + G step + EMA (SURVEY 8d definition), GPU time of this rank'}
+        tot16 = sum(t for t, _ in iters)
+        out['amortised16'] = {'ms_per_iteration': tot16 / len(iters), 'images_per_s': cfg.batch * world * len(iters) / (1e-3 * tot16),
+                              'note': '16 consecutive iterations = 16 D + 16 G + 1 R1 + 4 path-length steps'}
+
+    if not args.no_roofline:
+        # instrumented repeat of 16 iterations: HIP events around every conv-family launch (eager issue; every rank
+        # runs it — the bucketed all-reduces must stay matched — rank 0 reports)
+        tr.enable_graphs(False)
         with launch_profiler() as prof:
-            run(16, i0 + args.warmup + args.steps)
+            run(16, i0 + args.warmup + args.steps + 16)
             torch.cuda.synchronize()
         agg = {}
         by_tag = {}
@@ -176,8 +228,8 @@ def main():
             bt[0] += flops
             bt[1] += dt
             bt[2] += 1
-        if os.environ.get('RICK_BENCH_BREAKDOWN'):
-            for tag, (fl, dt, n) in sorted(by_tag.items(), key=lambda kv: -kv[1][1])[:40]:
+        if os.environ.get('RICK_BENCH_BREAKDOWN') and rank == 0:
+            for tag, (fl, dt, n) in sorted(by_tag.items(), key=lambda kv: -kv[1][1]):
                 print(f'  {tag:44s} n={n:4d} total {dt*1e3/16:7.3f} ms/step  avg {dt/n*1e6:8.1f} us  {fl/dt/1e12:6.1f} TF',
                       file=sys.stderr)
         ig = agg.get('igemm', [0.0, 1.0, 1])
@@ -185,12 +237,14 @@ def main():
         mult = 3.0 if args.precision == 'bf16x3' else 1.0
         out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel', 'achieved': ach,
                            'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 'traffic': None,
+                           'frac': ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 'traffic': load_traffic(),
                            'mfma_issued_frac': mult * ach / MFMA_BF16_DENSE_PEAK_TFLOPS,
                            'launches': ig[2], 'avg_launch_us': 1e6 * ig[1] / max(ig[2], 1),
                            'algorithmic_gflop_per_launch': ig[0] / max(ig[2], 1) / 1e9,
                            'note': 'achieved = algorithmic FLOPs (2*N*OH*OW*Co*Ci*taps) / event-timed duration over '
-                                   '16 instrumented iterations; bf16x3 issues 3 MFMA FLOPs per algorithmic FLOP'}
+                                   '16 instrumented iterations (forward, data-gradient and transposed launches of the '
+                                   'igemm family incl. their split-K second stage); bf16x3 issues 3 MFMA FLOPs per '
+                                   'algorithmic FLOP; traffic = HBM bytes per launch from profiles/r02_pmc_traffic.json'}
         if 'wgrad' in agg:
             wg = agg['wgrad']
             out['roofline']['wgrad_kernel'] = {'achieved': wg[0] / wg[1] / 1e12, 'launches': wg[2],

@@ -162,6 +162,20 @@ int rick_conv_igemm_multi_f32(const float *x, const void *packed_w, float *out,
                               const float *iscale, const float *oscale,
                               const rick_conv_geom *geoms, int ngeom, void *workspace, void *stream);
 
+/* Transposed 3x3 stride-2 convolution, padding 0 — F.conv_transpose2d(stride=2) of the upsampling StyledConvs
+ * (model_probe_tune.py:257-268) and the data gradient of the discriminator's stride-2 3x3 convolutions (:608-630):
+ *   out[n, 2*iy+ky, 2*ix+kx, co] = alpha * oscale[n,co] * sum W[ky*3+kx][co][ci] * (iscale[n,ci] * x[n, iy, ix, ci])
+ * All four output-parity classes come from ONE staged input patch per block (the generic multi-class launch above
+ * stages it once per class).  packed_w = rick_conv_pack_weight(..., nslices = 9); out is [N, OH, OW, Co] with
+ * OH in {2*IH, 2*IH+1} (likewise OW; the smaller size crops the last row / column); Ci % 4 == Co % 4 == 0.
+ * Short grids are split over channel chunks through `workspace` (rick_convt2_workspace_bytes, 0 = not needed). */
+int64_t rick_convt2_workspace_bytes(int N, int IH, int IW, int Ci, int Co, int OH, int OW);
+int rick_convt2_f32(const float *x, const void *packed_w, float *out, const float *iscale, const float *oscale,
+                    int N, int IH, int IW, int Ci, int Co, int OH, int OW, int split, float alpha,
+                    void *workspace, void *stream);
+/* The tile / split plan the launch above will use: out6 = {TW, TH, NB, blocks before the split, nsplit, chunks per split}. */
+int rick_convt2_plan(int N, int IH, int IW, int Ci, int Co, int OH, int OW, int *out6);
+
 /* Weight gradient for the same geometry:
  *   gw[(co, ci, t)] = alpha * sum_{n, pos} (ascale[n,co] * gy[n, outpix(pos), co]) *
  *                                           (bscale[n,ci] * x[n, inpix(pos, t), ci])

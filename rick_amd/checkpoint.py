@@ -89,4 +89,5 @@ def resume(trainer, ckpt):
         load_adam_state_dict(trainer.g_optim, ckpt['g_optim'])
     if 'd_optim' in ckpt:
         load_adam_state_dict(trainer.d_optim, ckpt['d_optim'])
+    trainer.invalidate_graphs()      # captured steps bake in the Adam run grouping of the old step counts
     return ckpt

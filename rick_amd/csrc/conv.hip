@@ -22,55 +22,8 @@
 // lane (row = lane&15, k-group = lane>>4).  16-byte slot index is XOR-swizzled with bit 2 of
 // the row: slot = kg ^ (((row>>2)&1)<<1)  -> conflict-free for 16 consecutive rows at any
 // offset (checked by simulation against the gfx950 ds_read_b128 lane groups).
-#include "common.h"
+#include "conv_common.h"
 #include <stdlib.h>
-#include <type_traits>
-
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef short bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define CV_BM 128
-#define CV_BN 128
-#define CV_CK 32
-#define CV_WTILE_BYTES (CV_BM * CV_CK * 2)      // one of hi / lo: 8 KB
-#define CV_WSTEP_BYTES (2 * CV_WTILE_BYTES)     // hi + lo: 16 KB
-
-__host__ __device__ __forceinline__ int cv_swz(int kg, int row) { return kg ^ (((row >> 2) & 1) << 1); }
-
-__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned pack_bf16_rne(float a, float b) {   // v_cvt_pk_bf16_f32
-    bf16x2_t r = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
-    return *reinterpret_cast<unsigned *>(&r);
-}
-
-// x = hi + lo with hi = x truncated to bf16 (exactly representable, so lo = x - hi is exact in
-// fp32) and lo rounded to nearest bf16: |x - hi - lo| <= 2^-17 |x|, unbiased.  10 VALU ops per 4
-// elements (v_and, v_perm, v_pk_add, v_cvt_pk).  SPLIT == 1 (plain bf16): hi is rounded to nearest.
-template <int SPLIT>
-__device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
-    if (SPLIT == 1) {
-        hi.x = pack_bf16_rne(v.x, v.y);
-        hi.y = pack_bf16_rne(v.z, v.w);
-        lo.x = lo.y = 0;
-        return;
-    }
-    const unsigned ux = __float_as_uint(v.x), uy = __float_as_uint(v.y), uz = __float_as_uint(v.z),
-                   uw = __float_as_uint(v.w);
-    hi.x = __builtin_amdgcn_perm(uy, ux, 0x07060302);
-    hi.y = __builtin_amdgcn_perm(uw, uz, 0x07060302);
-    lo.x = pack_bf16_rne(v.x - __uint_as_float(ux & 0xffff0000u), v.y - __uint_as_float(uy & 0xffff0000u));
-    lo.y = pack_bf16_rne(v.z - __uint_as_float(uz & 0xffff0000u), v.w - __uint_as_float(uw & 0xffff0000u));
-}
 
 // ------------------------------------------------------------------------------------------
 // Weight packing.  Packed layout: block (cotile, chunk, slice) at
@@ -177,6 +130,18 @@ struct ConvTiling {
     int debug;                  // ablation switches for tools/bench_conv.py (RICK_CONV_DEBUG); 0 in production
 };
 
+// Ablation switches (tools/bench_conv.py) exist only in builds made with -DRICK_ABLATION; the production library never
+// reads the environment, so a stray variable cannot change results.
+static int ablation_env(const char *name, int dflt) {
+#ifdef RICK_ABLATION
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 static int ilog2_ceil(int v) {
     int l = 0;
     while ((1 << l) < v) l++;
@@ -215,8 +180,7 @@ static int make_tiling(const rick_conv_geom *g, int tile_positions, ConvTiling *
     t->ncot = cdiv(g->Co, CV_BM);
     t->nsplit = 1;
     t->cps = t->nchunks;
-    const char *dbg = getenv("RICK_CONV_DEBUG");
-    t->debug = dbg ? atoi(dbg) : 0;
+    t->debug = ablation_env("RICK_CONV_DEBUG", 0);
     return 0;
 }
 
@@ -235,7 +199,7 @@ static int igemm_tile_positions(const rick_conv_geom *g) { return (g->is >= 2 &&
 // plan minimises  waves x (k-steps per block + fixed block cost)  over the split factor — e.g. 128 output tiles
 // with 16 chunks run best as 4 splits (exactly one wave of 512 blocks: measured 69 us vs 82 us for 6 splits).
 static void igemm_plan_split(ConvTiling *t, int ntaps) {
-    static const int fixed = getenv("RICK_SPLITK_FIXED") ? atoi(getenv("RICK_SPLITK_FIXED")) : 32;
+    static const int fixed = ablation_env("RICK_SPLITK_FIXED", 32);
     const int base = t->ntx * t->nty * t->ntn * t->ncot;
     if (t->nchunks < 2) return;
     int best_cps = t->nchunks, best_cost = 1 << 30;
@@ -253,13 +217,6 @@ static void igemm_plan_split(ConvTiling *t, int ntaps) {
     t->nsplit = cdiv(t->nchunks, best_cps);
 }
 
-// XCD-aware bijective remap of the linear block id: blocks that share an XCD (id % 8) get a
-// contiguous range of logical tiles, so neighbouring position tiles of one co-tile share L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
-
 // Patch pixel -> (image-in-tile, row, col) table, built once per block so the staging loops need no
 // integer divisions: entry = nbi << 20 | py << 10 | px.
 __device__ __forceinline__ void build_patch_table(unsigned *ptab, const ConvTiling &t) {
@@ -269,32 +226,6 @@ __device__ __forceinline__ void build_patch_table(unsigned *ptab, const ConvTili
         const int rem = pix - nbi * phw;
         const int py = rem / t.PW, px = rem - py * t.PW;
         ptab[pix] = ((unsigned)nbi << 20) | ((unsigned)py << 10) | (unsigned)px;
-    }
-}
-
-// 16-byte load of 4 consecutive channels.  VEC (channel count % 4 == 0): one float4 load from an address
-// that is always safe (callers substitute the tensor base for out-of-range items) — no branch, so the
-// compiler has no reason to wait vmcnt(0) per element.  !VEC: guarded scalar loads (odd channel counts).
-template <bool VEC>
-__device__ __forceinline__ float4 load4(const float *p, bool ok, int c, int C) {
-    if (VEC) return *reinterpret_cast<const float4 *>(p);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok) {
-        v.x = p[0];
-        if (c + 1 < C) v.y = p[1];
-        if (c + 2 < C) v.z = p[2];
-        if (c + 3 < C) v.w = p[3];
-    }
-    return v;
-}
-
-__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &f) {   // f(integral_constant<int, I>) ... f(<N-1>): indices usable as constants
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
     }
 }
 
@@ -876,7 +807,7 @@ static void launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *
                          const ConvTiling &t, const rick_conv_epilogue &epi) {
     // production path (bf16x3, vector loads), 3x3 stride-1 layers with a long channel loop and a full grid: the
     // straight-line 9-tap k-loop (measured +3..8 % there; slower on split-K, short-K and stride-2 launches)
-    static const int no_unroll = getenv("RICK_IGEMM_NOUNROLL") ? atoi(getenv("RICK_IGEMM_NOUNROLL")) : 0;
+    static const int no_unroll = ablation_env("RICK_IGEMM_NOUNROLL", 0);
     const bool u9 = SPLIT == 2 && VEC && g->ntaps == 9 && !no_unroll && !t.debug && igemm_tile_positions(g) == CV_BN &&
                     t.NPP <= IG_DEEP_NPP && t.nsplit == 1 && t.nchunks >= 8;
     if (igemm_tile_positions(g) == 64) launch_igemm_k<SPLIT, VEC, false, 2>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
@@ -1488,7 +1419,7 @@ static size_t wgrad_lds_bytes(const rick_conv_geom *g, const ConvTiling &t, bool
 }
 // The software-pipelined form needs two operand buffers in LDS; production path only (bf16x3, vector loads).
 static bool wgrad_use_pipe(const rick_conv_geom *g, const ConvTiling &t) {
-    static const int off = getenv("RICK_WGRAD_NOPIPE") ? atoi(getenv("RICK_WGRAD_NOPIPE")) : 0;
+    static const int off = ablation_env("RICK_WGRAD_NOPIPE", 0);
     return !off && g->split == 2 && ((g->Ci | g->Co) & 3) == 0 && wgrad_lds_bytes(g, t, true) <= 160 * 1024;
 }
 

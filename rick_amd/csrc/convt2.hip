@@ -1,0 +1,387 @@
+// Transposed 3x3 stride-2 convolution (padding 0) on gfx950 MFMA — every output-parity class from ONE staged patch.
+//
+//   out[n, 2*iy + ky, 2*ix + kx, co] += W[co][ci][ky][kx] * (iscale[n,ci] * x[n, iy, ix, ci])      (* alpha * oscale[n,co])
+//
+// This is F.conv_transpose2d(stride=2) of the upsampling StyledConvs (model_probe_tune.py:257-268) and the data
+// gradient of the discriminator's stride-2 3x3 convolutions (:608-630).  An output pixel of parity (py, px) only
+// receives the taps with ky = py (mod 2), kx = px (mod 2): 4 / 2 / 2 / 1 of the 9 taps.  The generic kernel
+// (conv.hip) runs the four classes as four block ranges and each of them stages and converts (fp32 -> bf16 hi/lo)
+// the same input patch again; here a 512-thread block owns one tile of the input-aligned position grid
+// (gy, gx) in [0, IH] x [0, IW], stages the (TH+1) x (TW+1) patch ONCE per 32-channel chunk, and its 8 waves are
+// (parity class) x (64-channel half of the 128-channel co tile), each with a 64 co x 128 positions accumulator:
+//
+//   wave 0,1: class (0,0), 4 taps   |  wave 4,5: class (1,1), 1 tap      <- waves w and w+4 share a SIMD:
+//   wave 2,3: class (0,1), 2 taps   |  wave 6,7: class (1,0), 2 taps         5 / 5 / 4 / 4 taps per SIMD
+//
+// so all 9 taps of a chunk are multiplied against one staged patch (the same staging : MFMA ratio as a stride-1
+// 3x3 convolution).  Weights are private to a wave (its class's taps, its 64 rows), so they never touch LDS: a wave
+// loads its A fragments straight from the packed image in global memory — the packed layout makes every such
+// load one contiguous, fully used 1 KB — one tap ahead, into the registers the previous tap has just released.
+// The only LDS traffic is the B operand (patch), and the only barrier is one per channel chunk (double-buffered
+// patch).  Precision: bf16x3 (hi*hi + hi*lo + lo*hi, fp32 accumulate) or plain bf16, as in conv.hip.
+#include "conv_common.h"
+
+#define CT_THREADS 512
+#define CT_PITEMS 3                       // patch float4 per thread: up to 192 patch pixels
+#define CT_MAX_NPP (CT_PITEMS * (CT_THREADS / 8))
+
+struct Ct2Plan {
+    int N, IH, IW, Ci, OH, OW, Co;
+    int TW, TH, NB;                 // position tile: TW x TH positions of NB images (TW*TH*NB <= 128)
+    int ntx, nty, ntn;
+    int PH, PW, NPP;                // patch = (TH+1) x (TW+1) input pixels per image, NB images
+    int nchunks, ncot, nsplit, cps;
+    float alpha;
+};
+
+template <int SPLIT>
+__global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restrict__ x,
+                                                           const unsigned char *__restrict__ wpk,
+                                                           float *__restrict__ out, const float *__restrict__ iscale,
+                                                           const float *__restrict__ oscale, float *__restrict__ ws,
+                                                           const Ct2Plan P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int pbuf = P.NPP * 64;                              // one of hi / lo of one patch buffer
+    float *sct = reinterpret_cast<float *>(smem + 4 * pbuf);  // [NB][cps * 32] input scales
+
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int npos_tiles = P.ntx * P.nty * P.ntn;
+    int pt = lid % npos_tiles;
+    const int split = (lid / npos_tiles) % P.nsplit;
+    const int cot = lid / (npos_tiles * P.nsplit);
+    const int c_begin = split * P.cps;
+    const int c_end = c_begin + P.cps < P.nchunks ? c_begin + P.cps : P.nchunks;
+    const int tx_i = pt % P.ntx;
+    pt /= P.ntx;
+    const int ty_i = pt % P.nty;
+    const int tn_i = pt / P.nty;
+    const int gx0 = tx_i * P.TW, gy0 = ty_i * P.TH, n0 = tn_i * P.NB;
+
+    const int cspan = P.cps * CV_CK;
+    for (int i = threadIdx.x; i < P.NB * cspan; i += CT_THREADS) {
+        const int nbi = i / cspan, c = c_begin * CV_CK + (i - nbi * cspan);
+        sct[i] = !iscale ? 1.f : (n0 + nbi < P.N && c < P.Ci) ? iscale[(int64_t)(n0 + nbi) * P.Ci + c] : 0.f;
+    }
+
+    // ---- roles
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int h = wave & 1;                                   // 64-row half of the co tile
+    const int wp = wave >> 1;
+    const int cls = wp ^ (wp >> 1);                           // py*2 + px of wave pairs {0,1},{2,3},{4,5},{6,7}: (0,0) (0,1) (1,1) (1,0)
+    const int py = cls >> 1, px = cls & 1;
+    const int nky = py ? 1 : 2, nkx = px ? 1 : 2;
+    const int ntap = nky * nkx;
+
+    // ---- patch staging state (tile is fixed for the block)
+    const int c4 = threadIdx.x & 7;
+    const int iy0 = gy0 - 1, ix0 = gx0 - 1;                   // input pixel of patch (0, 0)
+    const float *xt = x + (((int64_t)n0 * P.IH + iy0) * P.IW + ix0) * P.Ci + c4 * 4;
+    // item k of a thread is patch pixel (tid >> 3) + 64 k: same swizzle key (bit 2 of the pixel), LDS offset + k * 4096
+    int p_rel[CT_PITEMS];
+    unsigned p_ok = 0, p_nbi = 0;                             // validity bits; image-in-tile of each item, 8 bits each
+    const int pix0 = threadIdx.x >> 3;
+    const int p_lds0 = pix0 * 64 + cv_swz(c4 >> 1, pix0) * 16 + (c4 & 1) * 8;
+    const int phw = P.PH * P.PW;
+#pragma unroll
+    for (int k = 0; k < CT_PITEMS; k++) {
+        const int pix = pix0 + (CT_THREADS / 8) * k;
+        p_rel[k] = 0;
+        if (pix < P.NPP) {
+            const int nbi = pix / phw, rem = pix - nbi * phw;
+            const int ry = rem / P.PW, rx = rem - ry * P.PW;
+            const int n = n0 + nbi, iy = iy0 + ry, ix = ix0 + rx;
+            if (n < P.N && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) {
+                p_ok |= 1u << k;
+                p_nbi |= (unsigned)nbi << (8 * k);
+                p_rel[k] = ((nbi * P.IH + ry) * P.IW + rx) * P.Ci;
+            }
+        }
+    }
+    float4 pq[CT_PITEMS];
+    unsigned cur_ok = 0;
+    auto issue_patch = [&](int chunk) {
+        const int ci = chunk * CV_CK + c4 * 4;
+        cur_ok = ci < P.Ci ? p_ok : 0u;
+#pragma unroll
+        for (int k = 0; k < CT_PITEMS; k++) {
+            const bool ok = (cur_ok >> k) & 1u;
+            pq[k] = *reinterpret_cast<const float4 *>(ok ? xt + p_rel[k] + chunk * CV_CK : x);
+        }
+    };
+    auto commit_patch = [&](int chunk, unsigned char *ph) {
+        unsigned char *pl = ph + pbuf;
+        const float *sc = sct + (chunk - c_begin) * CV_CK + c4 * 4;
+#pragma unroll
+        for (int k = 0; k < CT_PITEMS; k++) {
+            const bool ok = (cur_ok >> k) & 1u;
+            float4 v = mul4(pq[k], *reinterpret_cast<const float4 *>(sc + ((p_nbi >> (8 * k)) & 255u) * cspan));
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 hi, lo;
+            split4<SPLIT>(v, hi, lo);
+            if (pix0 + (CT_THREADS / 8) * k < P.NPP) {        // (a branch around an LDS store is harmless; loads stay unconditional)
+                *reinterpret_cast<uint2 *>(ph + p_lds0 + k * 4096) = hi;
+                if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds0 + k * 4096) = lo;
+            }
+        }
+    };
+
+    // ---- B operand (patch) read offsets: position j*16 + l15 of the tile -> patch pixel (ty + 1, tx + 1).  The same for
+    // every wave; kept in LDS ([l15][8 j] ints, one b128 read per half of the j range) to leave the registers to the MFMAs
+    const int tpos = P.TW * P.TH;
+    int *pbt = reinterpret_cast<int *>(sct + P.NB * cspan);
+    if (threadIdx.x < 128) {
+        const int pos = threadIdx.x;
+        int nbi = pos / tpos;
+        const int rem = pos - nbi * tpos;
+        const int ty = rem / P.TW, tx = rem - ty * P.TW;
+        nbi = nbi < P.NB ? nbi : P.NB - 1;                    // tile slots beyond NB images are masked in the epilogue
+        pbt[(pos & 15) * 8 + (pos >> 4)] = (nbi * P.PH + ty + 1) * P.PW + tx + 1;
+    }
+    const int4 *pbl = reinterpret_cast<const int4 *>(pbt + l15 * 8);
+    // ---- A operand (weights) fragment offset inside one packed 16 KB tap tile: row = h*64 + i*16 + l15
+    const int arow = h * 64 + l15;
+    const int a_off = arow * 64 + cv_swz(kg, arow) * 16;      // + i * 1024 (the swizzle key (row >> 2) & 1 does not depend on i)
+    const unsigned char *wbase = wpk + (int64_t)cot * P.nchunks * 9 * CV_WSTEP_BYTES + a_off;
+    auto tap_slice = [&](int t) {                             // weight slice ky*3 + kx of this class's tap t
+        const int ty = t / nkx, tx = t - ty * nkx;
+        return (py ? 1 : 2 * ty) * 3 + (px ? 1 : 2 * tx);
+    };
+    auto tap_off = [&](int t) {                               // patch offset (dy*PW + dx): ky == 2 reads the row above
+        const int ty = t / nkx, tx = t - ty * nkx;
+        return -((!py && ty) ? P.PW : 0) - ((!px && tx) ? 1 : 0);
+    };
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // A fragments of the NEXT tap roll into the registers the current tap releases: a tap multiplies positions 0-63
+    // (all four 16-row groups), then positions 64-127; in that second half row group i is finished after its 12 MFMAs
+    // and its registers are reloaded at once — 48 MFMAs (>= 768 cycles) before the next tap touches them again.
+    // The order of the groups is pinned with sched_barrier (hipcc otherwise interleaves the groups and ends up waiting
+    // vmcnt(0) for all eight loads at the top of every tap).
+    bf16x8 ahi[4], alo[4];
+    auto load_a = [&](auto IC, const unsigned char *wt) {
+        constexpr int i = decltype(IC)::value;
+        ahi[i] = *reinterpret_cast<const bf16x8 *>(wt + i * 1024);
+        if (SPLIT == 2) alo[i] = *reinterpret_cast<const bf16x8 *>(wt + CV_WTILE_BYTES + i * 1024);
+    };
+    auto mma_tap = [&](const unsigned char *ph, const unsigned char *pl, int toff, const unsigned char *wnext) {
+#pragma unroll
+        for (int jh = 0; jh < 2; jh++) {
+            const int4 pb4 = pbl[jh];
+            const int pbv[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
+            bf16x8 bhi[4], blo[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int pp = pbv[jj] + toff;
+                const int off = pp * 64 + cv_swz(kg, pp) * 16;
+                bhi[jj] = *reinterpret_cast<const bf16x8 *>(ph + off);
+                if (SPLIT == 2) blo[jj] = *reinterpret_cast<const bf16x8 *>(pl + off);
+            }
+            static_for<0, 4>([&](auto IC) {
+                constexpr int i = decltype(IC)::value;
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    f32x4 &a = acc[i][jh * 4 + jj];
+                    if (SPLIT == 2) {
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi[jj], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo[jj], a, 0, 0, 0);
+                    }
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi[jj], a, 0, 0, 0);
+                }
+                if (jh == 1) load_a(IC, wnext);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    };
+
+    // ---- prologue: patch(c_begin) -> buffer 0, A fragments of (c_begin, tap 0)
+    issue_patch(c_begin);
+    {
+        const unsigned char *wt = wbase + ((int64_t)c_begin * 9 + tap_slice(0)) * CV_WSTEP_BYTES;
+        static_for<0, 4>([&](auto IC) { load_a(IC, wt); });
+    }
+    __syncthreads();                                          // scale table and position table complete
+    commit_patch(c_begin, smem);
+    __syncthreads();
+
+    for (int chunk = c_begin; chunk < c_end; chunk++) {
+        const int cur = (chunk - c_begin) & 1;
+        const unsigned char *ph = smem + cur * 2 * pbuf, *pl = ph + pbuf;
+        const int cnext = chunk + 1 < c_end ? chunk + 1 : chunk;     // past the end the last chunk is staged again (never used)
+        issue_patch(cnext);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < ntap; t++) {
+            // the tap after this one: next tap of the chunk, else tap 0 of the next chunk
+            const int tn = t + 1 < ntap ? t + 1 : 0;
+            const int cn = t + 1 < ntap ? chunk : cnext;
+            mma_tap(ph, pl, tap_off(t), wbase + ((int64_t)cn * 9 + tap_slice(tn)) * CV_WSTEP_BYTES);
+        }
+        commit_patch(cnext, smem + (cur ^ 1) * 2 * pbuf);
+        __syncthreads();   // buffer cur^1 written by everyone, buffer cur read by everyone
+    }
+
+    // ---- epilogue: class (py, px), position (gy, gx) -> output pixel (2*gy + py, 2*gx + px)
+    const int GHc = P.IH + 1 - py, GWc = P.IW + 1 - px;
+    const int64_t osz = (int64_t)P.N * P.OH * P.OW * P.Co;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int pos = j * 16 + l15;
+        const int nbi = pos / tpos, rem = pos - nbi * tpos;
+        const int ty = rem / P.TW, tx = rem - ty * P.TW;
+        const int n = n0 + nbi, gy = gy0 + ty, gx = gx0 + tx;
+        const int oy = 2 * gy + py, ox = 2 * gx + px;
+        if (nbi >= P.NB || n >= P.N || gy >= GHc || gx >= GWc || oy >= P.OH || ox >= P.OW) continue;
+        const int64_t opix = ((int64_t)n * P.OH + oy) * P.OW + ox;
+        if (P.nsplit > 1) {     // raw partial sums in output layout; scaled by the reduce kernel
+            float *wrow = ws + (int64_t)split * osz + opix * P.Co;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int co = cot * CV_BM + h * 64 + i * 16 + kg * 4;
+                if (co < P.Co)
+                    *reinterpret_cast<float4 *>(wrow + co) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+            continue;
+        }
+        float *orow = out + opix * P.Co;
+        float4 sc[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int co = cot * CV_BM + h * 64 + i * 16 + kg * 4;
+            sc[i] = make_float4(P.alpha, P.alpha, P.alpha, P.alpha);
+            if (oscale) {
+                const float4 o = *reinterpret_cast<const float4 *>(oscale + (int64_t)n * P.Co + (co < P.Co ? co : 0));
+                sc[i] = make_float4(o.x * P.alpha, o.y * P.alpha, o.z * P.alpha, o.w * P.alpha);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int co = cot * CV_BM + h * 64 + i * 16 + kg * 4;
+            if (co < P.Co)
+                *reinterpret_cast<float4 *>(orow + co) = make_float4(acc[i][j][0] * sc[i].x, acc[i][j][1] * sc[i].y,
+                                                                     acc[i][j][2] * sc[i].z, acc[i][j][3] * sc[i].w);
+        }
+    }
+}
+
+// out[i] = alpha * oscale[n, co] * sum_s ws[s][i]   (ws in output layout; Co % 4 == 0)
+__global__ __launch_bounds__(256) void convt2_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
+                                                            const float *__restrict__ oscale, int64_t n4, int64_t per_img4,
+                                                            int co4, int nsplit, float alpha) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 *src = reinterpret_cast<const float4 *>(ws) + i;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sp = 0; sp < nsplit; sp++) {
+            const float4 v = src[(int64_t)sp * n4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        float4 sc = make_float4(alpha, alpha, alpha, alpha);
+        if (oscale) {
+            const int64_t n = i / per_img4;
+            const int cq = (int)(i % co4);
+            const float4 o = *(reinterpret_cast<const float4 *>(oscale) + n * co4 + cq);
+            s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha;
+            sc = o;
+        }
+        reinterpret_cast<float4 *>(out)[i] = make_float4(s.x * sc.x, s.y * sc.y, s.z * sc.z, s.w * sc.w);
+    }
+}
+
+// Tile and split-K plan.  One 512-thread block (256 registers per thread) is resident per CU, so the grid runs in
+// waves of 256 blocks: minimise  waves x (chunks per block x 9 taps + fixed cost)  over the position-tile shape
+// (any TW x TH x NB with <= 128 positions: the class grids are (2^k + 1)-sized, powers of two would waste up to
+// 2/3 of a tile on the small layers) and the channel split.
+static int ct2_plan(int N, int IH, int IW, int Ci, int Co, int OH, int OW, float alpha, Ct2Plan *p) {
+    if (N <= 0 || IH <= 0 || IW <= 0 || Ci <= 0 || Co <= 0 || (Ci & 3) || (Co & 3)) return RICK_EINVAL;
+    if (OH < 2 * IH || OH > 2 * IH + 1 || OW < 2 * IW || OW > 2 * IW + 1) return RICK_EINVAL;
+    if ((int64_t)N * IH * IW * Ci >= (1LL << 31) || (int64_t)N * OH * OW * Co >= (1LL << 31)) return RICK_EINVAL;
+    p->N = N; p->IH = IH; p->IW = IW; p->Ci = Ci; p->OH = OH; p->OW = OW; p->Co = Co; p->alpha = alpha;
+    p->nchunks = cdiv(Ci, CV_CK);
+    p->ncot = cdiv(Co, CV_BM);
+    const int GH = IH + 1, GW = IW + 1;
+    long best = -1;
+    for (int tw = 1; tw <= GW && tw <= 128; tw++)
+        for (int th = 1; th <= GH && th * tw <= 128; th++) {
+            int nb = 128 / (tw * th);
+            if (nb > N) nb = N;
+            const int npp = nb * (th + 1) * (tw + 1);
+            if (npp > CT_MAX_NPP) continue;
+            const long tiles = (long)cdiv(GW, tw) * cdiv(GH, th) * cdiv(N, nb) * p->ncot;
+            for (int s = 1; s <= p->nchunks && s <= 16; s++) {
+                const int cps = cdiv(p->nchunks, s), se = cdiv(p->nchunks, cps);
+                const long waves = (tiles * se + 255) / 256;
+                // rough time model in ns: a block needs ~6 us per channel chunk (9 taps x 96 MFMAs per wave) + ~4 us fixed;
+                // a split writes and re-reads se partial copies of the output (~4 TB/s) plus a second launch.  Patch rows
+                // shorter than 8 pixels stage poorly (tie-break towards wide tiles).
+                long cost = waves * (cps * 6000L + 4000L) + tiles * se * 40L + (tw < 8 ? 8 - tw : 0);
+                if (se > 1) cost += (long)((double)N * OH * OW * Co * 4.0 * (2 * se + 1) / 4000.0) + 3000L;
+                if (best < 0 || cost < best) {
+                    best = cost;
+                    p->TW = tw; p->TH = th; p->NB = nb; p->cps = cps; p->nsplit = se;
+                }
+            }
+        }
+    if (best < 0) return RICK_EINVAL;
+    p->ntx = cdiv(GW, p->TW);
+    p->nty = cdiv(GH, p->TH);
+    p->ntn = cdiv(N, p->NB);
+    p->PH = p->TH + 1;
+    p->PW = p->TW + 1;
+    p->NPP = p->NB * p->PH * p->PW;
+    return 0;
+}
+
+static size_t ct2_lds_bytes(const Ct2Plan &p) { return 4 * (size_t)p.NPP * 64 + (size_t)p.NB * p.cps * CV_CK * 4 + 128 * 4; }
+
+extern "C" int64_t rick_convt2_workspace_bytes(int N, int IH, int IW, int Ci, int Co, int OH, int OW) {
+    Ct2Plan p;
+    if (ct2_plan(N, IH, IW, Ci, Co, OH, OW, 1.f, &p)) return -1;
+    return p.nsplit > 1 ? (int64_t)p.nsplit * N * OH * OW * Co * 4 : 0;
+}
+
+extern "C" int rick_convt2_f32(const float *x, const void *packed_w, float *out, const float *iscale, const float *oscale,
+                               int N, int IH, int IW, int Ci, int Co, int OH, int OW, int split, float alpha,
+                               void *workspace, void *stream) {
+    if (!x || !packed_w || !out || (split != 1 && split != 2)) return RICK_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed_w | (uintptr_t)(iscale ? iscale : x) | (uintptr_t)(oscale ? oscale : x)) % 16)
+        return RICK_EINVAL;
+    Ct2Plan p;
+    if (ct2_plan(N, IH, IW, Ci, Co, OH, OW, alpha, &p)) return RICK_EINVAL;
+    if (p.nsplit > 1 && (!workspace || ((uintptr_t)workspace % 16))) return RICK_EINVAL;
+    const size_t lds = ct2_lds_bytes(p);
+    if (lds > 160 * 1024) return RICK_EINVAL;
+    const int64_t nwg = (int64_t)p.ntx * p.nty * p.ntn * p.ncot * p.nsplit;
+    if (nwg > 0x7fffffff) return RICK_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (split == 2) {
+        (void)hipFuncSetAttribute((const void *)convt2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(convt2_kernel<2>, dim3((unsigned)nwg), dim3(CT_THREADS), lds, st, x, (const unsigned char *)packed_w,
+                           out, iscale, oscale, (float *)workspace, p);
+    } else {
+        (void)hipFuncSetAttribute((const void *)convt2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(convt2_kernel<1>, dim3((unsigned)nwg), dim3(CT_THREADS), lds, st, x, (const unsigned char *)packed_w,
+                           out, iscale, oscale, (float *)workspace, p);
+    }
+    if (p.nsplit > 1) {
+        const int64_t n4 = (int64_t)N * OH * OW * Co / 4;
+        int64_t nb = cdiv64(n4, 256);
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(convt2_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float *)workspace, out, oscale, n4,
+                           (int64_t)OH * OW * Co / 4, Co / 4, p.nsplit, alpha);
+    }
+    RICK_LAUNCH_STATUS();
+}
+
+// Plan introspection for tools/bench_conv.py and the tests: {TW, TH, NB, tiles, nsplit, cps}.
+extern "C" int rick_convt2_plan(int N, int IH, int IW, int Ci, int Co, int OH, int OW, int *out6) {
+    Ct2Plan p;
+    const int rc = ct2_plan(N, IH, IW, Ci, Co, OH, OW, 1.f, &p);
+    if (rc || !out6) return RICK_EINVAL;
+    out6[0] = p.TW; out6[1] = p.TH; out6[2] = p.NB; out6[3] = p.ntx * p.nty * p.ntn * p.ncot; out6[4] = p.nsplit; out6[5] = p.cps;
+    return 0;
+}

@@ -112,13 +112,50 @@ class PackGroup:
     The optimiser updates every parameter of a network together, so the first stale lookup after a step
     repacks every (parameter view, orientation) the network has asked for so far — rick_conv_pack_weights_multi —
     instead of one pack launch + one allocation per layer and orientation.  Destination buffers and the device
-    descriptor table persist across steps."""
+    descriptor table persist across steps.
+
+    The pack launch may be captured into a hipGraph (RickTrainer._run), which bakes in the table pointer, the entry
+    count and the block count.  The table is therefore APPEND-ONLY at fixed capacity: a request registered after a
+    capture lands behind the entries the captured launch reads (its prefix, and the prefix's block ranges, never
+    change), and a table that has to be rebuilt (capacity exceeded, a parameter's storage moved) is retired, not
+    freed — replays keep reading valid memory."""
+
+    CAPACITY = 256          # descriptors per table (one per parameter view and orientation; a network needs < 100)
 
     def __init__(self):
-        self.reqs = {}          # request key -> dict(param, buf, desc fields, stamp)
-        self.table = None       # device copy of the descriptor array
+        self.reqs = {}          # request key -> dict(param, buf, desc fields, stamp); insertion order == table order
+        self.table = None       # device copy of the descriptor array (CAPACITY entries)
+        self.host = None        # host mirror
+        self.n = 0              # entries in use
         self.total_blocks = 0
+        self.retired = []       # tables a captured graph may still reference
         self.epoch = 0          # bumped when this network's parameters were updated through raw pointers
+
+    def _append(self, req):
+        """Write the request's descriptor behind the existing ones (host mirror + the one device entry)."""
+        dev = req['buf'].device
+        if self.table is None or self.n >= self.host.shape[0]:
+            cap = max(self.CAPACITY, 2 * self.n)
+            host = np.zeros(cap, dtype=_DESC)
+            if self.table is not None:
+                host[:self.n] = self.host[:self.n]
+                self.retired.append(self.table)
+            self.host = host
+            self.table = torch.from_numpy(host.view(np.uint8).copy()).to(dev)
+        w, s_o, s_i, s_t, packed, O, I, ns, sc = req['desc']
+        self.host[self.n] = (w, s_o, s_i, s_t, packed, O, I, ns, sc, self.total_blocks, 0)
+        sz = _DESC.itemsize
+        self.table[self.n * sz:(self.n + 1) * sz].copy_(torch.from_numpy(self.host[self.n:self.n + 1].view(np.uint8).copy()))
+        self.total_blocks += lib.rick_conv_pack_blocks(O, I)
+        self.n += 1
+
+    def _rebuild(self):
+        """Some parameter's storage moved: a fresh table from the surviving requests (the old one is retired)."""
+        if self.table is not None:
+            self.retired.append(self.table)
+        self.table, self.host, self.n, self.total_blocks = None, None, 0, 0
+        for r in self.reqs.values():
+            self._append(r)
 
     def lookup(self, w, scale, key):
         param, tag = key
@@ -128,12 +165,15 @@ class PackGroup:
             w2, s_o, s_i, s_t = _w_strides(w)
             if w2.data_ptr() != w.data_ptr():
                 return None                      # needed a temporary copy: not a stable view, pack individually
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('PackGroup: a packed-weight request was registered during hipGraph capture; run the '
+                                   'step eagerly once before capturing it')
             O, I, kh, kw = w.shape
             buf = torch.empty(lib.rick_conv_packed_bytes(O, I, kh * kw), device=w.device, dtype=torch.uint8)
             req = dict(param=param, off=w.data_ptr() - param.data_ptr(), buf=buf, stamp=None,
                        desc=(w.data_ptr(), s_o, s_i, s_t, buf.data_ptr(), O, I, kh * kw, float(scale)))
             self.reqs[rk] = req
-            self.table = None
+            self._append(req)
             # first use: pack just this one (the group launch takes over from the next refresh on)
             check(lib.rick_conv_pack_weight(w.data_ptr(), s_o, s_i, s_t, O, I, kh * kw, float(scale), _SPLIT,
                                             buf.data_ptr(), stream_ptr()), 'rick_conv_pack_weight')
@@ -145,25 +185,15 @@ class PackGroup:
     def _repack(self):
         # requests whose parameter storage moved (e.g. .to(), re-flattening) are dropped; they re-register on use
         stale = [k for k, r in self.reqs.items() if r['param'].data_ptr() + r['off'] != r['desc'][0]]
-        for k in stale:
-            del self.reqs[k]
-            self.table = None
+        if stale:
+            for k in stale:
+                del self.reqs[k]
+            self._rebuild()
         if not self.reqs:
             return
-        reqs = list(self.reqs.values())
-        if self.table is None:
-            arr = np.zeros(len(reqs), dtype=_DESC)
-            blk = 0
-            for i, r in enumerate(reqs):
-                w, s_o, s_i, s_t, packed, O, I, ns, sc = r['desc']
-                arr[i] = (w, s_o, s_i, s_t, packed, O, I, ns, sc, blk, 0)
-                blk += lib.rick_conv_pack_blocks(O, I)
-            self.total_blocks = blk
-            dev = reqs[0]['buf'].device
-            self.table = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
-        check(lib.rick_conv_pack_weights_multi(ptr(self.table), len(reqs), self.total_blocks, _SPLIT, stream_ptr()),
+        check(lib.rick_conv_pack_weights_multi(ptr(self.table), self.n, self.total_blocks, _SPLIT, stream_ptr()),
               'rick_conv_pack_weights_multi')
-        for r in reqs:
+        for r in self.reqs.values():
             r['stamp'] = (r['param']._version, _weights_epoch, self.epoch, _SPLIT)
 
 
@@ -275,11 +305,40 @@ def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0, ep
     return y
 
 
+_USE_CT2 = True     # tools/bench_conv.py switches the dedicated stride-2 kernel off to time the generic multi-class launch
+
+
+def _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha):
+    """3x3 stride-2 padding-0 transposed convolution on the single-staging kernel (csrc/convt2.hip)."""
+    N, I, IH, IW = x.shape
+    OH, OW = out_hw
+    key = ('t2', N, I, IH, IW, O, OH, OW)
+    ent = _geom_cache.get(key)
+    if ent is None:
+        nbytes = lib.rick_convt2_workspace_bytes(N, IH, IW, I, O, OH, OW)
+        if nbytes < 0:
+            raise RuntimeError('rick_convt2_workspace_bytes: invalid geometry')
+        # algorithmic FLOPs: every (input pixel, tap) pair whose output pixel exists
+        ny = [sum(1 for iy in range(IH) if 2 * iy + k < OH) for k in range(3)]
+        nx = [sum(1 for ix in range(IW) if 2 * ix + k < OW) for k in range(3)]
+        ent = (nbytes, 2.0 * N * O * I * sum(ny) * sum(nx), f'convT {I}->{O} k3 s2 N{N} {IH}x{IW}')
+        _geom_cache[key] = ent
+    nbytes, flops, tag = ent
+    y = _empty_nhwc(N, O, OH, OW, x)
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
+    check(_launch('igemm', flops, lib.rick_convt2_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), N, IH, IW, I, O,
+                  OH, OW, _SPLIT, alpha, ptr(ws), stream_ptr(), tag=tag), 'rick_convt2_f32')
+    return y
+
+
 def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alpha=1.0):
     """y[q] += w[k] x[pos], q = pos*s + k - p: the output parity classes (s*s of them) run as one launch."""
     x = _nhwc(x)
     N, I, IH, IW = x.shape
     OH, OW = out_hw
+    if (_USE_CT2 and kh == 3 and kw == 3 and s == 2 and p == 0 and I % 4 == 0 and O % 4 == 0
+            and OH in (2 * IH, 2 * IH + 1) and OW in (2 * IW, 2 * IW + 1)):
+        return _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha)
     key = ('t', N, I, IH, IW, O, kh, kw, s, p, OH, OW, alpha, _SPLIT)
     ent = _geom_cache.get(key)
     if ent is None:

@@ -382,6 +382,7 @@ class RickTrainer:
         self.zero_idx_g = self.zero_idx_d = None
         self.losses = {}
         self.use_graphs = False
+        self.step_events = None     # list of (step name, event) while bench.py times step types
         self._gs, self._inject, self._layer_idx, self._real = {}, {}, None, None
         if dp is not None:
             dp.attach(self.g_flat, self.d_flat)
@@ -479,10 +480,13 @@ class RickTrainer:
             self._reduce(flat)
             optim.step()
             return
+        if 'graphs' in st and st['sig'] != self._graph_signature(optim):
+            del st['graphs']                                  # optimiser state / stage changed under the capture: redo it
         if 'graphs' not in st:
             op.bump_weights_epoch()                           # every pack refresh the step needs lands inside its graph
             torch.cuda.synchronize()
             before = list(optim.steps)
+            seen = dict(self.losses)
             if self.dp is None:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -497,7 +501,9 @@ class RickTrainer:
                     optim.step()
                 st['graphs'] = (g1, g2)
             st['runs'] = list(optim.last_runs)
+            st['losses'] = {k: v for k, v in self.losses.items() if seen.get(k) is not v}   # this graph's output tensors
             optim.steps[:] = before                           # capture executes nothing: the replay below is this step
+            st['sig'] = self._graph_signature(optim)
         gs = st['graphs']
         gs[0].replay()
         if len(gs) == 2:
@@ -505,6 +511,25 @@ class RickTrainer:
             gs[1].replay()
         optim.last_runs = st['runs']
         optim.note_replayed_step()
+        # the replay updated the parameters through raw pointers: packed weights cached by EAGER launches are stale
+        # (graphs re-pack inside themselves; this is a host-side counter only)
+        op.bump_weights_epoch(flat.params)
+        self.losses.update(st['losses'])                      # eager steps in between may have re-bound the entries
+
+    def _graph_signature(self, optim):
+        """What a captured step bakes in from the host: which parameters step (requires_grad pattern of the stage) and
+        how they group into runs of equal step count (one bias-correction row per run).  A checkpoint resume or a
+        stage change alters it; the step is then re-captured instead of replayed with stale grouping."""
+        fp = optim.fp
+        active = tuple(fp.params[i].requires_grad for i in fp.opt_idx)
+        st = [optim.steps[i] for i in fp.opt_idx]
+        rel = tuple(s - st[0] for s in st)
+        return (active, rel, optim.lr, tuple(optim.betas), optim.eps)
+
+    def invalidate_graphs(self):
+        """Drop every captured step (after loading a checkpoint or changing optimiser hyper-parameters)."""
+        for st in self._gs.values():
+            st.pop('graphs', None)
 
     # ---- steps (each returns the loss tensor; no host sync)
     def d_step(self, real_img, noise, i=10 ** 9, g_noise=None, graph=False):
@@ -658,11 +683,24 @@ class RickTrainer:
             self._real.copy_(real_img)                        # captured launches read this buffer
             real_img = self._real
         nz = (lambda b: None) if graph else (lambda b: mixing_noise(b, cfg.latent, cfg.mixing, self.device))
+        self._mark('begin')
         self.d_step(real_img, nz(cfg.batch), i, graph=graph)
+        self._mark('d')
         if i % cfg.d_reg_every == 0:
             self.r1_step(real_img, i, graph=graph)
+            self._mark('r1')
         if i >= cfg.warmup_iter:
             self.g_step(nz(cfg.batch), graph=graph)
+            self._mark('g')
             if i % cfg.g_reg_every == 0:
                 self.plr_step(nz(max(1, cfg.batch // cfg.path_batch_shrink)), graph=graph)
+                self._mark('plr')
         self.ema_step()
+        self._mark('ema')
+
+    def _mark(self, name):
+        """bench.py's per-step-type timing: a HIP event on the launch stream after each step (no host sync)."""
+        if self.step_events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.step_events.append((name, e))

@@ -250,6 +250,109 @@ def test_trainer_steps_match_oracle():
     tr.ema_step()
 
 
+def _key_samples(key, n, count=64):
+    """tools/make_golden.py::key_samples — the fixed pseudo-random element indices a key's samples were taken at."""
+    import zlib
+    return np.random.RandomState(zlib.crc32(key.encode()) & 0x7fffffff).randint(0, n, size=min(count, n))
+
+
+def _check_summaries(gold, prefix, named, what, abs_tol, rel_tol, med_tol):
+    """Per-key sampled elements (64 per tensor) and sums vs the reference run.  A handful of elements may sit on a
+    LeakyReLU kink or (for Adam with beta1 = 0, a sign-like first step) on a gradient sign change between the two fp32
+    arithmetics: at most 2 of a key's 64 samples and 0.5 % of all samples may miss the element bound, and the median
+    relative L2 error over keys must be at rounding level."""
+    bad_total, n_total, l2s = 0, 0, []
+    for k, t in named:
+        pre = f'{prefix}/{k}'
+        if f'{pre}/samples' not in gold:
+            continue
+        a = t.detach().double().reshape(-1).cpu().numpy()
+        ref = gold[f'{pre}/samples'].astype(np.float64)
+        got = a[_key_samples(k, a.size)]
+        scale = max(float(np.abs(ref).max()), 1e-30)
+        bad = int((np.abs(got - ref) > abs_tol + rel_tol * scale).sum())
+        assert bad <= 2, f'{what} {k}: {bad} of {ref.size} sampled elements off (max err {np.abs(got - ref).max():.3e}, scale {scale:.3e})'
+        bad_total += bad
+        n_total += ref.size
+        nr = float(np.linalg.norm(ref))
+        if nr > 0 and ref.size >= 16:
+            l2s.append(float(np.linalg.norm(got - ref)) / nr)
+        sq_ref = float(gold[f'{pre}/sq'])
+        if sq_ref > 0:
+            assert abs(float((a * a).sum()) - sq_ref) <= 2e-2 * sq_ref + 1e-12, f'{what} {k}: sum of squares'
+    assert n_total > 0
+    assert bad_total <= 0.005 * n_total, (what, bad_total, n_total)
+    med = float(np.median(l2s))
+    assert med < med_tol, f'{what}: median sampled l2 error {med:.2e}'
+
+
+def test_rick_loop_body_256_batch4_vs_reference(golden):
+    """Rows L / R1 / PL / K / O / H at the BENCHMARKED configuration (256 px, batch 4; D step on cat(fake, real) = N 8):
+    one D step, R1 step, G step, path-length step and EMA of RickTrainer against tests/golden/rick256.npz, which holds
+    what the reference's OWN loop body (train_dynamic_update_prune.py:401-589, executed slice by slice on CPU with its
+    torch.optim.Adam and its mask-application blocks) leaves behind: losses, masked gradients (element samples),
+    post-step parameters after each optimiser step, EMA weights.  Masks are the reference decision block's own index
+    sets (README quantiles 40 / 0.1, first sweep)."""
+    from rick_amd.train import RickTrainer, TrainConfig, build_mask
+    gold = golden('rick256')
+    size, B = 256, 4
+    g, d = build(size)
+    g_ema, d_ema = build(size)
+    tr = RickTrainer(TrainConfig(size=size, batch=B, warmup_iter=0), g, d, g_ema, d_ema)
+
+    def sets(name):
+        pre = f'q40/s0/{name}/'
+        return {k[len(pre):]: gold[k].astype(np.int64) for k in gold.files if k.startswith(pre)}
+    tr.g_optim.set_mask(build_mask(tr.g_flat, sets('idx_freeze_g'), sets('zero_filter_idx_g')))
+    tr.d_optim.set_mask(build_mask(tr.d_flat, sets('idx_freeze_d'), sets('zero_filter_idx_d')))
+    z = {'d': synth_latents(B, seed=901).to(DEV), 'g': synth_latents(B, seed=902).to(DEV),
+         'plr': synth_latents(B // 2, seed=903).to(DEV)}
+    real = synth_reals(B, size=size, seed=904).to(DEV)
+    pl_noise = synth_tensor('plnoise/rick256', (B // 2, 3, size, size)).to(DEV)
+    noises = [getattr(g.noises, f'noise_{i}') for i in range(g.num_layers)]
+    gp, dp = list(g.named_parameters()), list(d.named_parameters())
+
+    def flat_grads(flat, named):
+        out = []
+        for k, p in named:
+            if k in flat.index and flat.index[k] in flat.opt_idx:
+                lo, hi = flat.segment(k)
+                out.append((k, flat.grad[lo:hi].view(p.shape)))
+        return out
+
+    d_loss = tr.d_step(real, [z['d']], g_noise=noises)
+    assert rel(d_loss, gold['step/d_loss']) < 5e-4
+    assert abs(float(tr.losses['real_score']) - float(gold['step/real_pred'].mean())) < 2e-3 * max(1.0, abs(float(gold['step/real_pred'].mean())))
+    assert abs(float(tr.losses['fake_score']) - float(gold['step/fake_pred'].mean())) < 2e-3 * max(1.0, abs(float(gold['step/fake_pred'].mean())))
+    _check_summaries(gold, 'step/d_grad', flat_grads(tr.d_flat, dp), 'D grad', 0.0, 2e-3, 2e-3)
+    _check_summaries(gold, 'step/d_param', dp, 'D param after Adam', 2e-5, 1e-5, 1e-4)
+
+    r1 = tr.r1_step(real)
+    assert rel(r1, gold['step/r1_loss']) < 5e-3
+    _check_summaries(gold, 'step/r1_grad', flat_grads(tr.d_flat, dp), 'R1 grad', 0.0, 5e-3, 5e-3)
+    _check_summaries(gold, 'step/r1_param', dp, 'D param after R1 Adam', 4e-5, 1e-5, 2e-4)
+
+    g_loss = tr.g_step([z['g']], g_noise=noises)
+    assert rel(g_loss, gold['step/g_loss']) < 1e-3
+    _check_summaries(gold, 'step/g_grad', flat_grads(tr.g_flat, gp), 'G grad', 0.0, 2e-3, 2e-3)
+    _check_summaries(gold, 'step/g_param', gp, 'G param after Adam', 2e-5, 1e-5, 1e-4)
+
+    pen = tr.plr_step([z['plr']], pl_noise=pl_noise, g_noise=noises)
+    assert rel(pen, gold['step/path_loss']) < 2e-3
+    assert rel(tr.losses['path_length'], gold['step/path_lengths'].mean()) < 1e-3
+    assert rel(tr.mean_path_length, gold['step/mean_path_length']) < 1e-3
+    _check_summaries(gold, 'step/pl_grad', flat_grads(tr.g_flat, gp), 'path-length grad', 0.0, 5e-3, 5e-3)
+    _check_summaries(gold, 'step/pl_param', gp, 'G param after path-length Adam', 4e-5, 1e-5, 2e-4)
+
+    tr.ema_step()
+    _check_summaries(gold, 'step/g_ema', list(g_ema.named_parameters()), 'g_ema', 1e-6, 1e-6, 1e-5)
+    _check_summaries(gold, 'step/d_ema', list(d_ema.named_parameters()), 'd_ema', 1e-6, 1e-6, 1e-5)
+    # pruned filters are exactly zero on both sides
+    for k, idx in sets('zero_filter_idx_d').items():
+        if len(idx):
+            assert float(dict(dp)[k][idx].abs().max()) == 0.0, k
+
+
 def test_warmup_stage_and_fisher_sweep_masks():
     """Rows H / F / Q / K at 32 px: (a) during warm-up only `final_*` of D is updated and the G step is skipped
     (train_dynamic_update_prune.py:202-211, 518-519); (b) fisher_sweep accumulates grad^2 on device exactly like

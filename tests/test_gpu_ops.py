@@ -186,6 +186,51 @@ def test_conv_transpose2d_vs_fp64(case):
     assert rel_err(gg[1], ggr[1]) < 5e-5
 
 
+CT2_CASES = [  # tag, N, Ci, Co, IH, IW, crop (output 2*IH instead of 2*IH+1), scales
+    ('g4', 4, 512, 512, 4, 4, False, True),          # G convs.0: split-K over all 16 chunks, 4 images per tile
+    ('g8', 4, 512, 512, 8, 8, False, True),
+    ('g16_n8', 8, 512, 512, 16, 16, False, False),    # D dgrad shape at N = 8 (cat(fake, real))
+    ('g64', 4, 512, 256, 64, 64, False, True),        # G convs.8 (512 -> 256 @64^2 -> 129^2): the benchmarked layer
+    ('g128_n8', 8, 256, 128, 128, 128, False, False),  # D conv2 dgrad 128^2 -> 257^2, N = 8
+    ('odd', 3, 36, 20, 5, 7, False, True),            # ragged channels (Ci, Co % 4 == 0 but not % 32 / % 128), odd sizes
+    ('crop', 2, 64, 32, 9, 6, True, False),           # even-sized target: last output row / column cropped
+]
+
+
+@pytest.mark.parametrize('case', CT2_CASES, ids=[c[0] for c in CT2_CASES])
+def test_convt2_single_staging_kernel(case):
+    """rick_convt2_f32 (all four parity classes from one staged patch) vs F.conv_transpose2d in fp64 and vs the generic
+    multi-class launch it replaces, at the real layer shapes incl. modulation / demodulation scales."""
+    from rick_amd.op import conv as cv
+    tag, N, Ci, Co, IH, IW, crop, scales = case
+    x = synth_tensor(f'ct2/{tag}/x', (N, Ci, IH, IW))
+    w = synth_tensor(f'ct2/{tag}/w', (Co, Ci, 3, 3))
+    si = (synth_tensor(f'ct2/{tag}/si', (N, Ci)) * 0.5 + 1.0) if scales else None
+    so = (synth_tensor(f'ct2/{tag}/so', (N, Co)) * 0.5 + 1.0) if scales else None
+    wscale = 1.0 / (Ci * 9) ** 0.5
+    xs = x.double() * (si.double()[:, :, None, None] if scales else 1.0)
+    ref = F.conv_transpose2d(xs, w.double().transpose(0, 1) * wscale, stride=2)
+    if scales:
+        ref = ref * so.double()[:, :, None, None]
+    OH, OW = (2 * IH, 2 * IW) if crop else (2 * IH + 1, 2 * IW + 1)
+    ref = ref[:, :, :OH, :OW]
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    wp = cv._pack(w.to(DEV), wscale)
+    sid, sod = (si.to(DEV), so.to(DEV)) if scales else (None, None)
+    assert cv._USE_CT2
+    y = cv._convT_launch(xd, wp, Co, 3, 3, 2, 0, (OH, OW), iscale=sid, oscale=sod)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < 2e-5
+    y2 = cv._convT_launch(xd, wp, Co, 3, 3, 2, 0, (OH, OW), iscale=sid, oscale=sod)
+    assert torch.equal(y, y2), 'not deterministic'
+    cv._USE_CT2 = False
+    try:
+        y_old = cv._convT_launch(xd, wp, Co, 3, 3, 2, 0, (OH, OW), iscale=sid, oscale=sod)
+    finally:
+        cv._USE_CT2 = True
+    assert rel_err(y, y_old.double()) < 2e-6      # same products, different summation order over channel chunks
+
+
 def test_conv_bf16_single_pass_is_coarser():
     """split=1 (plain bf16 MFMA) is a speed option, not the parity path: ~1e-3..1e-2 error."""
     from rick_amd import op

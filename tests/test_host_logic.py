@@ -83,6 +83,42 @@ def test_decisions_on_reference_fim(golden):
         assert set(fr) == set(conv) | set(fc) | {k.replace('weight', 'bias') for k in fc}
 
 
+@pytest.mark.parametrize('qtag,fq,pq', [('q40', 40.0, 0.1), ('q85', 85.0, 0.075)])
+def test_decisions_equal_reference_block(golden, qtag, fq, pq):
+    """Row Q pinned by the reference's OWN code: tests/golden/rick256.npz holds the index sets its decision block
+    (train_dynamic_update_prune.py:277-393, executed as a source slice by tools/make_golden.py on Fisher dictionaries from
+    its estimate_fisher, 256 px, two sweeps of two samples) produced for the README quantiles, next to the per-filter
+    FIM vectors in its own expressions.  decide_g / decide_d / zero_idx_merge must reproduce every set EXACTLY — freeze,
+    fine-tune and prune sets of both networks (incl. the >= / < rule of the skip layers and the bias keys derived by
+    character arithmetic), the percentile lines, and the cumulative prune set after the second sweep."""
+    g = golden('rick256')
+    zero_g = zero_d = None
+    for sw in range(2):
+        conv = {k.split('/', 2)[2]: g[k] for k in g.files if k.startswith(f'fim{sw}/g_conv/')}
+        fc = {k.split('/', 2)[2]: g[k] for k in g.files if k.startswith(f'fim{sw}/g_fc/')}
+        dfim = {k.split('/', 2)[2]: g[k] for k in g.files if k.startswith(f'fim{sw}/d/')}
+        assert len(conv) == 12 and len(fc) == 12 and len(dfim) == 18
+        fr_g, ft_g, pr_g = decide_g(conv, fc, fq, pq)
+        fr_d, ft_d, pr_d = decide_d(dfim, fq, pq)
+        if sw == 0:                                          # :386-393
+            zero_g, zero_d = pr_g, pr_d
+        else:
+            zero_g, zero_d = zero_idx_merge(zero_g, pr_g), zero_idx_merge(zero_d, pr_d)
+        for name, got in (('idx_freeze_g', fr_g), ('idx_ft_g', ft_g), ('idx_prune_g', pr_g), ('idx_freeze_d', fr_d),
+                          ('idx_ft_d', ft_d), ('idx_prune_d', pr_d), ('zero_filter_idx_g', zero_g),
+                          ('zero_filter_idx_d', zero_d)):
+            pre = f'{qtag}/s{sw}/{name}/'
+            ref = {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+            assert ref.keys() == got.keys(), (name, set(ref) ^ set(got))
+            for k in ref:
+                assert np.array_equal(np.asarray(got[k]), ref[k]), (name, k, sw)
+        # the percentile lines themselves
+        allc = np.concatenate([[]] + [conv[f'convs.{k}.conv.weight'] for k in range(12)], axis=None)
+        assert np.percentile(allc, q=fq) == float(g[f'{qtag}/s{sw}/cutline_g_conv'])
+        assert np.percentile(allc, q=pq) == float(g[f'{qtag}/s{sw}/pruneline_g_conv'])
+    assert sum(len(v) for v in zero_g.values()) >= sum(len(v) for v in pr_g.values())
+
+
 def test_flat_params_and_masks_cpu():
     from rick_amd.models import Generator
     g = Generator(16, 512, 8)

@@ -43,16 +43,27 @@ for ci, co, r in shapes:
         t = timeit(lambda: cv._wgrad_launch(gy, x, 3, 3, 1, 1, ascale=so, bscale=si))
         out.append(f'wgrad {t*1e6:8.1f} us {flops/t/1e12:6.1f} TF')
     print(' | '.join(out))
-# stride-2 (D conv2) and transposed (G up)
-for ci, co, r in [(128, 256, 256), (256, 512, 128), (512, 512, 64)]:
+# stride-2 (D conv2) and transposed (G up): dedicated single-staging kernel (csrc/convt2.hip) vs the generic multi-class launch
+for ci, co, r in [(128, 256, 256), (256, 512, 128), (512, 512, 64), (512, 512, 32), (512, 512, 16), (512, 512, 8)]:
     x = torch.randn(B, ci, r + 1, r + 1, device='cuda').contiguous(memory_format=torch.channels_last)
     w = torch.randn(co, ci, 3, 3, device='cuda')
     wp = cv._pack(w, 1.0)
     flops = 2.0 * B * (r // 2) ** 2 * ci * co * 9
-    t = timeit(lambda: cv._conv_launch(x, wp, co, 3, 3, 2, 0))
+    out = [f's2 {ci:4d}->{co:4d} @{r:3d}->{r//2}: {flops/1e9:7.2f} GF']
+    if 'fprop' in which:
+        t = timeit(lambda: cv._conv_launch(x, wp, co, 3, 3, 2, 0))
+        out.append(f'fprop {t*1e6:8.1f} us {flops/t/1e12:6.1f} TF')
     gy = torch.randn(B, co, r // 2, r // 2, device='cuda').contiguous(memory_format=torch.channels_last)
-    t3 = timeit(lambda: cv._wgrad_launch(gy, x, 3, 3, 2, 0))
-    wpT = cv._pack(w.transpose(0, 1), 1.0)
-    t2 = timeit(lambda: cv._convT_launch(gy, wpT, ci, 3, 3, 2, 0, (r + 1, r + 1)))
-    print(f's2 {ci:4d}->{co:4d} @{r:3d}->{r//2}: {flops/1e9:7.2f} GF | fprop {t*1e6:8.1f} us {flops/t/1e12:6.1f} TF | '
-          f'dgrad(convT) {t2*1e6:8.1f} us {flops/t2/1e12:6.1f} TF | wgrad {t3*1e6:8.1f} us {flops/t3/1e12:6.1f} TF')
+    if 'wgrad' in which:
+        t3 = timeit(lambda: cv._wgrad_launch(gy, x, 3, 3, 2, 0))
+        out.append(f'wgrad {t3*1e6:8.1f} us {flops/t3/1e12:6.1f} TF')
+    if 'dgrad' in which:
+        wpT = cv._pack(w.transpose(0, 1), 1.0)
+        so = torch.rand(B, co, device='cuda') + 0.5 if SC else None
+        si = torch.rand(B, ci, device='cuda') + 0.5 if SC else None
+        for flag in (True, False):
+            cv._USE_CT2 = flag
+            t2 = timeit(lambda: cv._convT_launch(gy, wpT, ci, 3, 3, 2, 0, (r + 1, r + 1), iscale=so, oscale=si))
+            out.append(f'convT[{"ct2" if flag else "multi"}] {t2*1e6:8.1f} us {flops/t2/1e12:6.1f} TF')
+        cv._USE_CT2 = True
+    print(' | '.join(out))
