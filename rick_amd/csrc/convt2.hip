@@ -20,6 +20,8 @@
 // The only LDS traffic is the B operand (patch), and the only barrier is one per channel chunk (double-buffered
 // patch).  Precision: bf16x3 (hi*hi + hi*lo + lo*hi, fp32 accumulate) or plain bf16, as in conv.hip.
 #include "conv_common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 #define CT_THREADS 512
 #define CT_PITEMS 3                       // patch float4 per thread: up to 192 patch pixels
@@ -127,19 +129,18 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
         }
     };
 
-    // ---- B operand (patch) read offsets: position j*16 + l15 of the tile -> patch pixel (ty + 1, tx + 1).  The same for
-    // every wave; kept in LDS ([l15][8 j] ints, one b128 read per half of the j range) to leave the registers to the MFMAs
+    // ---- B operand (patch) read offsets: position j*16 + l15 of the tile -> patch pixel (ty + 1, tx + 1)
     const int tpos = P.TW * P.TH;
-    int *pbt = reinterpret_cast<int *>(sct + P.NB * cspan);
-    if (threadIdx.x < 128) {
-        const int pos = threadIdx.x;
+    int pb[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int pos = j * 16 + l15;
         int nbi = pos / tpos;
         const int rem = pos - nbi * tpos;
         const int ty = rem / P.TW, tx = rem - ty * P.TW;
         nbi = nbi < P.NB ? nbi : P.NB - 1;                    // tile slots beyond NB images are masked in the epilogue
-        pbt[(pos & 15) * 8 + (pos >> 4)] = (nbi * P.PH + ty + 1) * P.PW + tx + 1;
+        pb[j] = (nbi * P.PH + ty + 1) * P.PW + tx + 1;
     }
-    const int4 *pbl = reinterpret_cast<const int4 *>(pbt + l15 * 8);
     // ---- A operand (weights) fragment offset inside one packed 16 KB tap tile: row = h*64 + i*16 + l15
     const int arow = h * 64 + l15;
     const int a_off = arow * 64 + cv_swz(kg, arow) * 16;      // + i * 1024 (the swizzle key (row >> 2) & 1 does not depend on i)
@@ -173,12 +174,10 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     auto mma_tap = [&](const unsigned char *ph, const unsigned char *pl, int toff, const unsigned char *wnext) {
 #pragma unroll
         for (int jh = 0; jh < 2; jh++) {
-            const int4 pb4 = pbl[jh];
-            const int pbv[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
             bf16x8 bhi[4], blo[4];
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
-                const int pp = pbv[jj] + toff;
+                const int pp = pb[jh * 4 + jj] + toff;
                 const int off = pp * 64 + cv_swz(kg, pp) * 16;
                 bhi[jj] = *reinterpret_cast<const bf16x8 *>(ph + off);
                 if (SPLIT == 2) blo[jj] = *reinterpret_cast<const bf16x8 *>(pl + off);
@@ -327,6 +326,15 @@ static int ct2_plan(int N, int IH, int IW, int Ci, int Co, int OH, int OW, float
             }
         }
     if (best < 0) return RICK_EINVAL;
+#ifdef RICK_ABLATION   // tile / split override for tools/bench_conv.py: RICK_CT2_TILE="tw,th,nb,nsplit"
+    if (const char *ov = getenv("RICK_CT2_TILE")) {
+        int tw, th, nb, ns;
+        if (sscanf(ov, "%d,%d,%d,%d", &tw, &th, &nb, &ns) == 4 && tw * th * nb <= 128 && nb * (th + 1) * (tw + 1) <= CT_MAX_NPP) {
+            p->TW = tw; p->TH = th; p->NB = nb < N ? nb : N;
+            p->cps = cdiv(p->nchunks, ns); p->nsplit = cdiv(p->nchunks, p->cps);
+        }
+    }
+#endif
     p->ntx = cdiv(GW, p->TW);
     p->nty = cdiv(GH, p->TH);
     p->ntn = cdiv(N, p->NB);
@@ -336,7 +344,7 @@ static int ct2_plan(int N, int IH, int IW, int Ci, int Co, int OH, int OW, float
     return 0;
 }
 
-static size_t ct2_lds_bytes(const Ct2Plan &p) { return 4 * (size_t)p.NPP * 64 + (size_t)p.NB * p.cps * CV_CK * 4 + 128 * 4; }
+static size_t ct2_lds_bytes(const Ct2Plan &p) { return 4 * (size_t)p.NPP * 64 + (size_t)p.NB * p.cps * CV_CK * 4; }
 
 extern "C" int64_t rick_convt2_workspace_bytes(int N, int IH, int IW, int Ci, int Co, int OH, int OW) {
     Ct2Plan p;
