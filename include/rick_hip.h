@@ -251,6 +251,25 @@ int rick_demod_bwd_s_f32(const float *s, const float *wsq, const float *d, const
                          void *stream);
 int rick_demod_bwd_w_f32(const float *w, const float *s, const float *d, const float *gd, float *gw, int B, int I, int O,
                          int K, float scale, void *stream);
+/* Modulation bank: s_l = EqualLinear_l(latent[:, idx_l]) for EVERY modulated convolution of the generator
+ * (ModulatedConv2d.modulation, model_probe_tune.py:233,246) in one launch, and the weight / bias gradients of all of
+ * them in one more.  lat is [B, n_latent, K]; layer l owns blocks [blk_begin, blk_begin + rick_modbank_blocks(C_l));
+ *   fwd: out[io_off + b*C + c] = scale * sum_k lat[b, lat_idx, k] * w[c*K + k] + b[c]
+ *   bwd: grad[gw_off + c*K + k] = scale * sum_b gs[io_off + b*C + c] * lat[b, lat_idx, k];  grad[gb_off + c] = sum_b gs[..]
+ * (gb_off < 0: no bias gradient).  `descs_device` lives in device memory.  K % 256 == 0, B <= 8. */
+typedef struct {
+    const float *w;         /* [C, K] */
+    const float *b;         /* [C] or NULL */
+    int64_t io_off;         /* float offset of s_l / gs_l ([B, C] contiguous) */
+    int64_t gw_off, gb_off; /* float offsets of the weight / bias gradient */
+    int C, lat_idx, blk_begin, reserved;
+} rick_modbank_desc;
+int rick_modbank_blocks(int C);
+int rick_modbank_fwd_f32(const float *lat, int B, int n_latent, int K, const rick_modbank_desc *descs_device, int n,
+                         int total_blocks, float scale, float *out, void *stream);
+int rick_modbank_bwd_f32(const float *lat, const float *gs, int B, int n_latent, int K, const rick_modbank_desc *descs_device,
+                         int n, int total_blocks, float scale, float *grad, void *stream);
+
 /* Masked Adam over a flat parameter buffer (mask bits: 1 = freeze (grad := 0),
  * 2 = prune (param := 0, grad := 0); mask may be NULL), torch.optim.Adam semantics
  * (no weight decay, no amsgrad), bias corrections passed in. */

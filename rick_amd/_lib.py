@@ -81,6 +81,9 @@ SIGNATURES = {
     'rick_demod_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_f, c_fp]),
     'rick_demod_bwd_s_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     'rick_demod_bwd_w_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_f, c_fp]),
+    'rick_modbank_blocks': (c_int, [c_int]),
+    'rick_modbank_fwd_f32': (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int, c_int, c_f, c_fp, c_fp]),
+    'rick_modbank_bwd_f32': (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_int, c_int, c_f, c_fp, c_fp]),
     'rick_adam_prepare_f32': (c_int, [c_fp, c_int, c_int, c_f, c_f, c_fp, c_fp]),
     'rick_masked_adam_dev_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f, c_f, c_f, c_f, c_fp, c_fp]),
     'rick_ema_f32': (c_int, [c_fp, c_fp, c_i64, c_f, c_fp]),

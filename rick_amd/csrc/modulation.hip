@@ -175,3 +175,117 @@ extern "C" int rick_demod_bwd_w_f32(const float *w, const float *s, const float 
                        scale * scale);
     RICK_LAUNCH_STATUS();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Modulation bank: the style -> per-channel scale linears of EVERY modulated convolution of the generator
+// (ModulatedConv2d.modulation = EqualLinear(style_dim, in_channel, bias_init=1), model_probe_tune.py:233,246; 13
+// StyledConvs + 7 ToRGBs at 256 px) in ONE launch, and their weight / bias gradients in one more — instead of one
+// rocBLAS GEMM per layer forward and two GEMMs + a column sum + scalings per layer backward (~180 launches of 4-8 us
+// per generator forward + backward).
+//   s_l[b, c]  = scale * sum_k lat[b, idx_l, k] * W_l[c, k] + bias_l[c]
+//   gW_l[c, k] = scale * sum_b gs_l[b, c] * lat[b, idx_l, k] ;   gb_l[c] = sum_b gs_l[b, c]
+// Layer l owns blocks [blk_begin, blk_begin + ceil(C_l / 32)); s_l / gs_l are [B, C_l] contiguous at float offset
+// io_off of the flat output / gradient-input buffer, gW_l / gb_l at gw_off / gb_off of the flat gradient buffer.
+// K % 256 == 0, B <= 8.
+#define MB_ROWS 32       // channels per block
+#define MB_MAXB 8
+
+__global__ __launch_bounds__(256) void modbank_fwd_kernel(const float *__restrict__ lat, int B, int n_latent, int K,
+                                                          const rick_modbank_desc *__restrict__ descs, int n, float scale,
+                                                          float *__restrict__ out) {
+    extern __shared__ float sl[];   // [B][K] latent rows of this layer
+    int d = 0;
+    for (int i = 1; i < n; i++)
+        if ((int)blockIdx.x >= descs[i].blk_begin) d = i;
+    const rick_modbank_desc ds = descs[d];
+    for (int j = threadIdx.x; j < B * K; j += 256) {
+        const int b = j / K, k = j - b * K;
+        sl[j] = lat[((int64_t)b * n_latent + ds.lat_idx) * K + k];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = ((int)blockIdx.x - ds.blk_begin) * MB_ROWS + wave * (MB_ROWS / 4);
+    for (int r = 0; r < MB_ROWS / 4; r++) {
+        const int c = c0 + r;
+        if (c >= ds.C) break;                       // wave-uniform
+        const float *wr = ds.w + (int64_t)c * K;
+        float acc[MB_MAXB];
+#pragma unroll
+        for (int b = 0; b < MB_MAXB; b++) acc[b] = 0.f;
+        for (int k = lane * 4; k < K; k += 256) {
+            const float4 wv = *reinterpret_cast<const float4 *>(wr + k);
+#pragma unroll
+            for (int b = 0; b < MB_MAXB; b++)
+                if (b < B) {
+                    const float4 lv = *reinterpret_cast<const float4 *>(sl + b * K + k);
+                    acc[b] = __builtin_fmaf(wv.x, lv.x, acc[b]);
+                    acc[b] = __builtin_fmaf(wv.y, lv.y, acc[b]);
+                    acc[b] = __builtin_fmaf(wv.z, lv.z, acc[b]);
+                    acc[b] = __builtin_fmaf(wv.w, lv.w, acc[b]);
+                }
+        }
+#pragma unroll
+        for (int b = 0; b < MB_MAXB; b++)
+            if (b < B) {
+                const float v = wave_sum(acc[b]);
+                if (lane == 0) out[ds.io_off + (int64_t)b * ds.C + c] = v * scale + (ds.b ? ds.b[c] : 0.f);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void modbank_bwd_kernel(const float *__restrict__ lat, const float *__restrict__ gs, int B,
+                                                          int n_latent, int K, const rick_modbank_desc *__restrict__ descs,
+                                                          int n, float scale, float *__restrict__ grad) {
+    __shared__ float sg[MB_MAXB][MB_ROWS];
+    int d = 0;
+    for (int i = 1; i < n; i++)
+        if ((int)blockIdx.x >= descs[i].blk_begin) d = i;
+    const rick_modbank_desc ds = descs[d];
+    const int c0 = ((int)blockIdx.x - ds.blk_begin) * MB_ROWS;
+    if (threadIdx.x < MB_ROWS * MB_MAXB) {
+        const int b = threadIdx.x / MB_ROWS, r = threadIdx.x % MB_ROWS;
+        sg[b][r] = (b < B && c0 + r < ds.C) ? gs[ds.io_off + (int64_t)b * ds.C + c0 + r] : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < MB_ROWS && c0 + (int)threadIdx.x < ds.C && ds.gb_off >= 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; b++) s += sg[b][threadIdx.x];
+        grad[ds.gb_off + c0 + threadIdx.x] = s;
+    }
+    // thread = (4 consecutive k, row r): gW[c0 + r, k..k+3]
+    const int kq = K / 4;
+    for (int it = threadIdx.x; it < MB_ROWS * kq; it += 256) {
+        const int r = it / kq, k = (it - r * kq) * 4;
+        if (c0 + r >= ds.C) continue;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < B; b++) {
+            const float g = sg[b][r];
+            const float4 lv = *reinterpret_cast<const float4 *>(lat + ((int64_t)b * n_latent + ds.lat_idx) * K + k);
+            a.x = __builtin_fmaf(g, lv.x, a.x);
+            a.y = __builtin_fmaf(g, lv.y, a.y);
+            a.z = __builtin_fmaf(g, lv.z, a.z);
+            a.w = __builtin_fmaf(g, lv.w, a.w);
+        }
+        *reinterpret_cast<float4 *>(grad + ds.gw_off + (int64_t)(c0 + r) * K + k) = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+    }
+}
+
+extern "C" int rick_modbank_blocks(int C) { return cdiv(C, MB_ROWS); }
+
+extern "C" int rick_modbank_fwd_f32(const float *lat, int B, int n_latent, int K, const rick_modbank_desc *descs_device, int n,
+                                    int total_blocks, float scale, float *out, void *stream) {
+    if (!lat || !descs_device || !out || B < 1 || B > MB_MAXB || K < 256 || (K & 255) || n < 1 || total_blocks < 1) return RICK_EINVAL;
+    hipLaunchKernelGGL(modbank_fwd_kernel, dim3((unsigned)total_blocks), dim3(256), (size_t)B * K * 4, (hipStream_t)stream, lat, B,
+                       n_latent, K, descs_device, n, scale, out);
+    RICK_LAUNCH_STATUS();
+}
+
+extern "C" int rick_modbank_bwd_f32(const float *lat, const float *gs, int B, int n_latent, int K,
+                                    const rick_modbank_desc *descs_device, int n, int total_blocks, float scale, float *grad,
+                                    void *stream) {
+    if (!lat || !gs || !descs_device || !grad || B < 1 || B > MB_MAXB || K < 256 || (K & 255) || n < 1 || total_blocks < 1)
+        return RICK_EINVAL;
+    hipLaunchKernelGGL(modbank_bwd_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, lat, gs, B, n_latent, K,
+                       descs_device, n, scale, grad);
+    RICK_LAUNCH_STATUS();
+}

@@ -139,10 +139,12 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
 
-    def forward(self, x, style, tail=None):
+    def forward(self, x, style, tail=None, s=None):
         """tail = (bias, noise, noise_weight, negative_slope, gain): apply StyledConv's NoiseInjection + FusedLeakyReLU
-        as part of this layer (fused into the blur launch of the upsampling variant; first-order mode only)."""
-        s = self.modulation(style)                                   # [B, Ci]
+        as part of this layer (fused into the blur launch of the upsampling variant; first-order mode only).
+        s = modulation(style) when the Generator has already evaluated all modulation layers in one launch."""
+        if s is None:
+            s = self.modulation(style)                               # [B, Ci]
         w = self.weight[0]                                           # [Co, Ci, k, k]
         if self.kernel_size == 1 and self.out_channel <= 4 and not self.demodulate:
             Wn = (self.scale * w.view(1, self.out_channel, self.in_channel)) * s.unsqueeze(1)   # [B, 3, Ci]
@@ -197,14 +199,14 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, x, style, noise=None):
+    def forward(self, x, style, noise=None, s=None):
         if noise is None:
             r = x.shape[2] * 2 if self.conv.upsample else x.shape[2]
             noise = torch.empty(x.shape[0], 1, r, r * x.shape[3] // x.shape[2], device=x.device, dtype=x.dtype).normal_()
         tail = (self.activate.bias, noise, self.noise.weight, self.activate.negative_slope, self.activate.scale)
         if op.second_order_enabled():
-            return fused_noise_bias_act(self.conv(x, style), *tail)
-        return self.conv(x, style, tail)
+            return fused_noise_bias_act(self.conv(x, style, s=s), *tail)
+        return self.conv(x, style, tail, s=s)
 
 
 class ToRGB(nn.Module):
@@ -215,8 +217,8 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
-    def forward(self, x, style, skip=None):
-        out = self.conv(x, style) + self.bias
+    def forward(self, x, style, skip=None, s=None):
+        out = self.conv(x, style, s=s) + self.bias
         if skip is not None:
             out = out + self.upsample(skip)
         return out
@@ -261,6 +263,20 @@ class Generator(nn.Module, _FisherMixin):
             in_channel = out_channel
         self.n_latent = self.log_size * 2 - 2
 
+    def _modulation_bank(self):
+        """ModulationBank over the modulation EqualLinears in forward order (conv1, to_rgb1, then convs / convs / to_rgb per
+        resolution) with the latent row each of them reads."""
+        bank = self.__dict__.get('_modbank')
+        if bank is None:
+            mods, idx = [self.conv1.conv.modulation, self.to_rgb1.conv.modulation], [0, 1]
+            i = 1
+            for blk, to_rgb in enumerate(self.to_rgbs):
+                mods += [self.convs[2 * blk].conv.modulation, self.convs[2 * blk + 1].conv.modulation, to_rgb.conv.modulation]
+                idx += [i, i + 1, i + 2]
+                i += 2
+            bank = self.__dict__['_modbank'] = _mc.ModulationBank(mods, idx)
+        return bank
+
     def make_noise(self):
         device = self.input.input.device
         noises = [torch.randn(1, 1, 4, 4, device=device)]
@@ -295,16 +311,22 @@ class Generator(nn.Module, _FisherMixin):
         feats = []
         # one unbind instead of 20 selects: its backward is a single stack, not zeros + slice-copy + add per use
         lat = latent.unbind(1)
-        out = self.conv1(self.input(latent), lat[0], noise=noise[0])
+        # every modulation linear of the network in one launch (first-order steps whose latent needs no gradient: the D / G
+        # train steps and inference; the path-length step and the Fisher sweep take the per-layer, twice-differentiable path)
+        sb = [None] * (2 + 3 * len(self.to_rgbs))
+        if (latent.is_cuda and not op.second_order_enabled() and not latent.requires_grad and latent.ndim == 3
+                and latent.shape[0] <= 8 and latent.shape[1] == self.n_latent and latent.dtype == torch.float32):
+            sb = self._modulation_bank()(latent)
+        out = self.conv1(self.input(latent), lat[0], noise=noise[0], s=sb[0])
         feats.append(out)
-        skip = self.to_rgb1(out, lat[1])
+        skip = self.to_rgb1(out, lat[1], s=sb[1])
         i = 1
         for blk, to_rgb in enumerate(self.to_rgbs):
-            out = self.convs[2 * blk](out, lat[i], noise=noise[2 * blk + 1])
+            out = self.convs[2 * blk](out, lat[i], noise=noise[2 * blk + 1], s=sb[2 + 3 * blk])
             feats.append(out)
-            out = self.convs[2 * blk + 1](out, lat[i + 1], noise=noise[2 * blk + 2])
+            out = self.convs[2 * blk + 1](out, lat[i + 1], noise=noise[2 * blk + 2], s=sb[3 + 3 * blk])
             feats.append(out)
-            skip = to_rgb(out, lat[i + 2], skip)
+            skip = to_rgb(out, lat[i + 2], skip, s=sb[4 + 3 * blk])
             i += 2
         image = skip.contiguous()
         if return_latents:

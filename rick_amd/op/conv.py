@@ -182,6 +182,16 @@ class PackGroup:
             self._repack()
         return req['buf']
 
+    def refresh(self):
+        """Repack now if any registered request is stale (one launch).  RickTrainer calls this on the host before it
+        captures or replays a step graph, so the graphs themselves contain no pack launches and a network is repacked
+        once per update of its weights instead of once per step graph that uses it."""
+        for r in self.reqs.values():
+            if r['stamp'] != (r['param']._version, _weights_epoch, self.epoch, _SPLIT):
+                self._repack()
+                return True
+        return False
+
     def _repack(self):
         # requests whose parameter storage moved (e.g. .to(), re-flattening) are dropped; they re-register on use
         stale = [k for k, r in self.reqs.items() if r['param'].data_ptr() + r['off'] != r['desc'][0]]

@@ -14,6 +14,7 @@ Two implementations with identical values:
 """
 import ctypes
 
+import numpy as np
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -181,3 +182,107 @@ def modulated_conv_fused(x, w, s, d, wscale, upsample, key=None, tail=None):
         return _ModConvFused.apply(x, w, s, d, float(wscale), bool(upsample), key, None, None, None, 0.2, 1.0)
     bias, noise, nw, slope, gain = tail
     return _ModConvFused.apply(x, w, s, d, float(wscale), bool(upsample), key, bias, noise, nw, float(slope), float(gain))
+
+
+# ------------------------------------------------------------------------------------ modulation bank
+# rick_modbank_desc (include/rick_hip.h), 56 bytes
+_MB_DESC = np.dtype([('w', '<u8'), ('b', '<u8'), ('io_off', '<i8'), ('gw_off', '<i8'), ('gb_off', '<i8'), ('C', '<i4'),
+                     ('lat_idx', '<i4'), ('blk_begin', '<i4'), ('reserved', '<i4')])
+
+
+class ModulationBank:
+    """The style -> per-channel scale linears of every modulated convolution of a generator
+    (``ModulatedConv2d.modulation``, model_probe_tune.py:233,246) evaluated by ONE launch, their weight / bias gradients
+    by one more (rick_modbank_{fwd,bwd}_f32) — the per-layer form costs a rocBLAS GEMM forward and two GEMMs, a column
+    sum and several scalings backward, ~180 launches of 4-8 us per generator forward + backward.  `linears` are the
+    EqualLinear modules in layer order, `lat_idx` the latent row each of them reads."""
+
+    def __init__(self, linears, lat_idx):
+        self.linears, self.lat_idx = list(linears), list(lat_idx)
+        self.C = [m.weight.shape[0] for m in self.linears]
+        self.K = self.linears[0].weight.shape[1]
+        self.scale = self.linears[0].scale
+        if any(m.weight.shape[1] != self.K or m.scale != self.scale or m.lr_mul != 1 or m.activation for m in self.linears):
+            raise RuntimeError('ModulationBank: layers must share style_dim / scale and have no activation')
+        self._tables = {}      # batch -> (device table, pointer signature); old tables are kept (graphs may read them)
+        self._retired = []
+        # gradient layout: [W_0 | b_0 | W_1 | b_1 ...], each start 16-byte aligned
+        self.gw_off, self.gb_off, pos = [], [], 0
+        for c in self.C:
+            self.gw_off.append(pos)
+            pos += c * self.K
+            self.gb_off.append(pos)
+            pos += (c + 3) // 4 * 4
+        self.grad_floats = pos
+        self.blk_begin, blk = [], 0
+        for c in self.C:
+            self.blk_begin.append(blk)
+            blk += lib.rick_modbank_blocks(c)
+        self.total_blocks = blk
+
+    def params(self):
+        out = []
+        for m in self.linears:
+            out += [m.weight, m.bias]
+        return out
+
+    def table(self, B, device):
+        sig = tuple(p.data_ptr() for p in self.params())
+        ent = self._tables.get(B)
+        if ent is None or ent[1] != sig:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('ModulationBank: descriptor table must be built before hipGraph capture (run the step eagerly once)')
+            arr = np.zeros(len(self.linears), dtype=_MB_DESC)
+            io = 0
+            for i, m in enumerate(self.linears):
+                arr[i] = (m.weight.data_ptr(), m.bias.data_ptr(), io, self.gw_off[i], self.gb_off[i], self.C[i], self.lat_idx[i],
+                          self.blk_begin[i], 0)
+                io += B * self.C[i]
+            if ent is not None:
+                self._retired.append(ent[0])
+            ent = (torch.from_numpy(arr.view(np.uint8).copy()).to(device), sig)
+            self._tables[B] = ent
+        return ent[0]
+
+    def __call__(self, latent):
+        """latent [B, n_latent, K] (no gradient is produced for it) -> list of s_l [B, C_l]."""
+        require_cuda_f32(latent)
+        return list(_ModBank.apply(latent.contiguous(), self, *self.params()))
+
+
+class _ModBank(Function):
+    @staticmethod
+    def forward(ctx, latent, bank, *params):
+        B, n_latent, K = latent.shape
+        if K != bank.K or B > 8:
+            raise RuntimeError('ModulationBank: unsupported latent shape')
+        tab = bank.table(B, latent.device)
+        out = torch.empty(B * sum(bank.C), device=latent.device, dtype=latent.dtype)
+        check(lib.rick_modbank_fwd_f32(ptr(latent), B, n_latent, K, ptr(tab), len(bank.C), bank.total_blocks, bank.scale, ptr(out),
+                                       stream_ptr()), 'rick_modbank_fwd_f32')
+        ctx.save_for_backward(latent)
+        ctx.bank = bank
+        res, off = [], 0
+        for c in bank.C:
+            res.append(out[off:off + B * c].view(B, c))
+            off += B * c
+        return tuple(res)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gs):
+        (latent,) = ctx.saved_tensors
+        bank = ctx.bank
+        B, n_latent, K = latent.shape
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError('ModulationBank produces no latent gradient; use the per-layer path when the latent requires grad')
+        flat = torch.cat([(g if g is not None else latent.new_zeros(B, c)).reshape(-1) for g, c in zip(gs, bank.C)])
+        grad = torch.empty(bank.grad_floats, device=latent.device, dtype=latent.dtype)
+        check(lib.rick_modbank_bwd_f32(ptr(latent), ptr(flat), B, n_latent, K, ptr(bank.table(B, latent.device)), len(bank.C),
+                                       bank.total_blocks, bank.scale, ptr(grad), stream_ptr()), 'rick_modbank_bwd_f32')
+        res = [None, None]
+        for i, c in enumerate(bank.C):
+            need_w, need_b = ctx.needs_input_grad[2 + 2 * i], ctx.needs_input_grad[3 + 2 * i]
+            res.append(grad[bank.gw_off[i]:bank.gw_off[i] + c * K].view(c, K) if need_w else None)
+            res.append(grad[bank.gb_off[i]:bank.gb_off[i] + c] if need_b else None)
+        return tuple(res)

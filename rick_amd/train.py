@@ -363,7 +363,9 @@ class RickTrainer:
     def __init__(self, cfg, generator, discriminator, g_ema, d_ema, dp=None):
         self.cfg, self.g, self.d, self.g_ema, self.d_ema, self.dp = cfg, generator, discriminator, g_ema, d_ema, dp
         self.device = next(generator.parameters()).device
-        for net in (generator, discriminator, g_ema, d_ema):      # packed conv weights: one refresh launch per network
+        # packed conv weights: one refresh launch per network
+        self._pack_groups = [op.register_pack_group(net) for net in (generator, discriminator)]
+        for net in (g_ema, d_ema):
             op.register_pack_group(net)
         self.g_flat = FlatParams(generator.named_parameters(), g_optim_filter)
         self.d_flat = FlatParams(discriminator.named_parameters(), d_optim_filter)
@@ -482,8 +484,11 @@ class RickTrainer:
             return
         if 'graphs' in st and st['sig'] != self._graph_signature(optim):
             del st['graphs']                                  # optimiser state / stage changed under the capture: redo it
+        # packed weights are refreshed HERE, on the host side of the graph: a network is repacked once per update of its
+        # weights (the D step's graph used to repack G again although the G step's graph had just done so, and vice versa)
+        for grp in self._pack_groups:
+            grp.refresh()
         if 'graphs' not in st:
-            op.bump_weights_epoch()                           # every pack refresh the step needs lands inside its graph
             torch.cuda.synchronize()
             before = list(optim.steps)
             seen = dict(self.losses)

@@ -494,3 +494,31 @@ def test_modconv_fused_tail_equals_two_pass(B, I, O, H, nb):
             assert rel_err(c, a) < 2e-5
         else:
             assert torch.equal(a, c), k
+
+
+@pytest.mark.parametrize('B', [1, 2, 4, 8])
+def test_modulation_bank_equals_per_layer_linears(B):
+    """rick_modbank_{fwd,bwd}_f32 (every modulation EqualLinear of a generator in one launch) vs the per-layer
+    EqualLinear path (model_probe_tune.py:139-173,233): values, weight and bias gradients."""
+    from rick_amd.models import Generator
+    torch.manual_seed(5)
+    g = Generator(64, 512, 8).to(DEV)
+    bank = g._modulation_bank()
+    for m in bank.linears:                         # non-trivial biases
+        m.bias.data.normal_()
+    lat = torch.randn(B, g.n_latent, 512, device=DEV)
+    outs = bank(lat)
+    refs = [m(lat[:, i]) for m, i in zip(bank.linears, bank.lat_idx)]
+    assert len(outs) == len(refs) == 2 + 3 * len(g.to_rgbs)
+    for o, r in zip(outs, refs):
+        assert o.shape == r.shape and o.is_contiguous()
+        assert rel_err(o, r.double()) < 2e-6
+    gs = [torch.randn_like(o) for o in outs]
+    params = bank.params()
+    got = torch.autograd.grad(outs, params, gs)
+    ref = torch.autograd.grad(refs, params, gs)
+    for a, b in zip(got, ref):
+        assert rel_err(a, b.double()) < 3e-6
+    # unused outputs (None gradients) are treated as zeros
+    got2 = torch.autograd.grad(bank(lat)[3].sum(), [params[6], params[7]], allow_unused=True)
+    assert rel_err(got2[1], torch.full_like(got2[1], float(B)).double()) < 1e-6

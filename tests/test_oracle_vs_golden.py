@@ -177,3 +177,24 @@ def test_decisions_restated(golden):
         nprune = int((conv <= pr).sum())
         assert abs(nfreeze - round(4864 * (100 - fq) / 100)) <= 2
         assert 1 <= nprune <= 6
+
+
+def test_reference_fp32_vs_fp64_spread(golden):
+    """How far the REFERENCE's own fp32 run (tests/golden/full256.npz, the arithmetic it trains in) sits from its own
+    fp64 run (spread256.npz) at 256 px, per parameter key of the D / G loss gradients: the yardstick the GPU parity
+    bounds are quoted against (tests/test_gpu_models.py::check_grad2).  LeakyReLU sign flips of ~0 pre-activations are
+    the only mechanism that can move a key by more than rounding; at fp32 they move it by <= 5e-5 (noise strengths,
+    scalar sums over a whole feature map with heavy cancellation: <= 2e-2)."""
+    a, b = golden('full256'), golden('spread256')
+    assert abs(float(a['f256/d_loss']) - float(b['f256_f64/d_loss'])) < 2e-6 * float(b['f256_f64/d_loss'])
+    assert np.abs(a['f256/img_samples'] - b['f256_f64/img_samples']).max() < 1e-5 * np.abs(b['f256_f64/img_samples']).max()
+    for pre in ('d_grad2', 'g_grad2'):
+        rels, noise = [], []
+        for k in b.files:
+            if not k.startswith(f'f256_f64/{pre}/'):
+                continue
+            r64, r32 = float(b[k]), float(a[k.replace('f256_f64', 'f256')])
+            if r64 > 0:
+                (noise if k.endswith('noise.weight') else rels).append(abs(r32 - r64) / r64)
+        assert len(rels) > 30 and np.median(rels) < 1e-5 and max(rels) < 5e-5, (pre, np.median(rels), max(rels))
+        assert not noise or max(noise) < 2e-2, (pre, max(noise))
