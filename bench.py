@@ -93,8 +93,9 @@ def main():
     ap.add_argument('--no-step-times', action='store_true')
     ap.add_argument('--no-fisher', action='store_true', help='skip the (untimed) Fisher sweep; masks stay empty (profiling runs)')
     ap.add_argument('--no-graphs', action='store_true', help='issue every launch from Python instead of replaying captured hipGraphs')
-    ap.add_argument('--graphs', action='store_true', help='replay captured step graphs also with N > 1 (default: N = 1 only; '
-                    'with data parallelism the eager path overlaps the bucketed all-reduce with backward)')
+    ap.add_argument('--graphs', action='store_true', help='(default) replay captured step graphs; with N > 1 each step is a '
+                    'forward/backward graph, the bucketed RCCL all-reduce, and an optimiser graph (--no-graphs: eager issue, '
+                    'all-reduce launched from autograd hooks and overlapped with backward, but host-bound)')
     ap.add_argument('--eval', action='store_true', help='also time G inference (BASELINE config 4: batches of 25)')
     ap.add_argument('--fisher-img', type=int, default=2, help='samples of the (untimed) Fisher sweep that sets the masks')
     args = ap.parse_args()
@@ -138,7 +139,7 @@ def main():
                         [synth_reals(1, cfg.size, seed=600 + j).to(dev) for j in mine], first=True)
 
     i0 = cfg.warmup_iter + 1
-    use_graphs = (args.graphs or world == 1) and not args.no_graphs
+    use_graphs = not args.no_graphs
     if use_graphs:
         try:
             tr.enable_graphs(True)

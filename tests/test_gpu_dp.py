@@ -96,3 +96,132 @@ def test_two_rank_trainer_bucketed_equals_blocking_allreduce():
         assert np.array_equal(a[0][net], a[1][net])               # replicas stay identical
         assert np.isfinite(a[0][net]).all()
         assert np.array_equal(a[0][net], b[0][net])               # same update as the plain exchange
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The data-parallel invariant for the REAL trainer: the gradients two ranks hold after the bucketed
+# exchange equal the gradients ONE process computes on the concatenated global batch when minibatch-stddev keeps
+# per-rank groups (nn.DataParallel's per-device chunks, train_dynamic_update_prune.py:941-944) — for the D step, the G step
+# and (graph mode) the split forward/backward-graph -> all-reduce -> optimiser-graph form; and a Fisher sweep sharded over
+# the ranks yields bit-identical masks on every rank, equal to the single-process sweep over all samples.
+def _inv_inputs(size, B, world):
+    from rick_amd.synth import synth_latents, synth_reals, synth_tensor
+    z = [synth_latents(B, seed=300 + r) for r in range(world)]
+    real = [synth_reals(B, size=size, seed=400 + r) for r in range(world)]
+    fz = [synth_latents(1, seed=500 + j) for j in range(4)]
+    fr = [synth_reals(1, size=size, seed=600 + j) for j in range(4)]
+    return z, real, fz, fr
+
+
+def _inv_build(size, dev):
+    from rick_amd.models import Discriminator, Generator
+    from rick_amd.synth import synth_state_dict
+    from tests.shapes import discriminator_shapes, generator_shapes
+    g = Generator(size, 512, 8, channel_multiplier=2)
+    d = Discriminator(size, channel_multiplier=2)
+    g.load_state_dict(synth_state_dict(generator_shapes(size)), strict=False)
+    d.load_state_dict(synth_state_dict(discriminator_shapes(size)), strict=False)
+    return g.to(dev), d.to(dev)
+
+
+def _inv_worker(rank, world, port, graphs, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from rick_amd.dist import DataParallelGrads, init_from_env
+    from rick_amd.train import RickTrainer, TrainConfig
+    init_from_env('gloo')
+    size, B, dev = 32, 2, 'cuda:0'
+    g, d = _inv_build(size, dev)
+    tr = RickTrainer(TrainConfig(size=size, batch=B, warmup_iter=0, num_fisher_img=4, prune_quantile=1.0), g, d,
+                     *_inv_build(size, dev), dp=DataParallelGrads(bucket_bytes=256 * 1024))
+    z, real, fz, fr = _inv_inputs(size, B, world)
+    noises = [getattr(g.noises, f'noise_{i}') for i in range(g.num_layers)]
+    out = {}
+    # Fisher sweep: samples j = rank, rank + world, ... on this rank; per-filter vectors summed over ranks
+    mine = list(range(rank, 4, world))
+    tr.fisher_sweep([fz[j].to(dev) for j in mine], [fr[j].to(dev) for j in mine], first=True, fixed_noise=True)
+    out['mask_g'], out['mask_d'] = tr.g_optim.mask.cpu().numpy(), tr.d_optim.mask.cpu().numpy()
+    tr.g_optim.mask.zero_()
+    tr.d_optim.mask.zero_()
+    # keep parameters where they are (the gradients of repeated steps stay comparable): learning rate 0
+    tr.d_optim.lr = 0.0
+    tr.g_optim.lr = 0.0
+    if graphs:
+        tr.enable_graphs(True)
+        lat = {'d': tr.g.style(z[rank].to(dev)).unsqueeze(1).repeat(1, g.n_latent, 1).detach(),
+               'g': tr.g.style(z[rank].to(dev)).unsqueeze(1).repeat(1, g.n_latent, 1).detach()}
+        tr._draw_inject('d')
+        tr._draw_inject('g')
+        tr._graph_latents = lambda key, batch: lat[key]
+        static_real = real[rank].to(dev).clone()
+        for _ in range(4):                                       # two eager runs, the capture, one replay
+            tr.d_step(static_real, None, g_noise=noises, graph=True)
+        out['d_grad'] = tr.d_flat.grad.cpu().numpy()
+        for _ in range(4):
+            tr.g_step(None, g_noise=noises, graph=True)
+        out['g_grad'] = tr.g_flat.grad.cpu().numpy()
+        assert 'graphs' in tr._gs['d'] and len(tr._gs['d']['graphs']) == 2
+    else:
+        tr.d_step(real[rank].to(dev), [z[rank].to(dev)], g_noise=noises)
+        out['d_grad'] = tr.d_flat.grad.cpu().numpy()
+        tr.g_step([z[rank].to(dev)], g_noise=noises)
+        out['g_grad'] = tr.g_flat.grad.cpu().numpy()
+    torch.cuda.synchronize()
+    q.put((rank, out))
+    torch.distributed.destroy_process_group()
+
+
+def _inv_run(graphs):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [ctx.Process(target=_inv_worker, args=(r, 2, port, graphs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=900) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return [o[1] for o in outs]
+
+
+@pytest.mark.parametrize('graphs', [False, True], ids=['eager_buckets', 'split_graphs'])
+def test_two_rank_gradients_equal_single_process_global_batch(graphs):
+    from rick_amd.train import RickTrainer, TrainConfig, d_logistic_loss, g_nonsaturating_loss
+    a, b = _inv_run(graphs)
+    for k in ('d_grad', 'g_grad', 'mask_g', 'mask_d'):
+        assert np.array_equal(a[k], b[k]), k                    # identical on both ranks (gradients AND masks)
+    # ---- single process, global batch 2 x B, minibatch-stddev in per-rank groups
+    size, B, world, dev = 32, 2, 2, 'cuda:0'
+    g, d = _inv_build(size, dev)
+    tr = RickTrainer(TrainConfig(size=size, batch=B * world, warmup_iter=0, num_fisher_img=4, prune_quantile=1.0), g, d,
+                     *_inv_build(size, dev))
+    z, real, fz, fr = _inv_inputs(size, B, world)
+    noises = [getattr(g.noises, f'noise_{i}') for i in range(g.num_layers)]
+    tr.fisher_sweep([t.to(dev) for t in fz], [t.to(dev) for t in fr], first=True, fixed_noise=True)
+    for got, ref in ((a['mask_g'], tr.g_optim.mask.cpu().numpy()), (a['mask_d'], tr.d_optim.mask.cpu().numpy())):
+        # (per-filter sums are added in a different order across ranks: a filter sitting exactly on a percentile line may move)
+        assert (got != ref).mean() < 2e-3
+    zc, rc = torch.cat(z).to(dev), torch.cat(real).to(dev)
+    with torch.no_grad():
+        fake, _ = g([zc], noise=noises)
+    tr._set_d_stage(10 ** 9)
+    pred, _ = d(torch.cat([fake, rc], 0), calls=2 * world)       # [fake r0 | fake r1 | real r0 | real r1], one stddev group per rank and call
+    fake_pred, real_pred = pred.chunk(2, 0)
+    tr.d_flat.zero_grad()
+    d_logistic_loss(real_pred, fake_pred).backward()
+    ref = tr.d_flat.grad.cpu().numpy()
+    # (batch 2 per rank vs batch 4 in one pass: other tiles, split-K and summation orders of the bf16x3 kernels)
+    assert np.abs(a['d_grad'] - ref).max() <= 5e-4 * np.abs(ref).max(), np.abs(a['d_grad'] - ref).max() / np.abs(ref).max()
+    assert np.linalg.norm(a['d_grad'] - ref) <= 1e-3 * np.linalg.norm(ref)
+    fake, _ = g([zc], noise=noises)
+    with tr._d_frozen():
+        fp, _ = d(fake, calls=world)
+        tr.g_flat.zero_grad()
+        g_nonsaturating_loss(fp).backward()
+    ref = tr.g_flat.grad.cpu().numpy()
+    assert np.abs(a['g_grad'] - ref).max() <= 5e-4 * np.abs(ref).max(), np.abs(a['g_grad'] - ref).max() / np.abs(ref).max()
+    assert np.linalg.norm(a['g_grad'] - ref) <= 1e-3 * np.linalg.norm(ref)
