@@ -286,6 +286,15 @@ int rick_masked_adam_dev_f32(float *p, float *g, float *m, float *v, const uint8
 /* ema[i] = ema[i]*decay + p[i]*(1-decay) */
 int rick_ema_f32(float *ema, const float *p, int64_t n, float decay, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Data path (dataset.py:8-40, train_dynamic_update_prune.py:789-843).  The dataset stays resident in device memory as
+ * uint8 [N, H, W, 3]; one launch builds a training batch: out[b, c, y, x] = (images[index[b], y, flip[b] ? W-1-x : x, c]
+ * / 255 - 0.5) / 0.5 — ToTensor + RandomHorizontalFlip + Normalize(0.5, 0.5) of the reference transform, [B, 3, H, W]. */
+int rick_image_batch_f32(const uint8_t *images, const int64_t *index, const uint8_t *flip, float *out,
+                         int N, int H, int W, int B, void *stream);
+/* PNG scanline reconstruction (filter types 0-4), in place, HOST memory: H rows of 1 filter byte + stride bytes. */
+int rick_png_unfilter(uint8_t *data, int H, int stride, int bpp);
+
 #ifdef __cplusplus
 }
 #endif

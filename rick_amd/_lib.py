@@ -87,6 +87,8 @@ SIGNATURES = {
     'rick_adam_prepare_f32': (c_int, [c_fp, c_int, c_int, c_f, c_f, c_fp, c_fp]),
     'rick_masked_adam_dev_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f, c_f, c_f, c_f, c_fp, c_fp]),
     'rick_ema_f32': (c_int, [c_fp, c_fp, c_i64, c_f, c_fp]),
+    'rick_image_batch_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    'rick_png_unfilter': (c_int, [c_fp, c_int, c_int, c_int]),
 }
 
 if not os.path.exists(LIB_PATH):
