@@ -250,7 +250,7 @@ int rick_demod_f32(const float *s, const float *wsq, float *d, int B, int I, int
 int rick_demod_bwd_s_f32(const float *s, const float *wsq, const float *d, const float *gd, float *gs, int B, int I, int O,
                          void *stream);
 int rick_demod_bwd_w_f32(const float *w, const float *s, const float *d, const float *gd, float *gw, int B, int I, int O,
-                         int K, float scale, void *stream);
+                         int K, float scale, int accumulate, void *stream);
 /* Modulation bank: s_l = EqualLinear_l(latent[:, idx_l]) for EVERY modulated convolution of the generator
  * (ModulatedConv2d.modulation, model_probe_tune.py:233,246) in one launch, and the weight / bias gradients of all of
  * them in one more.  lat is [B, n_latent, K]; layer l owns blocks [blk_begin, blk_begin + rick_modbank_blocks(C_l));

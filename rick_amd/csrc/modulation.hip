@@ -152,7 +152,8 @@ extern "C" int rick_demod_bwd_s_f32(const float *s, const float *wsq, const floa
 // gw[o,i,k] = 2 scale^2 w[o,i,k] * sum_b t[b,o] s[b,i]^2
 __global__ __launch_bounds__(256) void demod_bwd_w_kernel(const float *__restrict__ w, const float *__restrict__ s,
                                                           const float *__restrict__ d, const float *__restrict__ gd,
-                                                          float *__restrict__ gw, int B, int I, int O, int K, float scale2) {
+                                                          float *__restrict__ gw, int B, int I, int O, int K, float scale2,
+                                                          int accumulate) {
     const int64_t OI = (int64_t)O * I;
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < OI; j += (int64_t)gridDim.x * 256) {
         const int o = (int)(j / I), i = (int)(j - (int64_t)o * I);
@@ -162,17 +163,20 @@ __global__ __launch_bounds__(256) void demod_bwd_w_kernel(const float *__restric
             acc = __builtin_fmaf(-0.5f * dv * dv * dv * gd[(int64_t)b * O + o], sv * sv, acc);
         }
         const float f = 2.f * scale2 * acc;
-        for (int k = 0; k < K; k++) gw[j * K + k] = w[j * K + k] * f;
+        if (accumulate)
+            for (int k = 0; k < K; k++) gw[j * K + k] += w[j * K + k] * f;
+        else
+            for (int k = 0; k < K; k++) gw[j * K + k] = w[j * K + k] * f;
     }
 }
 
 extern "C" int rick_demod_bwd_w_f32(const float *w, const float *s, const float *d, const float *gd, float *gw, int B, int I,
-                                    int O, int K, float scale, void *stream) {
+                                    int O, int K, float scale, int accumulate, void *stream) {
     if (!w || !s || !d || !gd || !gw || B <= 0 || I <= 0 || O <= 0 || K <= 0) return RICK_EINVAL;
     int64_t nb = cdiv64((int64_t)O * I, 256);
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(demod_bwd_w_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, s, d, gd, gw, B, I, O, K,
-                       scale * scale);
+                       scale * scale, accumulate);
     RICK_LAUNCH_STATUS();
 }
 

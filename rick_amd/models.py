@@ -150,9 +150,10 @@ class ModulatedConv2d(nn.Module):
             Wn = (self.scale * w.view(1, self.out_channel, self.in_channel)) * s.unsqueeze(1)   # [B, 3, Ci]
             return op.thin_fwd(x, Wn)                                # planar [B, 3, H, W]
         d = None
-        if self.demodulate:     # composed tensor algebra when a second derivative is needed, 2 + 2 launches otherwise
-            d = (_mc.demod_coeff if op.second_order_enabled() else _mc.demod_coeff_fused)(w, s, self.scale, self.eps)
         key = (self.weight, 'mod')
+        if self.demodulate:     # composed tensor algebra when a second derivative is needed, 2 + 2 launches otherwise
+            d = (_mc.demod_coeff(w, s, self.scale, self.eps) if op.second_order_enabled()
+                 else _mc.demod_coeff_fused(w, s, self.scale, self.eps, key))
         if op.second_order_enabled():
             y = _mc.modulated_conv_composed(x, w, s, None, self.scale, self.upsample, key)
             if self.upsample:

@@ -400,8 +400,40 @@ def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alph
     return y
 
 
-def _wgrad_launch(a, b, kh, kw, s, p, alpha=1.0, ascale=None, bscale=None):
-    """gw[o,i,ky,kx] = alpha * sum a[n,o,pos] b[n,i,pos*s + k - p]  -> contiguous [O, I, kh, kw]."""
+_GRAD_SINK = False
+
+
+class grad_sink:
+    """Inside this context the first-order conv / modulated-conv backward ADDS a weight gradient straight into the
+    parameter's existing ``.grad`` (the trainer's flat gradient buffer) from the wgrad kernel's second stage and reports
+    no gradient to autograd — instead of materialising it, routing it through the select / view nodes of the parameter and
+    an AccumulateGrad add (three extra passes over a 9.4 MB tensor per 512x512 layer).  Only valid around a plain
+    ``loss.backward()`` on leaf parameters whose ``.grad`` is allocated (RickTrainer's D / G steps); ``autograd.grad`` users
+    (Fisher sweep, tests) never enable it."""
+
+    def __enter__(self):
+        global _GRAD_SINK
+        self.prev, _GRAD_SINK = _GRAD_SINK, True
+
+    def __exit__(self, *a):
+        global _GRAD_SINK
+        _GRAD_SINK = self.prev
+
+
+def _sink_target(key, shape):
+    """The [O, I, kh, kw] view of the parameter's .grad a weight gradient may be added into, or None."""
+    if not _GRAD_SINK or key is None:
+        return None
+    p = key[0]
+    if not (p.is_leaf and p.requires_grad and p.grad is not None and p.grad.is_contiguous() and p.numel() == int(np.prod(shape))):
+        return None
+    return p.grad.view(shape)
+
+
+def _wgrad_launch(a, b, kh, kw, s, p, alpha=1.0, ascale=None, bscale=None, out=None, transposed=False):
+    """gw[o,i,ky,kx] = alpha * sum a[n,o,pos] b[n,i,pos*s + k - p]  -> contiguous [O, I, kh, kw].
+    `out`: ADD the result into this contiguous tensor instead ([O, I, kh, kw], or [I, O, kh, kw] when `transposed` — the
+    parameter layout of a transposed convolution's weight gradient)."""
     a, b = _nhwc(a), _nhwc(b)
     N, O, AH, AW = a.shape
     _, I, BH, BW = b.shape
@@ -419,9 +451,15 @@ def _wgrad_launch(a, b, kh, kw, s, p, alpha=1.0, ascale=None, bscale=None):
                f'wgrad {I}x{O} k{kh} s{s} N{N} a{AH}x{AW} b{BH}x{BW}')
         _geom_cache[key] = ent
     g, gref, nbytes, flops, tag = ent
-    gw = torch.empty((O, I, kh, kw), device=a.device, dtype=a.dtype)
     ws = torch.empty(nbytes, device=a.device, dtype=torch.uint8)
-    check(_launch('wgrad', flops, lib.rick_conv_wgrad_f32, ptr(b), ptr(a), ptr(gw), I * kh * kw, kh * kw, 1,
+    K = kh * kw
+    if out is not None:
+        s_co, s_ci = (K, O * K) if transposed else (I * K, K)
+        check(_launch('wgrad', flops, lib.rick_conv_wgrad_f32, ptr(b), ptr(a), ptr(out), s_co, s_ci, 1,
+                      ptr(ascale), ptr(bscale), gref, 1, ptr(ws), stream_ptr(), tag=tag), 'rick_conv_wgrad_f32')
+        return None
+    gw = torch.empty((O, I, kh, kw), device=a.device, dtype=a.dtype)
+    check(_launch('wgrad', flops, lib.rick_conv_wgrad_f32, ptr(b), ptr(a), ptr(gw), I * K, K, 1,
                   ptr(ascale), ptr(bscale), gref, 0, ptr(ws), stream_ptr(), tag=tag), 'rick_conv_wgrad_f32')
     return gw
 
@@ -525,7 +563,7 @@ class _ConvBiasAct(Function):
             wpT = _pack(w.transpose(0, 1), wscale, key and (key[0], key[1] + '/T/convT'))
             gx = _convT_launch(gz, wpT, I, kh, kw, s, p, (x.shape[2], x.shape[3]))
         if ctx.needs_input_grad[1]:
-            gw = _wgrad_launch(gz, x, kh, kw, s, p, wscale)
+            gw = _wgrad_launch(gz, x, kh, kw, s, p, wscale, out=_sink_target(key, w.shape))
         return gx, gw, (gb if ctx.needs_input_grad[2] else None), None, None, None, None, None, None
 
 

@@ -20,7 +20,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .._lib import check, lib, ptr, require_cuda_f32, stream_ptr
-from .conv import _conv_launch, _convT_launch, _epilogue, _pack, _wgrad_launch, conv2d, conv_transpose2d
+from .conv import _conv_launch, _convT_launch, _epilogue, _pack, _sink_target, _wgrad_launch, conv2d, conv_transpose2d
 from .misc import _chan_scale_raw, _hw_dot_raw, chan_scale
 
 
@@ -46,7 +46,7 @@ class _DemodFused(Function):
     the network is made of.  Under op.second_order() the composed form is used instead."""
 
     @staticmethod
-    def forward(ctx, w, s, wscale, eps):
+    def forward(ctx, w, s, wscale, eps, key=None):
         O, I, kh, kw = w.shape
         w = w.contiguous()
         s = s.contiguous()
@@ -57,6 +57,7 @@ class _DemodFused(Function):
         check(lib.rick_demod_f32(ptr(s), ptr(wsq), ptr(d), B, I, O, float(eps), stream_ptr()), 'rick_demod_f32')
         ctx.save_for_backward(w, s, wsq, d)
         ctx.wscale = float(wscale)
+        ctx.key = key
         return d
 
     @staticmethod
@@ -72,18 +73,20 @@ class _DemodFused(Function):
             check(lib.rick_demod_bwd_s_f32(ptr(s), ptr(wsq), ptr(d), ptr(gd), ptr(gs), B, I, O, stream_ptr()),
                   'rick_demod_bwd_s_f32')
         if ctx.needs_input_grad[0]:
-            gw = torch.empty_like(w)
-            check(lib.rick_demod_bwd_w_f32(ptr(w), ptr(s), ptr(d), ptr(gd), ptr(gw), B, I, O, kh * kw, ctx.wscale,
-                                           stream_ptr()), 'rick_demod_bwd_w_f32')
-        return gw, gs, None, None
+            sink = _sink_target(ctx.key, w.shape)      # op.grad_sink(): add straight into the parameter's .grad
+            gw = torch.empty_like(w) if sink is None else None
+            check(lib.rick_demod_bwd_w_f32(ptr(w), ptr(s), ptr(d), ptr(gd), ptr(sink if sink is not None else gw), B, I, O,
+                                           kh * kw, ctx.wscale, int(sink is not None), stream_ptr()), 'rick_demod_bwd_w_f32')
+        return gw, gs, None, None, None
 
 
-def demod_coeff_fused(w, s, wscale, eps=1e-8):
-    """Same values as demod_coeff; first-order differentiable; needs B <= 32 (falls back to the composed form)."""
+def demod_coeff_fused(w, s, wscale, eps=1e-8, key=None):
+    """Same values as demod_coeff; first-order differentiable; needs B <= 32 (falls back to the composed form).
+    `key` = (parameter, tag) lets op.grad_sink() add the weight gradient straight into the parameter's .grad."""
     require_cuda_f32(w, s)
     if s.shape[0] > 32:
         return demod_coeff(w, s, wscale, eps)
-    return _DemodFused.apply(w, s, wscale, eps)
+    return _DemodFused.apply(w, s, wscale, eps, key)
 
 
 class _ModConvFused(Function):
@@ -140,10 +143,12 @@ class _ModConvFused(Function):
             if ctx.needs_input_grad[0]:
                 gx = _chan_scale_raw(gxu, s)
         if ctx.needs_input_grad[1]:
+            sink = _sink_target(key, w.shape)     # op.grad_sink(): add straight into the parameter's .grad
             if upsample:   # convT: gw[o,i,k] = sum x[pos,i] g[pos*2+k, o]  (a = x, b = g), transposed back
-                gw = _wgrad_launch(x, g, kh, kw, 2, 0, wscale, ascale=s, bscale=d).transpose(0, 1)
+                gw = _wgrad_launch(x, g, kh, kw, 2, 0, wscale, ascale=s, bscale=d, out=sink, transposed=True)
+                gw = gw.transpose(0, 1) if gw is not None else None
             else:
-                gw = _wgrad_launch(g, x, kh, kw, 1, kh // 2, wscale, ascale=d, bscale=s)
+                gw = _wgrad_launch(g, x, kh, kw, 1, kh // 2, wscale, ascale=d, bscale=s, out=sink)
         if d is not None and ctx.needs_input_grad[3]:
             # conv_out = d * y'  ->  sum g*y' = (sum g*conv_out) / d,  d > 0
             if tail:
@@ -262,10 +267,16 @@ class _ModBank(Function):
                                        stream_ptr()), 'rick_modbank_fwd_f32')
         ctx.save_for_backward(latent)
         ctx.bank = bank
-        res, off = [], 0
-        for c in bank.C:
+        res, off, dead = [], 0, []
+        for i, c in enumerate(bank.C):
             res.append(out[off:off + B * c].view(B, c))
             off += B * c
+            # a layer whose modulation parameters are frozen (ToRGB: the optimiser owns only `convs.*`,
+            # train_dynamic_update_prune.py:908-917) must not make its consumer compute a style gradient
+            if not (params[2 * i].requires_grad or params[2 * i + 1].requires_grad):
+                dead.append(res[-1])
+        if dead:
+            ctx.mark_non_differentiable(*dead)
         return tuple(res)
 
     @staticmethod
