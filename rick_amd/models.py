@@ -139,19 +139,19 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
 
-    def forward(self, x, style, tail=None, s=None):
+    def forward(self, x, style, tail=None, s=None, d=None):
         """tail = (bias, noise, noise_weight, negative_slope, gain): apply StyledConv's NoiseInjection + FusedLeakyReLU
         as part of this layer (fused into the blur launch of the upsampling variant; first-order mode only).
-        s = modulation(style) when the Generator has already evaluated all modulation layers in one launch."""
+        s = modulation(style) (and d, the demodulation coefficients) when the Generator has already evaluated them for
+        all layers at once."""
         if s is None:
             s = self.modulation(style)                               # [B, Ci]
         w = self.weight[0]                                           # [Co, Ci, k, k]
         if self.kernel_size == 1 and self.out_channel <= 4 and not self.demodulate:
             Wn = (self.scale * w.view(1, self.out_channel, self.in_channel)) * s.unsqueeze(1)   # [B, 3, Ci]
             return op.thin_fwd(x, Wn)                                # planar [B, 3, H, W]
-        d = None
         key = (self.weight, 'mod')
-        if self.demodulate:     # composed tensor algebra when a second derivative is needed, 2 + 2 launches otherwise
+        if self.demodulate and d is None:     # composed tensor algebra when a second derivative is needed, 2 + 2 launches otherwise
             d = (_mc.demod_coeff(w, s, self.scale, self.eps) if op.second_order_enabled()
                  else _mc.demod_coeff_fused(w, s, self.scale, self.eps, key))
         if op.second_order_enabled():
@@ -200,13 +200,13 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, x, style, noise=None, s=None):
+    def forward(self, x, style, noise=None, s=None, d=None):
         if noise is None:
             r = x.shape[2] * 2 if self.conv.upsample else x.shape[2]
             noise = torch.empty(x.shape[0], 1, r, r * x.shape[3] // x.shape[2], device=x.device, dtype=x.dtype).normal_()
         tail = (self.activate.bias, noise, self.noise.weight, self.activate.negative_slope, self.activate.scale)
         if op.second_order_enabled():
-            return fused_noise_bias_act(self.conv(x, style, s=s), *tail)
+            return fused_noise_bias_act(self.conv(x, style, s=s, d=d), *tail)
         return self.conv(x, style, tail, s=s)
 
 
@@ -278,6 +278,45 @@ class Generator(nn.Module, _FisherMixin):
             bank = self.__dict__['_modbank'] = _mc.ModulationBank(mods, idx)
         return bank
 
+    def _styles_batched(self, latent):
+        """Path-length step (second-order autograd): the per-layer style algebra — s = EqualLinear(latent row),
+        d = rsqrt(s^2 @ (scale^2 sum_k W^2)^T + eps), model_probe_tune.py:246-252 — is [B, 512]-sized tensor work that
+        costs ~7 launches per layer forward and several dozen in each of the two backward passes (measured: ~700 of the
+        ~1 950 launches of a path-length step).  Layers of equal shape are stacked and evaluated by batched tensor ops
+        (plain torch: differentiable to any order), so the count no longer scales with the depth of the network."""
+        bank = self._modulation_bank()
+        convs = [self.conv1.conv, self.to_rgb1.conv]
+        for blk, to_rgb in enumerate(self.to_rgbs):
+            convs += [self.convs[2 * blk].conv, self.convs[2 * blk + 1].conv, to_rgb.conv]
+        n = len(convs)
+        s_out, d_out = [None] * n, [None] * n
+        groups = {}
+        for l, m in enumerate(bank.linears):
+            groups.setdefault(m.weight.shape[0], []).append(l)
+        for C, ls in groups.items():
+            W = torch.stack([bank.linears[l].weight for l in ls])                       # [L, C, K]
+            b = torch.stack([bank.linears[l].bias for l in ls])                         # [L, C]
+            cache = self.__dict__.setdefault('_lat_index', {})                          # device index tensors (built on the first,
+            key = (C, latent.device)                                                    # eager, call: no H2D copy under capture)
+            if key not in cache:
+                cache[key] = torch.tensor([bank.lat_idx[l] for l in ls], device=latent.device)
+            L = latent.index_select(1, cache[key]).transpose(0, 1)                      # [L, B, K]
+            S = torch.baddbmm(b.unsqueeze(1), L, W.transpose(1, 2), alpha=bank.scale)   # [L, B, C]
+            for l, sl in zip(ls, S.unbind(0)):      # one unbind: its backward is a single stack
+                s_out[l] = sl
+        groups = {}
+        for l, c in enumerate(convs):
+            if c.demodulate:
+                groups.setdefault(tuple(c.weight.shape), []).append(l)
+        for shape, ls in groups.items():
+            Wc = torch.stack([convs[l].weight[0] for l in ls])                          # [L, O, I, k, k]
+            wsq = (Wc * convs[ls[0]].scale).pow(2).sum([3, 4])                          # [L, O, I]
+            S2 = torch.stack([s_out[l] for l in ls]).pow(2)                             # [L, B, I]
+            D = torch.rsqrt(torch.bmm(S2, wsq.transpose(1, 2)) + convs[ls[0]].eps)      # [L, B, O]
+            for l, dl in zip(ls, D.unbind(0)):
+                d_out[l] = dl
+        return s_out, d_out
+
     def make_noise(self):
         device = self.input.input.device
         noises = [torch.randn(1, 1, 4, 4, device=device)]
@@ -315,17 +354,20 @@ class Generator(nn.Module, _FisherMixin):
         # every modulation linear of the network in one launch (first-order steps whose latent needs no gradient: the D / G
         # train steps and inference; the path-length step and the Fisher sweep take the per-layer, twice-differentiable path)
         sb = [None] * (2 + 3 * len(self.to_rgbs))
+        db = list(sb)
         if (latent.is_cuda and not op.second_order_enabled() and not latent.requires_grad and latent.ndim == 3
                 and latent.shape[0] <= 8 and latent.shape[1] == self.n_latent and latent.dtype == torch.float32):
             sb = self._modulation_bank()(latent)
-        out = self.conv1(self.input(latent), lat[0], noise=noise[0], s=sb[0])
+        elif latent.is_cuda and op.second_order_enabled() and latent.ndim == 3 and latent.shape[1] == self.n_latent:
+            sb, db = self._styles_batched(latent)
+        out = self.conv1(self.input(latent), lat[0], noise=noise[0], s=sb[0], d=db[0])
         feats.append(out)
         skip = self.to_rgb1(out, lat[1], s=sb[1])
         i = 1
         for blk, to_rgb in enumerate(self.to_rgbs):
-            out = self.convs[2 * blk](out, lat[i], noise=noise[2 * blk + 1], s=sb[2 + 3 * blk])
+            out = self.convs[2 * blk](out, lat[i], noise=noise[2 * blk + 1], s=sb[2 + 3 * blk], d=db[2 + 3 * blk])
             feats.append(out)
-            out = self.convs[2 * blk + 1](out, lat[i + 1], noise=noise[2 * blk + 2], s=sb[3 + 3 * blk])
+            out = self.convs[2 * blk + 1](out, lat[i + 1], noise=noise[2 * blk + 2], s=sb[3 + 3 * blk], d=db[3 + 3 * blk])
             feats.append(out)
             skip = to_rgb(out, lat[i + 2], skip, s=sb[4 + 3 * blk])
             i += 2

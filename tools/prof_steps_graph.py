@@ -14,11 +14,13 @@ ge, de = Generator(256, 512, 8).to(dev), Discriminator(256).to(dev)
 tr = RickTrainer(cfg, g, d, ge, de)
 real = synth_reals(4, 256, seed=1).to(dev)
 tr.enable_graphs(True)
-tr.prepare_graphs(real)
 which = sys.argv[1:] or ['d', 'r1', 'g', 'plr']
+tr._real = real.clone()
+tr.d_step(tr._real, None, graph=True)          # one D step so that every network has been used once
 fns = {'d': lambda: tr.d_step(tr._real, None, graph=True), 'r1': lambda: tr.r1_step(tr._real, graph=True),
        'g': lambda: tr.g_step(None, graph=True), 'plr': lambda: tr.plr_step(None, graph=True)}
 for k in which:
+    for _ in range(3): fns[k]()                  # two eager runs + the capture
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(8): fns[k]()
     torch.cuda.synchronize()
