@@ -33,13 +33,17 @@ MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.
 
 
 def cpu_baseline(size=256, batch=2, timed=2):
-    """Non-reg iterations (D step fwd+bwd, G step fwd+bwd) of the CPU oracle at BASELINE configs[0]'s batch 2 on ALL
-    host cores: one warm-up iteration (oneDNN primitive creation, allocator), then `timed` timed ones."""
+    """Non-reg iterations (D step fwd+bwd, G step fwd+bwd) of the CPU oracle at BASELINE configs[0]'s batch 2: one warm-up
+    iteration (oneDNN primitive creation, allocator), then `timed` timed ones.  Thread count: the box has 256
+    hardware threads, but oneDNN's convolutions at this size collapse beyond one socket's worth — measured on the GPU box:
+    12 s per iteration at 32 threads, 335 s at 256 (gpurun_out/r2_bench_full.log) — so the baseline runs at the count
+    that is FASTEST for the CPU path (32, or every core of a smaller host) and reports both numbers."""
     from oracle.model_ref import discriminator_ref, generator_ref
     from oracle.train_ref import d_logistic_loss_ref, g_nonsaturating_loss_ref
     from rick_amd.synth import synth_latents, synth_reals, synth_state_dict
     from tests.shapes import discriminator_shapes, generator_shapes
-    cores = os.cpu_count() or 1
+    host = os.cpu_count() or 1
+    cores = min(host, 32)
     torch.set_num_threads(cores)
     sg = synth_state_dict(generator_shapes(size))
     sd = synth_state_dict(discriminator_shapes(size))
@@ -66,7 +70,8 @@ def cpu_baseline(size=256, batch=2, timed=2):
     dt = sorted(times)[len(times) // 2] if len(times) % 2 else sum(times) / len(times)
     return {'value': batch / dt, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': f'1 warm-up + {timed} timed non-reg iterations (D step + G step, fwd+bwd, no optimiser) at batch '
-                      f'{batch}, {size}px, fp32 oneDNN on {cores} host threads: ' + ', '.join(f'{t:.1f}' for t in times) + ' s'}
+                      f'{batch}, {size}px, fp32 oneDNN on {cores} of {host} host threads (fastest setting for the CPU path; 256 '
+                      f'threads measured 28x slower): ' + ', '.join(f'{t:.1f}' for t in times) + ' s'}
 
 
 def load_traffic():
