@@ -124,8 +124,6 @@ class ModulatedConv2d(nn.Module):
     def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
                  downsample=False, blur_kernel=[1, 3, 3, 1]):
         super().__init__()
-        if downsample:
-            raise NotImplementedError('downsample=True is never used by the reference networks')
         self.eps = 1e-8
         self.kernel_size, self.in_channel, self.out_channel = kernel_size, in_channel, out_channel
         self.upsample, self.downsample = upsample, downsample
@@ -133,6 +131,10 @@ class ModulatedConv2d(nn.Module):
             factor = 2
             p = (len(blur_kernel) - factor) - (kernel_size - 1)
             self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
+        if downsample:      # model_probe_tune.py:214-220 (no network of the reference uses it)
+            factor = 2
+            p = (len(blur_kernel) - factor) + (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2, p // 2))
         self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
         self.padding = kernel_size // 2
         self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
@@ -151,6 +153,12 @@ class ModulatedConv2d(nn.Module):
             Wn = (self.scale * w.view(1, self.out_channel, self.in_channel)) * s.unsqueeze(1)   # [B, 3, Ci]
             return op.thin_fwd(x, Wn)                                # planar [B, 3, H, W]
         key = (self.weight, 'mod')
+        if self.downsample:
+            # blur -> stride-2 modulated conv (model_probe_tune.py:270-276), composed from the twice-differentiable
+            # primitives: y = d * conv_s2(W, blur(s * x)); the blur is per channel, so it commutes with the scale s
+            dd = _mc.demod_coeff(w, s, self.scale, self.eps) if self.demodulate else None
+            y = op.conv2d(self.blur(op.chan_scale(x, s)), w, 2, 0, wscale=self.scale, key=key)
+            return op.chan_scale(y, dd) if dd is not None else y
         if self.demodulate and d is None:     # composed tensor algebra when a second derivative is needed, 2 + 2 launches otherwise
             d = (_mc.demod_coeff(w, s, self.scale, self.eps) if op.second_order_enabled()
                  else _mc.demod_coeff_fused(w, s, self.scale, self.eps, key))
@@ -379,6 +387,17 @@ class Generator(nn.Module, _FisherMixin):
         return image, None
 
 
+class ScaledLeakyReLU(nn.Module):
+    """model_probe_tune.py:176-185: sqrt(2) * leaky_relu(x, 0.2) — the fused bias + activation kernel without a bias."""
+
+    def __init__(self, negative_slope=0.2):
+        super().__init__()
+        self.negative_slope = negative_slope
+
+    def forward(self, x):
+        return fused_leaky_relu(x, None, self.negative_slope, math.sqrt(2))
+
+
 class ConvLayer(nn.Sequential):
     """[Blur] + EqualConv2d + [FusedLeakyReLU] with the reference's child indices
     (model_probe_tune.py:595-641) — the Fisher code derives bias keys from them."""
@@ -395,11 +414,9 @@ class ConvLayer(nn.Sequential):
         layers.append(EqualConv2d(in_channel, out_channel, kernel_size, padding=self.padding, stride=stride,
                                   bias=bias and not activate))
         if activate:
-            if not bias:
-                raise NotImplementedError('ScaledLeakyReLU variant is not used by the reference networks')
-            layers.append(FusedLeakyReLU(out_channel))
+            layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
         super().__init__(*layers)
-        self._fusable = activate and out_channel % 4 == 0 and not (in_channel <= 4 and kernel_size == 1)
+        self._fusable = activate and bias and out_channel % 4 == 0 and not (in_channel <= 4 and kernel_size == 1)
 
     def forward(self, x):
         # conv -> bias + LeakyReLU as ONE launch (tail in the MFMA kernel's epilogue) when only first derivatives are

@@ -1,6 +1,7 @@
 """Drop-in replacements for the reference's ``op`` package (op/__init__.py:1-2) plus the
 additional HIP ops the MI355X engine is built from."""
 import contextlib
+import threading
 
 from .fused_act import FusedLeakyReLU, FusedLeakyReLU_kml, fused_leaky_relu, fused_noise_bias_act
 from .upfirdn2d import upfirdn2d, upfirdn2d_noise_bias_act
@@ -9,11 +10,13 @@ from .conv import (bump_weights_epoch, conv2d, conv2d_bias_act, conv_transpose2d
 from .misc import add_scale, chan_scale, hw_dot, minibatch_stddev, thin_bwdx, thin_fwd
 from . import modconv
 
-_second_order = False
+# per-thread mode switches: the reference ops are called from nn.DataParallel worker threads
+# (train_dynamic_update_prune.py:941-944), so nothing a caller toggles may leak into another thread
+_tls = threading.local()
 
 
 def second_order_enabled():
-    return _second_order
+    return getattr(_tls, 'second_order', False)
 
 
 @contextlib.contextmanager
@@ -22,13 +25,12 @@ def second_order(enabled=True):
     (R1: train_dynamic_update_prune.py:89-96; path length: :104-118).  Outside it the modulated
     convolutions and minibatch-stddev use fused single-kernel paths whose backward is
     first-order only (it raises if differentiated twice)."""
-    global _second_order
-    prev = _second_order
-    _second_order = enabled
+    prev = second_order_enabled()
+    _tls.second_order = enabled
     try:
         yield
     finally:
-        _second_order = prev
+        _tls.second_order = prev
 
 
 __all__ = ['FusedLeakyReLU', 'FusedLeakyReLU_kml', 'fused_leaky_relu', 'fused_noise_bias_act', 'upfirdn2d', 'upfirdn2d_noise_bias_act',

@@ -18,6 +18,7 @@ two dims are jointly contiguous.  `precision()` selects bf16x3 (default, fp32-gr
 plain bf16 MFMA.
 """
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -30,7 +31,9 @@ _SPLIT = 2          # 2: bf16 hi/lo split, 3 MFMAs per product (fp32-grade); 1: 
 _weights_epoch = 0  # bumped by optimisers that update parameters through raw pointers
 
 
-_prof = None         # list of (kind, algorithmic_flops, start_event, end_event) while profiling
+_tls = threading.local()   # per-thread switch of the gradient sink (DataParallel-style callers run the ops from threads)
+_prof = None               # bench.py's launch profiler: process-wide on purpose — backward launches are issued by the autograd
+                           # engine's device thread, not by the thread that entered the context
 
 
 class launch_profiler:
@@ -400,29 +403,31 @@ def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alph
     return y
 
 
-_GRAD_SINK = False
-
-
 class grad_sink:
     """Inside this context the first-order conv / modulated-conv backward ADDS a weight gradient straight into the
     parameter's existing ``.grad`` (the trainer's flat gradient buffer) from the wgrad kernel's second stage and reports
     no gradient to autograd — instead of materialising it, routing it through the select / view nodes of the parameter and
     an AccumulateGrad add (three extra passes over a 9.4 MB tensor per 512x512 layer).  Only valid around a plain
     ``loss.backward()`` on leaf parameters whose ``.grad`` is allocated (RickTrainer's D / G steps); ``autograd.grad`` users
-    (Fisher sweep, tests) never enable it."""
+    (Fisher sweep, tests) never enable it.  The switch is per thread and is read in the FORWARD of the fused ops (the
+    backward runs on the autograd engine's device thread, where a thread-local would not be visible): wrap forward and
+    backward."""
 
     def __enter__(self):
-        global _GRAD_SINK
-        self.prev, _GRAD_SINK = _GRAD_SINK, True
+        self.prev, _tls.grad_sink = getattr(_tls, 'grad_sink', False), True
 
     def __exit__(self, *a):
-        global _GRAD_SINK
-        _GRAD_SINK = self.prev
+        _tls.grad_sink = self.prev
 
 
-def _sink_target(key, shape):
-    """The [O, I, kh, kw] view of the parameter's .grad a weight gradient may be added into, or None."""
-    if not _GRAD_SINK or key is None:
+def grad_sink_enabled():
+    return getattr(_tls, 'grad_sink', False)
+
+
+def _sink_target(key, shape, enabled):
+    """The [O, I, kh, kw] view of the parameter's .grad a weight gradient may be added into, or None.  `enabled` is the
+    switch as the op's forward saw it."""
+    if not enabled or key is None:
         return None
     p = key[0]
     if not (p.is_leaf and p.requires_grad and p.grad is not None and p.grad.is_contiguous() and p.numel() == int(np.prod(shape))):
@@ -548,6 +553,7 @@ class _ConvBiasAct(Function):
                          epi=_epilogue(bias, None, None, slope, gain))
         ctx.save_for_backward(x, w, y)
         ctx.cfg = (s, p, wscale, key, slope, gain)
+        ctx.sink = grad_sink_enabled()
         return y
 
     @staticmethod
@@ -563,7 +569,7 @@ class _ConvBiasAct(Function):
             wpT = _pack(w.transpose(0, 1), wscale, key and (key[0], key[1] + '/T/convT'))
             gx = _convT_launch(gz, wpT, I, kh, kw, s, p, (x.shape[2], x.shape[3]))
         if ctx.needs_input_grad[1]:
-            gw = _wgrad_launch(gz, x, kh, kw, s, p, wscale, out=_sink_target(key, w.shape))
+            gw = _wgrad_launch(gz, x, kh, kw, s, p, wscale, out=_sink_target(key, w.shape, ctx.sink))
         return gx, gw, (gb if ctx.needs_input_grad[2] else None), None, None, None, None, None, None
 
 

@@ -20,7 +20,8 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .._lib import check, lib, ptr, require_cuda_f32, stream_ptr
-from .conv import _conv_launch, _convT_launch, _epilogue, _pack, _sink_target, _wgrad_launch, conv2d, conv_transpose2d
+from .conv import (_conv_launch, _convT_launch, _epilogue, _pack, _sink_target, _wgrad_launch, conv2d, conv_transpose2d,
+                   grad_sink_enabled)
 from .misc import _chan_scale_raw, _hw_dot_raw, chan_scale
 
 
@@ -57,7 +58,7 @@ class _DemodFused(Function):
         check(lib.rick_demod_f32(ptr(s), ptr(wsq), ptr(d), B, I, O, float(eps), stream_ptr()), 'rick_demod_f32')
         ctx.save_for_backward(w, s, wsq, d)
         ctx.wscale = float(wscale)
-        ctx.key = key
+        ctx.key, ctx.sink = key, grad_sink_enabled()
         return d
 
     @staticmethod
@@ -73,7 +74,7 @@ class _DemodFused(Function):
             check(lib.rick_demod_bwd_s_f32(ptr(s), ptr(wsq), ptr(d), ptr(gd), ptr(gs), B, I, O, stream_ptr()),
                   'rick_demod_bwd_s_f32')
         if ctx.needs_input_grad[0]:
-            sink = _sink_target(ctx.key, w.shape)      # op.grad_sink(): add straight into the parameter's .grad
+            sink = _sink_target(ctx.key, w.shape, ctx.sink)      # op.grad_sink(): add straight into the parameter's .grad
             gw = torch.empty_like(w) if sink is None else None
             check(lib.rick_demod_bwd_w_f32(ptr(w), ptr(s), ptr(d), ptr(gd), ptr(sink if sink is not None else gw), B, I, O,
                                            kh * kw, ctx.wscale, int(sink is not None), stream_ptr()), 'rick_demod_bwd_w_f32')
@@ -114,6 +115,7 @@ class _ModConvFused(Function):
             y = _conv_launch(x, wp, O, kh, kw, 1, kh // 2, iscale=s, oscale=d)
         ctx.save_for_backward(x, w, s, d, y, *((bias, noise, nw) if tail else ()))
         ctx.cfg = (wscale, upsample, key, tail, slope, gain)
+        ctx.sink = grad_sink_enabled()
         return y
 
     @staticmethod
@@ -143,7 +145,7 @@ class _ModConvFused(Function):
             if ctx.needs_input_grad[0]:
                 gx = _chan_scale_raw(gxu, s)
         if ctx.needs_input_grad[1]:
-            sink = _sink_target(key, w.shape)     # op.grad_sink(): add straight into the parameter's .grad
+            sink = _sink_target(key, w.shape, ctx.sink)     # op.grad_sink(): add straight into the parameter's .grad
             if upsample:   # convT: gw[o,i,k] = sum x[pos,i] g[pos*2+k, o]  (a = x, b = g), transposed back
                 gw = _wgrad_launch(x, g, kh, kw, 2, 0, wscale, ascale=s, bscale=d, out=sink, transposed=True)
                 gw = gw.transpose(0, 1) if gw is not None else None

@@ -550,11 +550,11 @@ class RickTrainer:
                     fake_img, _ = self.g(noise, noise=g_noise)
             # one pass over cat(fake, real): identical to the reference's two calls (per-call minibatch-stddev
             # statistics are kept), half the launches and twice the GEMM rows per launch
-            pred, _ = self.d(torch.cat([fake_img, real_img], 0), calls=2)
-            fake_pred, real_pred = pred.chunk(2, 0)
-            d_loss = d_logistic_loss(real_pred, fake_pred)
-            self._zero_grad(self.d_flat)
             with op.grad_sink():                 # conv weight gradients are added straight into the flat buffer
+                pred, _ = self.d(torch.cat([fake_img, real_img], 0), calls=2)
+                fake_pred, real_pred = pred.chunk(2, 0)
+                d_loss = d_logistic_loss(real_pred, fake_pred)
+                self._zero_grad(self.d_flat)
                 d_loss.backward()
             self.losses.update(d=d_loss.detach(), real_score=real_pred.detach().mean(), fake_score=fake_pred.detach().mean())
         self._run(key, fb, self.d_flat, self.d_optim, pre=(lambda: self._draw_inject(key)) if graph else None)
@@ -581,16 +581,15 @@ class RickTrainer:
         batch = self.cfg.batch
 
         def fb():
-            if graph:
-                fake_img, _ = self.g([self._graph_latents(key, batch)], input_is_latent=True, noise=g_noise)
-            else:
-                fake_img, _ = self.g(noise, noise=g_noise)
-            with self._d_frozen():
+            with op.grad_sink(), self._d_frozen():
+                if graph:
+                    fake_img, _ = self.g([self._graph_latents(key, batch)], input_is_latent=True, noise=g_noise)
+                else:
+                    fake_img, _ = self.g(noise, noise=g_noise)
                 fake_pred, _ = self.d(fake_img)
                 g_loss = g_nonsaturating_loss(fake_pred)
                 self._zero_grad(self.g_flat)
-                with op.grad_sink():
-                    g_loss.backward()
+                g_loss.backward()
             self.losses['g'] = g_loss.detach()
         self._run(key, fb, self.g_flat, self.g_optim, pre=(lambda: self._draw_inject(key)) if graph else None)
         return self.losses['g']

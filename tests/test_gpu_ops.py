@@ -522,3 +522,32 @@ def test_modulation_bank_equals_per_layer_linears(B):
     # unused outputs (None gradients) are treated as zeros
     got2 = torch.autograd.grad(bank(lat)[3].sum(), [params[6], params[7]], allow_unused=True)
     assert rel_err(got2[1], torch.full_like(got2[1], float(B)).double()) < 1e-6
+
+
+def test_unused_reference_variants_downsample_modconv_and_scaled_lrelu():
+    """ModulatedConv2d(downsample=True) (model_probe_tune.py:214-220, 270-276) and the ScaledLeakyReLU branch of ConvLayer
+    (:176-185, 635-639) — never instantiated by the reference networks, present for API completeness — against the
+    reference's own formulation restated in fp64 (per-sample weights, grouped conv)."""
+    from oracle.ops_ref import make_blur_kernel, upfirdn2d_ref
+    from rick_amd.models import ConvLayer, ModulatedConv2d, ScaledLeakyReLU
+    B, CI, CO, R, SD = 2, 16, 24, 9, 32
+    m = ModulatedConv2d(CI, CO, 3, SD, downsample=True)
+    m.load_state_dict(synth_state_dict({k: v.shape for k, v in m.state_dict().items()}), strict=False)
+    x = synth_tensor('down/x', (B, CI, R, R))
+    st = synth_tensor('down/s', (B, SD))
+    y = m.to(DEV)(x.to(DEV), st.to(DEV))
+    sd = {k: v.double().cpu() for k, v in m.state_dict().items()}
+    s = st.double() @ (sd['modulation.weight'] * (1 / math.sqrt(SD))).t() + sd['modulation.bias']
+    w = m.scale * sd['weight'] * s.view(B, 1, CI, 1, 1)
+    w = w * torch.rsqrt(w.pow(2).sum([2, 3, 4]) + 1e-8).view(B, CO, 1, 1, 1)
+    p = (4 - 2) + (3 - 1)
+    xb = upfirdn2d_ref(x.double(), make_blur_kernel([1, 3, 3, 1]).double(), pad=((p + 1) // 2, p // 2))
+    ref = F.conv2d(xb.reshape(1, B * CI, *xb.shape[2:]), w.reshape(B * CO, CI, 3, 3), stride=2, groups=B)
+    ref = ref.view(B, CO, *ref.shape[2:])
+    assert y.shape == ref.shape and rel_err(y, ref) < 3e-5
+    layer = ConvLayer(8, 12, 3, bias=False, activate=True).to(DEV)
+    assert isinstance(layer[-1], ScaledLeakyReLU) and layer[0].bias is None
+    xi = synth_tensor('slr/x', (2, 8, 6, 6))
+    out = layer(xi.to(DEV))
+    refo = F.leaky_relu(F.conv2d(xi.double(), layer[0].weight.detach().double().cpu() * layer[0].scale, padding=1), 0.2) * math.sqrt(2)
+    assert rel_err(out, refo) < 3e-5
