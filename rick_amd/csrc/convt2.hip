@@ -27,6 +27,9 @@
 #define CT_PITEMS 3                       // patch float4 per thread: up to 192 patch pixels
 #define CT_MAX_NPP (CT_PITEMS * (CT_THREADS / 8))
 
+// zeros that out-of-range patch items load (no zero-select afterwards; see conv.hip)
+__device__ __attribute__((aligned(64))) float g_ct2_zero_page[16];
+
 struct Ct2Plan {
     int N, IH, IW, Ci, OH, OW, Co;
     int TW, TH, NB;                 // position tile: TW x TH positions of NB images (TW*TH*NB <= 128)
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
 #pragma unroll
         for (int k = 0; k < CT_PITEMS; k++) {
             const bool ok = (cur_ok >> k) & 1u;
-            pq[k] = *reinterpret_cast<const float4 *>(ok ? xt + p_rel[k] + chunk * CV_CK : x);
+            pq[k] = *reinterpret_cast<const float4 *>(ok ? xt + p_rel[k] + chunk * CV_CK : g_ct2_zero_page);
         }
     };
     auto commit_patch = [&](int chunk, unsigned char *ph) {
@@ -117,9 +120,8 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
         const float *sc = sct + (chunk - c_begin) * CV_CK + c4 * 4;
 #pragma unroll
         for (int k = 0; k < CT_PITEMS; k++) {
-            const bool ok = (cur_ok >> k) & 1u;
-            float4 v = mul4(pq[k], *reinterpret_cast<const float4 *>(sc + ((p_nbi >> (8 * k)) & 255u) * cspan));
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = pq[k];       // (an out-of-range item has read the zero page)
+            if (iscale) v = mul4(v, *reinterpret_cast<const float4 *>(sc + ((p_nbi >> (8 * k)) & 255u) * cspan));
             uint2 hi, lo;
             split4<SPLIT>(v, hi, lo);
             if (pix0 + (CT_THREADS / 8) * k < P.NPP) {        // (a branch around an LDS store is harmless; loads stay unconditional)
