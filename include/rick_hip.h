@@ -66,12 +66,13 @@ int rick_bias_act_f32(const float *x, const float *bias, const float *ref, float
  *   gnw     = sum_{r,c} gx[r,c] * noise[(r / rows_per_img % noise_nb)*noise_hw + r % noise_hw]
  * The per-channel / scalar sums use wavefront shuffles + a deterministic two-stage
  * reduction through `partials` (float[(C + 1) * rick_bias_act_bwd_blocks(rows, C)]).
- * gb / gnw / noise may be NULL. */
+ * gb / gnw / noise may be NULL.  accumulate != 0: the second stage ADDS the sums into gb / gnw (the caller passes
+ * the parameters' gradient buffers: no temporary, no separate accumulation pass); one second-stage launch serves both. */
 int rick_bias_act_bwd_blocks(int64_t rows, int C);
 int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx, float *gb, float *gnw,
                           const float *noise, int64_t rows, int C, int64_t rows_per_img,
                           int64_t noise_nb, int64_t noise_hw, float alpha, float scale,
-                          float *partials, void *stream);
+                          float *partials, int accumulate, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Convolution family (replaces the F.conv2d / F.conv_transpose2d calls of
@@ -207,19 +208,20 @@ int rick_thin_wgrad_f32(const float *t, const float *x, float *G, int N, int64_t
  * Elementwise / reduction helpers on NHWC [N, P, C] tensors. */
 /* y[n,p,c] = x[n,p,c] * s[n,c] */
 int rick_chan_scale_f32(const float *x, const float *s, float *y, int N, int64_t P, int C, void *stream);
-/* d[n,c] = sum_p a[n,p,c] * b[n,p,c]; partials: float[N*C*rick_hw_dot_blocks(P)] */
+/* d[n,c] = sum_p a[n,p,c] * b[n,p,c] (/ divisor[n,c] when divisor != NULL); partials: float[N*C*rick_hw_dot_blocks(P)] */
 int rick_hw_dot_blocks(int64_t P);
 int rick_hw_dot_f32(const float *a, const float *b, float *d, int N, int64_t P, int C,
-                    float *partials, void *stream);
+                    float *partials, const float *divisor, void *stream);
 /* rick_hw_dot_f32 that also writes scaled[n,p,c] = a[n,p,c] * scale[n,c] in the same pass (C % 4 == 0). */
 int rick_hw_dot_scale_f32(const float *a, const float *b, float *d, const float *scale, float *scaled, int N,
                           int64_t P, int C, float *partials, void *stream);
 /* d[n,c] = sum_p g[n,p,c] * (lrelu^-1(y[n,p,c]) - noise_w[0]*noise[n % noise_nb][p] - bias[c]) where y is the output
  * of a fused tail gain*lrelu_slope(v + bias + noise_w*noise): the sum over pixels of g times the PRE-tail value v,
- * without keeping v (demodulation gradient of the fused StyledConv).  C % 4 == 0; partials as rick_hw_dot_f32. */
+ * without keeping v (demodulation gradient of the fused StyledConv).  C % 4 == 0; partials and divisor as
+ * rick_hw_dot_f32. */
 int rick_hw_dot_act_f32(const float *g, const float *y, float *d, int N, int64_t P, int C, const float *bias,
                         const float *noise, const float *noise_w, int noise_nb, float slope, float gain,
-                        float *partials, void *stream);
+                        float *partials, const float *divisor, void *stream);
 /* y = (a + b) * alpha  (ResBlock merge, model_probe_tune.py:658); b may be NULL */
 int rick_add_scale_f32(const float *a, const float *b, float *y, int64_t n, float alpha, void *stream);
 
@@ -256,7 +258,9 @@ int rick_demod_bwd_w_f32(const float *w, const float *s, const float *d, const f
  * them in one more.  lat is [B, n_latent, K]; layer l owns blocks [blk_begin, blk_begin + rick_modbank_blocks(C_l));
  *   fwd: out[io_off + b*C + c] = scale * sum_k lat[b, lat_idx, k] * w[c*K + k] + b[c]
  *   bwd: grad[gw_off + c*K + k] = scale * sum_b gs[io_off + b*C + c] * lat[b, lat_idx, k];  grad[gb_off + c] = sum_b gs[..]
- * (gb_off < 0: no bias gradient).  `descs_device` lives in device memory.  K % 256 == 0, B <= 8. */
+ * (gw_off / gb_off < 0: no weight / bias gradient; a layer with neither is skipped and its gs is not read;
+ * accumulate != 0: the gradients are ADDED to what grad holds — grad + offsets then address the parameters' own
+ * gradient buffers).  `descs_device` lives in device memory.  K % 256 == 0, B <= 8, grad 16-byte aligned. */
 typedef struct {
     const float *w;         /* [C, K] */
     const float *b;         /* [C] or NULL */
@@ -268,7 +272,13 @@ int rick_modbank_blocks(int C);
 int rick_modbank_fwd_f32(const float *lat, int B, int n_latent, int K, const rick_modbank_desc *descs_device, int n,
                          int total_blocks, float scale, float *out, void *stream);
 int rick_modbank_bwd_f32(const float *lat, const float *gs, int B, int n_latent, int K, const rick_modbank_desc *descs_device,
-                         int n, int total_blocks, float scale, float *grad, void *stream);
+                         int n, int total_blocks, float scale, float *grad, int accumulate, void *stream);
+/* EqualLinear forward on a short batch (the mapping network, model_probe_tune.py:139-173, 418-428; no autograd):
+ *   x' = pixelnorm ? x * rsqrt(mean_k x^2 + 1e-8) : x                                  (PixelNorm, :92-98)
+ *   out[b,o] = act(scale * sum_k x'[b,k] W[o,k] + bias[o] * bias_mul);  act != 0: gain * leaky_relu(., slope)
+ * x [B, K], W [O, K], bias [O] or NULL, out [B, O].  B <= 16, K % 4 == 0, x / W 16-byte aligned. */
+int rick_equal_linear_f32(const float *x, const float *W, const float *bias, float *out, int B, int K, int O,
+                          float scale, float bias_mul, int act, float slope, float gain, int pixelnorm, void *stream);
 
 /* Masked Adam over a flat parameter buffer (mask bits: 1 = freeze (grad := 0),
  * 2 = prune (param := 0, grad := 0); mask may be NULL), torch.optim.Adam semantics

@@ -45,7 +45,7 @@ SIGNATURES = {
                                   c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_fp]),
     'rick_bias_act_bwd_blocks': (c_int, [c_i64, c_int]),
     'rick_bias_act_bwd_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_i64, c_i64, c_i64,
-                                      c_f, c_f, c_fp, c_fp]),
+                                      c_f, c_f, c_fp, c_int, c_fp]),
     'rick_conv_packed_bytes': (c_i64, [c_int, c_int, c_int]),
     'rick_conv_pack_weight': (c_int, [c_fp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_f, c_int, c_fp, c_fp]),
     'rick_conv_pack_blocks': (c_int, [c_int, c_int]),
@@ -68,9 +68,10 @@ SIGNATURES = {
     'rick_thin_wgrad_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_int, c_fp, c_fp]),
     'rick_chan_scale_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_fp]),
     'rick_hw_dot_blocks': (c_int, [c_i64]),
-    'rick_hw_dot_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_fp, c_fp]),
+    'rick_hw_dot_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_fp, c_fp, c_fp]),
     'rick_hw_dot_scale_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_fp, c_fp]),
-    'rick_hw_dot_act_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_fp, c_fp]),
+    'rick_hw_dot_act_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_fp, c_fp,
+                                    c_fp]),
     'rick_add_scale_f32': (c_int, [c_fp, c_fp, c_fp, c_i64, c_f, c_fp]),
     'rick_mbstd_fwd_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     'rick_mbstd_bwd_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
@@ -83,7 +84,8 @@ SIGNATURES = {
     'rick_demod_bwd_w_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_f, c_int, c_fp]),
     'rick_modbank_blocks': (c_int, [c_int]),
     'rick_modbank_fwd_f32': (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int, c_int, c_f, c_fp, c_fp]),
-    'rick_modbank_bwd_f32': (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_int, c_int, c_f, c_fp, c_fp]),
+    'rick_modbank_bwd_f32': (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_int, c_int, c_f, c_fp, c_int, c_fp]),
+    'rick_equal_linear_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_f, c_f, c_int, c_f, c_f, c_int, c_fp]),
     'rick_adam_prepare_f32': (c_int, [c_fp, c_int, c_int, c_f, c_f, c_fp, c_fp]),
     'rick_masked_adam_dev_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f, c_f, c_f, c_f, c_fp, c_fp]),
     'rick_ema_f32': (c_int, [c_fp, c_fp, c_i64, c_f, c_fp]),

@@ -231,13 +231,23 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restri
     }
 }
 
+// Destination options of the column-sum stage: columns >= split go to out2 (the noise-strength gradient behind the C bias
+// columns), the sum may be divided elementwise (demodulation gradient: sum / d) and added to what the destination
+// holds (gradient sink: the destination is the parameter's .grad).
+struct ColsumOut {
+    float *out2;
+    int split;
+    const float *divisor;
+    int accumulate;
+};
+
 // out[c] = sum_b partials[b*stride + col0 + c].  Block = CPB columns x (256 / CPB) row groups; a thread walks
 // its group's partial rows with 4 loads in flight, the group sums are combined by a fixed LDS tree
 // (deterministic).  CPB = 8 keeps many rows in parallel (the stage is latency-bound: few KB..MB of partials),
 // CPB = 1 spends the whole block on a single column (the noise-strength gradient).
 template <int CPB>
 __global__ __launch_bounds__(256) void partial_colsum_kernel(const float *__restrict__ partials, float *__restrict__ out,
-                                                             int nb, int stride, int ncols, int col0) {
+                                                             int nb, int stride, int ncols, int col0, ColsumOut o) {
     constexpr int G = 256 / CPB;
     __shared__ float red[256];
     const int cl = threadIdx.x % CPB, grp = threadIdx.x / CPB;
@@ -263,21 +273,28 @@ __global__ __launch_bounds__(256) void partial_colsum_kernel(const float *__rest
         if (grp < off) red[threadIdx.x] += red[threadIdx.x + off * CPB];
         __syncthreads();
     }
-    if (grp == 0 && c < ncols) out[c] = red[cl];
+    if (grp == 0 && c < ncols) {
+        float v = red[cl];
+        if (o.divisor) v /= o.divisor[c];
+        float *dst = c < o.split ? out + c : o.out2 + (c - o.split);
+        *dst = o.accumulate ? *dst + v : v;
+    }
 }
 
-static void launch_colsum(const float *partials, float *out, int nb, int stride, int ncols, int col0, hipStream_t st) {
+static void launch_colsum(const float *partials, float *out, int nb, int stride, int ncols, int col0, hipStream_t st,
+                          const float *divisor = nullptr, int accumulate = 0, float *out2 = nullptr, int split = 0) {
+    const ColsumOut o = {out2, out2 ? split : ncols, divisor, accumulate};
     if (ncols == 1)
-        hipLaunchKernelGGL(partial_colsum_kernel<1>, dim3(1), dim3(256), 0, st, partials, out, nb, stride, ncols, col0);
+        hipLaunchKernelGGL(partial_colsum_kernel<1>, dim3(1), dim3(256), 0, st, partials, out, nb, stride, ncols, col0, o);
     else
         hipLaunchKernelGGL(partial_colsum_kernel<8>, dim3(cdiv(ncols, 8)), dim3(256), 0, st, partials, out, nb, stride, ncols,
-                           col0);
+                           col0, o);
 }
 
 extern "C" int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx, float *gb, float *gnw,
                                      const float *noise, int64_t rows, int C, int64_t rows_per_img,
                                      int64_t noise_nb, int64_t noise_hw, float alpha, float scale,
-                                     float *partials, void *stream) {
+                                     float *partials, int accumulate, void *stream) {
     if (!g || !ref || !gx || rows <= 0 || C <= 0 || ((gb || gnw) && !partials)) return RICK_EINVAL;
     if (gnw && !noise) return RICK_EINVAL;
     if (noise && (rows_per_img <= 0 || noise_nb <= 0 || noise_hw != rows_per_img)) return RICK_EINVAL;
@@ -292,8 +309,10 @@ extern "C" int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx
     else
         hipLaunchKernelGGL(bias_act_bwd_kernel<false>, dim3(nb), dim3(256), lds, st, g, ref, gx, nz, partials, rows, C,
                            rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0);
-    if (gb) launch_colsum(partials, gb, nb, C + 1, C, 0, st);
-    if (gnw) launch_colsum(partials, gnw, nb, C + 1, 1, C, st);
+    // one second-stage launch for both parameter gradients; accumulate: gb / gnw are the parameters' .grad (gradient sink)
+    if (gb && gnw) launch_colsum(partials, gb, nb, C + 1, C + 1, 0, st, nullptr, accumulate, gnw, C);
+    else if (gb) launch_colsum(partials, gb, nb, C + 1, C, 0, st, nullptr, accumulate);
+    else if (gnw) launch_colsum(partials, gnw, nb, C + 1, 1, C, st, nullptr, accumulate);
     RICK_LAUNCH_STATUS();
 }
 
@@ -447,7 +466,7 @@ __global__ __launch_bounds__(256) void hw_dot_kernel(const float *__restrict__ a
 }
 
 extern "C" int rick_hw_dot_f32(const float *a, const float *b, float *d, int N, int64_t P, int C,
-                               float *partials, void *stream) {
+                               float *partials, const float *divisor, void *stream) {
     if (!a || !b || !d || !partials || N <= 0 || P <= 0 || C <= 0 || N > 65535) return RICK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nb = rick_hw_dot_blocks(P);
@@ -456,7 +475,7 @@ extern "C" int rick_hw_dot_f32(const float *a, const float *b, float *d, int N, 
         hipLaunchKernelGGL((hw_dot_kernel<true, false>), dim3(nb, N), dim3(256), 1024 * sizeof(float), st, a, b, partials, P, C, none);
     else
         hipLaunchKernelGGL((hw_dot_kernel<false, false>), dim3(nb, N), dim3(256), 1024 * sizeof(float), st, a, b, partials, P, C, none);
-    launch_colsum(partials, d, nb, N * C, N * C, 0, st);
+    launch_colsum(partials, d, nb, N * C, N * C, 0, st, divisor);
     RICK_LAUNCH_STATUS();
 }
 
@@ -476,7 +495,7 @@ extern "C" int rick_hw_dot_scale_f32(const float *a, const float *b, float *d, c
 
 extern "C" int rick_hw_dot_act_f32(const float *g, const float *y, float *d, int N, int64_t P, int C, const float *bias,
                                    const float *noise, const float *noise_w, int noise_nb, float slope, float gain,
-                                   float *partials, void *stream) {
+                                   float *partials, const float *divisor, void *stream) {
     if (!g || !y || !d || !partials || N <= 0 || P <= 0 || C <= 0 || N > 65535 || (C & 3) || gain == 0.f || slope == 0.f)
         return RICK_EINVAL;
     if ((((uintptr_t)g | (uintptr_t)y | (uintptr_t)(bias ? bias : g)) % 16) || (noise && (!noise_w || (noise_nb != 1 && noise_nb != N))))
@@ -485,7 +504,7 @@ extern "C" int rick_hw_dot_act_f32(const float *g, const float *y, float *d, int
     const int nb = rick_hw_dot_blocks(P);
     const HwDotAct t = {bias, noise, noise_w, noise_nb, 1.f / gain, 1.f / (gain * slope), nullptr, nullptr};
     hipLaunchKernelGGL((hw_dot_kernel<true, true>), dim3(nb, N), dim3(256), 1024 * sizeof(float), st, g, y, partials, P, C, t);
-    launch_colsum(partials, d, nb, N * C, N * C, 0, st);
+    launch_colsum(partials, d, nb, N * C, N * C, 0, st, divisor);
     RICK_LAUNCH_STATUS();
 }
 

@@ -239,12 +239,13 @@ __global__ __launch_bounds__(256) void modbank_fwd_kernel(const float *__restric
 
 __global__ __launch_bounds__(256) void modbank_bwd_kernel(const float *__restrict__ lat, const float *__restrict__ gs, int B,
                                                           int n_latent, int K, const rick_modbank_desc *__restrict__ descs,
-                                                          int n, float scale, float *__restrict__ grad) {
+                                                          int n, float scale, float *__restrict__ grad, int accumulate) {
     __shared__ float sg[MB_MAXB][MB_ROWS];
     int d = 0;
     for (int i = 1; i < n; i++)
         if ((int)blockIdx.x >= descs[i].blk_begin) d = i;
     const rick_modbank_desc ds = descs[d];
+    if (ds.gw_off < 0 && ds.gb_off < 0) return;          // frozen layer: gs of this layer is not even read
     const int c0 = ((int)blockIdx.x - ds.blk_begin) * MB_ROWS;
     if (threadIdx.x < MB_ROWS * MB_MAXB) {
         const int b = threadIdx.x / MB_ROWS, r = threadIdx.x % MB_ROWS;
@@ -254,8 +255,10 @@ __global__ __launch_bounds__(256) void modbank_bwd_kernel(const float *__restric
     if (threadIdx.x < MB_ROWS && c0 + (int)threadIdx.x < ds.C && ds.gb_off >= 0) {
         float s = 0.f;
         for (int b = 0; b < B; b++) s += sg[b][threadIdx.x];
-        grad[ds.gb_off + c0 + threadIdx.x] = s;
+        float *dst = grad + ds.gb_off + c0 + threadIdx.x;
+        *dst = accumulate ? *dst + s : s;
     }
+    if (ds.gw_off < 0) return;
     // thread = (4 consecutive k, row r): gW[c0 + r, k..k+3]
     const int kq = K / 4;
     for (int it = threadIdx.x; it < MB_ROWS * kq; it += 256) {
@@ -270,7 +273,13 @@ __global__ __launch_bounds__(256) void modbank_bwd_kernel(const float *__restric
             a.z = __builtin_fmaf(g, lv.z, a.z);
             a.w = __builtin_fmaf(g, lv.w, a.w);
         }
-        *reinterpret_cast<float4 *>(grad + ds.gw_off + (int64_t)(c0 + r) * K + k) = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+        float4 *dst = reinterpret_cast<float4 *>(grad + ds.gw_off + (int64_t)(c0 + r) * K + k);
+        float4 o = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+        if (accumulate) {
+            const float4 p = *dst;
+            o = make_float4(p.x + o.x, p.y + o.y, p.z + o.z, p.w + o.w);
+        }
+        *dst = o;
     }
 }
 
@@ -286,10 +295,81 @@ extern "C" int rick_modbank_fwd_f32(const float *lat, int B, int n_latent, int K
 
 extern "C" int rick_modbank_bwd_f32(const float *lat, const float *gs, int B, int n_latent, int K,
                                     const rick_modbank_desc *descs_device, int n, int total_blocks, float scale, float *grad,
-                                    void *stream) {
-    if (!lat || !gs || !descs_device || !grad || B < 1 || B > MB_MAXB || K < 256 || (K & 255) || n < 1 || total_blocks < 1)
+                                    int accumulate, void *stream) {
+    if (!lat || !gs || !descs_device || !grad || ((uintptr_t)grad & 15) || B < 1 || B > MB_MAXB || K < 256 || (K & 255) || n < 1 || total_blocks < 1)
         return RICK_EINVAL;
     hipLaunchKernelGGL(modbank_bwd_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, lat, gs, B, n_latent, K,
-                       descs_device, n, scale, grad);
+                       descs_device, n, scale, grad, accumulate);
+    RICK_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// EqualLinear on a short batch: the 8-layer mapping network (model_probe_tune.py:139-173, 418-428) maps [B <= 16, 512]
+// latents — per layer a GEMM with 8 rows, a bias scaling and the fused activation, i.e. three launches of 4-8 us for
+// 4 MFLOP.  One launch per layer here, PixelNorm (model_probe_tune.py:92-98) folded into the first:
+//   x'[b,:] = pixelnorm ? x[b,:] * rsqrt(mean_k x[b,k]^2 + 1e-8) : x[b,:]
+//   out[b,o] = act(scale * sum_k x'[b,k] W[o,k] + bias[o] * bias_mul),  act = gain * leaky_relu(., slope) or identity
+// A wave owns EL_CPW output columns: W rows are read once (float4 per lane), x' sits in LDS, sums finish with shuffles.
+#define EL_MAXB 16
+#define EL_CPW 2
+
+__global__ __launch_bounds__(256) void equal_linear_kernel(const float *__restrict__ x, const float *__restrict__ W,
+                                                           const float *__restrict__ bias, float *__restrict__ out, int B,
+                                                           int K, int O, float scale, float bias_mul, int act, float slope,
+                                                           float gain, int pixelnorm) {
+    extern __shared__ float sx[];   // [B][K]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = threadIdx.x * 4; j < B * K; j += 1024)
+        *reinterpret_cast<float4 *>(sx + j) = *reinterpret_cast<const float4 *>(x + j);
+    __syncthreads();
+    if (pixelnorm) {
+        for (int b = wave; b < B; b += 4) {
+            float q = 0.f;
+            for (int k = lane; k < K; k += 64) q = __builtin_fmaf(sx[b * K + k], sx[b * K + k], q);
+            q = wave_sum(q);
+            const float rn = rsqrtf(q / (float)K + 1e-8f);
+            for (int k = lane; k < K; k += 64) sx[b * K + k] *= rn;
+        }
+        __syncthreads();
+    }
+    const int o0 = ((int)blockIdx.x * 4 + wave) * EL_CPW;
+#pragma unroll
+    for (int r = 0; r < EL_CPW; r++) {
+        const int o = o0 + r;
+        if (o >= O) break;                          // wave-uniform
+        const float *wr = W + (int64_t)o * K;
+        float acc[EL_MAXB];
+#pragma unroll
+        for (int b = 0; b < EL_MAXB; b++) acc[b] = 0.f;
+        for (int k = lane * 4; k < K; k += 256) {
+            const float4 wv = *reinterpret_cast<const float4 *>(wr + k);
+#pragma unroll
+            for (int b = 0; b < EL_MAXB; b++)
+                if (b < B) {
+                    const float4 xv = *reinterpret_cast<const float4 *>(sx + b * K + k);
+                    acc[b] = __builtin_fmaf(wv.x, xv.x, acc[b]);
+                    acc[b] = __builtin_fmaf(wv.y, xv.y, acc[b]);
+                    acc[b] = __builtin_fmaf(wv.z, xv.z, acc[b]);
+                    acc[b] = __builtin_fmaf(wv.w, xv.w, acc[b]);
+                }
+        }
+        const float bo = bias ? bias[o] * bias_mul : 0.f;
+#pragma unroll
+        for (int b = 0; b < EL_MAXB; b++)
+            if (b < B) {
+                float v = wave_sum(acc[b]) * scale + bo;
+                if (act) v = (v > 0.f ? v : v * slope) * gain;
+                if (lane == 0) out[(int64_t)b * O + o] = v;
+            }
+    }
+}
+
+extern "C" int rick_equal_linear_f32(const float *x, const float *W, const float *bias, float *out, int B, int K, int O,
+                                     float scale, float bias_mul, int act, float slope, float gain, int pixelnorm,
+                                     void *stream) {
+    if (!x || !W || !out || B < 1 || B > EL_MAXB || K < 4 || (K & 3) || O < 1) return RICK_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)W) & 15) return RICK_EINVAL;
+    hipLaunchKernelGGL(equal_linear_kernel, dim3((unsigned)cdiv(O, 4 * EL_CPW)), dim3(256), (size_t)B * K * 4, (hipStream_t)stream,
+                       x, W, bias, out, B, K, O, scale, bias_mul, act, slope, gain, pixelnorm);
     RICK_LAUNCH_STATUS();
 }

@@ -81,7 +81,18 @@ class EqualLinear(nn.Module):
         self.scale = (1 / math.sqrt(in_dim)) * lr_mul
         self.lr_mul = lr_mul
 
-    def forward(self, x):
+    def _no_grad_needed(self, x):
+        return not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad
+                                                 or (self.bias is not None and self.bias.requires_grad)))
+
+    def forward(self, x, pixelnorm=False):
+        if (x.ndim == 2 and x.is_cuda and x.dtype == torch.float32 and x.shape[0] <= 16 and x.shape[1] % 4 == 0
+                and self.activation in (None, 'fused_lrelu') and self._no_grad_needed(x)):
+            # short-batch forward without autograd (the mapping network of every train step): one launch for
+            # [PixelNorm +] GEMM + bias * lr_mul + activation instead of 3 (+ 5)
+            return op.equal_linear(x, self.weight, self.bias, self.scale, self.lr_mul, bool(self.activation), pixelnorm)
+        if pixelnorm:
+            x = x * torch.rsqrt(torch.mean(x ** 2, dim=1, keepdim=True) + 1e-8)
         # x @ (W * scale)^T as one rocBLAS call (scale = GEMM alpha) instead of a [out, in] elementwise pass
         bias = self.bias if self.lr_mul == 1 or self.bias is None else self.bias * self.lr_mul
         if x.ndim != 2:
@@ -233,6 +244,20 @@ class ToRGB(nn.Module):
         return out
 
 
+class _Mapping(nn.Sequential):
+    """The mapping network ``Generator.style`` = Sequential(PixelNorm, EqualLinear x n_mlp) (model_probe_tune.py:418-428,
+    same child indices / state_dict keys); the PixelNorm is evaluated inside the first linear's launch."""
+
+    def forward(self, x):
+        mods = list(self)
+        if len(mods) > 1 and isinstance(mods[0], PixelNorm) and isinstance(mods[1], EqualLinear) and x.ndim == 2:
+            x = mods[1](x, pixelnorm=True)
+            mods = mods[2:]
+        for m in mods:
+            x = m(x)
+        return x
+
+
 class _FisherMixin:
     def estimate_fisher(self, loglikelihood):
         """(grads, {name: grad**2}) for every parameter that requires grad
@@ -250,8 +275,8 @@ class Generator(nn.Module, _FisherMixin):
     def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01):
         super().__init__()
         self.size, self.style_dim = size, style_dim
-        self.style = nn.Sequential(PixelNorm(), *[EqualLinear(style_dim, style_dim, lr_mul=lr_mlp,
-                                                              activation='fused_lrelu') for _ in range(n_mlp)])
+        self.style = _Mapping(PixelNorm(), *[EqualLinear(style_dim, style_dim, lr_mul=lr_mlp,
+                                                         activation='fused_lrelu') for _ in range(n_mlp)])
         self.channels = {r: _channels(r, channel_multiplier) for r in (4, 8, 16, 32, 64, 128, 256, 512, 1024)}
         self.input = ConstantInput(self.channels[4])
         self.conv1 = StyledConv(self.channels[4], self.channels[4], 3, style_dim, blur_kernel=blur_kernel)
@@ -356,6 +381,16 @@ class Generator(nn.Module, _FisherMixin):
                 inject_index = random.randint(1, self.n_latent - 1)
             latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
                                 styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
+        if randomize_noise and latent.is_cuda and all(n is None for n in noise):
+            # NoiseInjection draws image.new_empty(b, 1, h, w).normal_() per layer (model_probe_tune.py:294-296): the
+            # same i.i.d. N(0, 1) maps from ONE generator launch (per-layer views of one buffer)
+            B = latent.shape[0]
+            res = [4] + [2 ** i for i in range(3, self.log_size + 1) for _ in range(2)]
+            flat = torch.empty(B * sum(r * r for r in res), device=latent.device, dtype=latent.dtype).normal_()
+            noise, o = [], 0
+            for r in res:
+                noise.append(flat[o:o + B * r * r].view(B, 1, r, r))
+                o += B * r * r
         feats = []
         # one unbind instead of 20 selects: its backward is a single stack, not zeros + slice-copy + add per use
         lat = latent.unbind(1)

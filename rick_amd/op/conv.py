@@ -548,6 +548,7 @@ class _ConvBiasAct(Function):
         O, I, kh, kw = w.shape
         if x.shape[1] != I:
             raise RuntimeError(f'conv: input has {x.shape[1]} channels, weight expects {I}')
+        ctx.bias = bias                             # the Parameter itself (gradient sink target)
         bias = bias.contiguous()
         y = _conv_launch(x, _pack(w, wscale, key and (key[0], key[1] + '/conv')), O, kh, kw, s, p,
                          epi=_epilogue(bias, None, None, slope, gain))
@@ -559,18 +560,19 @@ class _ConvBiasAct(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        from .fused_act import _ActAdjoint
+        from .fused_act import _ActAdjoint, param_sink
         x, w, y = ctx.saved_tensors
         s, p, wscale, key, slope, gain = ctx.cfg
         O, I, kh, kw = w.shape
-        gz, gb, _ = _ActAdjoint.apply(g, y, None, slope, gain, ctx.needs_input_grad[2], False)
+        want_b = ctx.needs_input_grad[2]
+        gz, gb, _ = _ActAdjoint.apply(g, y, None, slope, gain, want_b, False, param_sink(ctx.bias, O, ctx.sink and want_b))
         gx = gw = None
         if ctx.needs_input_grad[0]:
             wpT = _pack(w.transpose(0, 1), wscale, key and (key[0], key[1] + '/T/convT'))
             gx = _convT_launch(gz, wpT, I, kh, kw, s, p, (x.shape[2], x.shape[3]))
         if ctx.needs_input_grad[1]:
             gw = _wgrad_launch(gz, x, kh, kw, s, p, wscale, out=_sink_target(key, w.shape, ctx.sink))
-        return gx, gw, (gb if ctx.needs_input_grad[2] else None), None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
 def conv2d_bias_act(x, w, bias, stride=1, padding=0, wscale=1.0, key=None, negative_slope=0.2, gain=2 ** 0.5):

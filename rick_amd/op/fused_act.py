@@ -21,6 +21,11 @@ from torch.autograd import Function
 from .._lib import check, lib, ptr, require_cuda_f32, stream_ptr
 
 
+def grad_sink_enabled():
+    from .conv import grad_sink_enabled as f
+    return f()
+
+
 def _as_rows(x):
     """-> (tensor in [rows, C] memory order, rows, C, hw)."""
     if x.ndim == 2:
@@ -53,29 +58,43 @@ def _pointwise(x, bias, ref, grad_mode, slope, scale, noise, nw):
     return out
 
 
+def param_sink(p, numel, enabled):
+    """The parameter's ``.grad`` when a [numel] gradient may be ADDED straight into it (op.grad_sink(), see op/conv.py),
+    else None.  `enabled` is the switch as the op's forward saw it."""
+    if not enabled or p is None:
+        return None
+    if not (p.is_leaf and p.requires_grad and p.grad is not None and p.grad.is_contiguous() and p.numel() == numel):
+        return None
+    return p.grad
+
+
 class _ActAdjoint(Function):
-    """L*: g -> (gx, gb, gnw) given the saved output y (and noise)."""
+    """L*: g -> (gx, gb, gnw) given the saved output y (and noise).  A gradient that is not wanted is None (not a zero
+    tensor).  sink_b / sink_w: the parameters' .grad buffers — the reduction's second stage adds the sums into them and
+    the corresponding output is None (nothing left for autograd to accumulate)."""
 
     @staticmethod
-    def forward(ctx, g, y, noise, slope, scale, want_b, want_w):
+    def forward(ctx, g, y, noise, slope, scale, want_b, want_w, sink_b=None, sink_w=None):
         gr, rows, c, hw = _as_rows(g)
         yr, _, _, _ = _as_rows(y)
         gx = torch.empty_like(gr)
-        nz, nb, nhw = _noise_args(noise, g) if (noise is not None and want_w) else (None, 1, 1)
-        gb = torch.empty(c, device=g.device, dtype=g.dtype) if want_b else None
-        gw = torch.empty(1, device=g.device, dtype=g.dtype) if nz is not None else None
+        want_w = want_w and noise is not None
+        nz, nb, nhw = _noise_args(noise, g) if want_w else (None, 1, 1)
+        if (want_b and sink_b is None) or (want_w and sink_w is None):
+            sink_b = sink_w = None                     # one accumulate switch serves both sums
+        sunk = (want_b and sink_b is not None) or (want_w and sink_w is not None)
+        gb = (sink_b if sunk else torch.empty(c, device=g.device, dtype=g.dtype)) if want_b else None
+        gw = (sink_w if sunk else torch.empty(1, device=g.device, dtype=g.dtype)) if want_w else None
         part = None
-        if want_b or nz is not None:
+        if want_b or want_w:
             nblk = lib.rick_bias_act_bwd_blocks(rows, c)
             part = torch.empty(nblk * (c + 1), device=g.device, dtype=g.dtype)
         check(lib.rick_bias_act_bwd_f32(ptr(gr), ptr(yr), ptr(gx), ptr(gb), ptr(gw), ptr(nz), rows, c, hw, nb, nhw,
-                                        slope, scale, ptr(part), stream_ptr()), 'rick_bias_act_bwd_f32')
+                                        slope, scale, ptr(part), int(sunk), stream_ptr()), 'rick_bias_act_bwd_f32')
         ctx.save_for_backward(y, noise)
         ctx.cfg = (slope, scale)
-        if gb is None:
-            gb = g.new_zeros(c)
-        if gw is None:
-            gw = g.new_zeros(1)
+        if sunk:
+            return gx, None, None
         return gx, gb, gw
 
     @staticmethod
@@ -83,7 +102,7 @@ class _ActAdjoint(Function):
         y, noise = ctx.saved_tensors
         slope, scale = ctx.cfg
         out = _ActLinear.apply(ggx, ggb, ggw, y, noise, slope, scale)
-        return out, None, None, None, None, None, None
+        return out, None, None, None, None, None, None, None, None
 
 
 class _ActLinear(Function):
@@ -114,15 +133,19 @@ class _Act(Function):
         ctx.save_for_backward(y, noise)
         ctx.cfg = (slope, scale)
         ctx.need = (bias is not None, noise is not None)
+        ctx.params = (bias, nw, grad_sink_enabled())      # the switch as the forward's thread sees it (op/conv.py)
         return y
 
     @staticmethod
     def backward(ctx, g):
         y, noise = ctx.saved_tensors
         slope, scale = ctx.cfg
-        gx, gb, gw = _ActAdjoint.apply(g, y, noise, slope, scale, ctx.need[0] and ctx.needs_input_grad[1],
-                                       ctx.need[1] and ctx.needs_input_grad[3])
-        return (gx, gb if ctx.need[0] else None, None, gw if ctx.need[1] else None, None, None)
+        bias, nw, sink = ctx.params
+        want_b, want_w = ctx.need[0] and ctx.needs_input_grad[1], ctx.need[1] and ctx.needs_input_grad[3]
+        sink = sink and not torch.is_grad_enabled()       # a twice-differentiable backward keeps its gradients in the graph
+        gx, gb, gw = _ActAdjoint.apply(g, y, noise, slope, scale, want_b, want_w,
+                                       param_sink(bias, y.shape[1], sink and want_b), param_sink(nw, 1, sink and want_w))
+        return (gx, gb, None, gw, None, None)
 
 
 def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):

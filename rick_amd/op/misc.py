@@ -31,13 +31,14 @@ def _chan_scale_raw(x, s):
     return y
 
 
-def _hw_dot_raw(a, b):
+def _hw_dot_raw(a, b, divisor=None):
+    """sum_hw a*b -> [n, c]; `divisor` [n, c]: the sums are divided by it in the reduction's second stage."""
     a, b = _nhwc(a), _nhwc(b)
     n, c, h, w = a.shape
     d = torch.empty((n, c), device=a.device, dtype=a.dtype)
     nb = lib.rick_hw_dot_blocks(h * w)
     part = torch.empty(nb * n * c, device=a.device, dtype=a.dtype)
-    check(lib.rick_hw_dot_f32(ptr(a), ptr(b), ptr(d), n, h * w, c, ptr(part), stream_ptr()), 'rick_hw_dot_f32')
+    check(lib.rick_hw_dot_f32(ptr(a), ptr(b), ptr(d), n, h * w, c, ptr(part), ptr(divisor), stream_ptr()), 'rick_hw_dot_f32')
     return d
 
 
@@ -262,3 +263,21 @@ def minibatch_stddev(x, stddev_group=25, stddev_feat=1, second_order=False, call
     if calls == 1:
         return _mbstd_composite(x, stddev_group, stddev_feat)
     return torch.cat([_mbstd_composite(xc, stddev_group, stddev_feat) for xc in x.chunk(calls)], 0)
+
+
+# ------------------------------------------------------------------------- short-batch EqualLinear
+def equal_linear(x, weight, bias, scale, lr_mul=1.0, activate=False, pixelnorm=False, negative_slope=0.2, gain=2 ** 0.5):
+    """act(scale * PixelNorm?(x) @ weight^T + bias * lr_mul) for x [B <= 16, K] in one launch (EqualLinear forward,
+    model_probe_tune.py:157-168; act = fused_leaky_relu's gain * leaky_relu).  No autograd graph is recorded."""
+    require_cuda_f32(x, weight, bias)
+    x = x.detach().contiguous()
+    w = weight.detach().contiguous()
+    B, K = x.shape
+    O = w.shape[0]
+    if w.shape[1] != K:
+        raise RuntimeError(f'equal_linear: input has {K} features, weight expects {w.shape[1]}')
+    out = torch.empty((B, O), device=x.device, dtype=x.dtype)
+    b = bias.detach().contiguous() if bias is not None else None
+    check(lib.rick_equal_linear_f32(ptr(x), ptr(w), ptr(b), ptr(out), B, K, O, float(scale), float(lr_mul), int(activate),
+                                    float(negative_slope), float(gain), int(pixelnorm), stream_ptr()), 'rick_equal_linear_f32')
+    return out

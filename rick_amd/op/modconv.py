@@ -102,6 +102,7 @@ class _ModConvFused(Function):
         s = s.contiguous()
         d = d.contiguous() if d is not None else None
         tail = bias is not None
+        tail_params = (bias, nw)                  # the Parameters themselves (gradient sink targets)
         wp = _pack(w, wscale, key and (key[0], key[1] + ('/convT' if upsample else '/conv')))
         if upsample:
             if tail:
@@ -114,6 +115,7 @@ class _ModConvFused(Function):
         else:
             y = _conv_launch(x, wp, O, kh, kw, 1, kh // 2, iscale=s, oscale=d)
         ctx.save_for_backward(x, w, s, d, y, *((bias, noise, nw) if tail else ()))
+        ctx.tail_params = tail_params
         ctx.cfg = (wscale, upsample, key, tail, slope, gain)
         ctx.sink = grad_sink_enabled()
         return y
@@ -127,9 +129,12 @@ class _ModConvFused(Function):
         g = g.contiguous(memory_format=torch.channels_last)
         gx = gs = gw = gd = gb = gnw = None
         if tail:
-            from .fused_act import _ActAdjoint
+            from .fused_act import _ActAdjoint, param_sink
             bias, noise, nw = ctx.saved_tensors[5:]
-            g, gb, gnw = _ActAdjoint.apply(g, y, noise, slope, gain, ctx.needs_input_grad[7], ctx.needs_input_grad[9])
+            want_b, want_w = ctx.needs_input_grad[7], ctx.needs_input_grad[9]
+            g, gb, gnw = _ActAdjoint.apply(g, y, noise, slope, gain, want_b, want_w,
+                                           param_sink(ctx.tail_params[0], O, ctx.sink and want_b),
+                                           param_sink(ctx.tail_params[1], 1, ctx.sink and want_w))
         wT = w.transpose(0, 1)
         wpT = _pack(wT, wscale, key and (key[0], key[1] + '/T'))
         # unscaled data gradient: gx' = W^T (g * d)
@@ -154,11 +159,10 @@ class _ModConvFused(Function):
         if d is not None and ctx.needs_input_grad[3]:
             # conv_out = d * y'  ->  sum g*y' = (sum g*conv_out) / d,  d > 0
             if tail:
-                gd = _hw_dot_act_raw(g, y, bias, noise, nw, slope, gain) / d
+                gd = _hw_dot_act_raw(g, y, bias, noise, nw, slope, gain, divisor=d)
             else:
-                gd = _hw_dot_raw(g, y) / d
-        return (gx, gw, gs, gd, None, None, None, gb if ctx.needs_input_grad[7] else None, None,
-                gnw if ctx.needs_input_grad[9] else None, None, None)
+                gd = _hw_dot_raw(g, y, divisor=d)
+        return (gx, gw, gs, gd, None, None, None, gb, None, gnw, None, None)
 
 
 def _hw_dot_scale_raw(a, b, scale):
@@ -174,12 +178,12 @@ def _hw_dot_scale_raw(a, b, scale):
     return out, scaled
 
 
-def _hw_dot_act_raw(g, y, bias, noise, nw, slope, gain):
+def _hw_dot_act_raw(g, y, bias, noise, nw, slope, gain, divisor=None):
     n, c, h, w = g.shape
     out = torch.empty((n, c), device=g.device, dtype=g.dtype)
     part = torch.empty(lib.rick_hw_dot_blocks(h * w) * n * c, device=g.device, dtype=g.dtype)
     check(lib.rick_hw_dot_act_f32(ptr(g), ptr(y), ptr(out), n, h * w, c, ptr(bias), ptr(noise), ptr(nw), noise.shape[0],
-                                  float(slope), float(gain), ptr(part), stream_ptr()), 'rick_hw_dot_act_f32')
+                                  float(slope), float(gain), ptr(part), ptr(divisor), stream_ptr()), 'rick_hw_dot_act_f32')
     return out
 
 
@@ -251,6 +255,34 @@ class ModulationBank:
             self._tables[B] = ent
         return ent[0]
 
+    def sink_table(self, B, device):
+        """(device table, base address) whose gradient offsets address the parameters' OWN ``.grad`` buffers relative to
+        `base` (op.grad_sink(): the backward launch adds into them), -1 for parameters that take no gradient; None when
+        some parameter that needs a gradient has no suitable buffer."""
+        need = [p.requires_grad for p in self.params()]
+        grads = [p.grad if n else None for p, n in zip(self.params(), need)]
+        if any(n and (g is None or not p.is_leaf or not g.is_contiguous() or g.data_ptr() % 16 or g.dtype != torch.float32)
+               for p, g, n in zip(self.params(), grads, need)) or not any(need):
+            return None
+        sig = (tuple(p.data_ptr() for p in self.params()), tuple(g.data_ptr() if g is not None else 0 for g in grads))
+        ent = self._tables.get(('sink', B))
+        if ent is None or ent[1] != sig:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('ModulationBank: descriptor table must be built before hipGraph capture (run the step eagerly once)')
+            base = min(g.data_ptr() for g in grads if g is not None)
+            arr = np.zeros(len(self.linears), dtype=_MB_DESC)
+            io = 0
+            for i, m in enumerate(self.linears):
+                gw, gb = grads[2 * i], grads[2 * i + 1]
+                arr[i] = (m.weight.data_ptr(), m.bias.data_ptr(), io, (gw.data_ptr() - base) // 4 if gw is not None else -1,
+                          (gb.data_ptr() - base) // 4 if gb is not None else -1, self.C[i], self.lat_idx[i], self.blk_begin[i], 0)
+                io += B * self.C[i]
+            if ent is not None:
+                self._retired.append(ent[0])
+            ent = (torch.from_numpy(arr.view(np.uint8).copy()).to(device), sig, base)
+            self._tables[('sink', B)] = ent
+        return ent[0], ent[2]
+
     def __call__(self, latent):
         """latent [B, n_latent, K] (no gradient is produced for it) -> list of s_l [B, C_l]."""
         require_cuda_f32(latent)
@@ -269,6 +301,8 @@ class _ModBank(Function):
                                        stream_ptr()), 'rick_modbank_fwd_f32')
         ctx.save_for_backward(latent)
         ctx.bank = bank
+        ctx.sink = grad_sink_enabled()
+        ctx.set_materialize_grads(False)
         res, off, dead = [], 0, []
         for i, c in enumerate(bank.C):
             res.append(out[off:off + B * c].view(B, c))
@@ -289,10 +323,23 @@ class _ModBank(Function):
         B, n_latent, K = latent.shape
         if ctx.needs_input_grad[0]:
             raise RuntimeError('ModulationBank produces no latent gradient; use the per-layer path when the latent requires grad')
-        flat = torch.cat([(g if g is not None else latent.new_zeros(B, c)).reshape(-1) for g, c in zip(gs, bank.C)])
+        need = ctx.needs_input_grad[2:]
+        live = [need[2 * i] or need[2 * i + 1] for i in range(len(bank.C))]
+        if not any(live):
+            return (None,) * (2 + len(need))
+        if any(l and g is None for l, g in zip(live, gs)):       # an unused output of a trainable layer: zero gradient
+            gs = [g if (g is not None or not l) else latent.new_zeros(B, c) for g, l, c in zip(gs, live, bank.C)]
+        # frozen layers (their slice of `flat` is never read) get an uninitialised placeholder: no fill launch
+        flat = torch.cat([(g if l else latent.new_empty(B, c)).reshape(-1) for g, l, c in zip(gs, live, bank.C)])
+        sink = bank.sink_table(B, latent.device) if ctx.sink else None
+        if sink is not None:
+            # op.grad_sink(): the launch adds every weight / bias gradient straight into the parameter's .grad
+            check(lib.rick_modbank_bwd_f32(ptr(latent), ptr(flat), B, n_latent, K, ptr(sink[0]), len(bank.C), bank.total_blocks,
+                                           bank.scale, sink[1], 1, stream_ptr()), 'rick_modbank_bwd_f32')
+            return (None,) * (2 + len(need))
         grad = torch.empty(bank.grad_floats, device=latent.device, dtype=latent.dtype)
         check(lib.rick_modbank_bwd_f32(ptr(latent), ptr(flat), B, n_latent, K, ptr(bank.table(B, latent.device)), len(bank.C),
-                                       bank.total_blocks, bank.scale, ptr(grad), stream_ptr()), 'rick_modbank_bwd_f32')
+                                       bank.total_blocks, bank.scale, ptr(grad), 0, stream_ptr()), 'rick_modbank_bwd_f32')
         res = [None, None]
         for i, c in enumerate(bank.C):
             need_w, need_b = ctx.needs_input_grad[2 + 2 * i], ctx.needs_input_grad[3 + 2 * i]

@@ -97,7 +97,8 @@ class _FirAct(Function):
 
     @staticmethod
     def forward(ctx, x, taps, pad4, bias, noise, nw, slope, gain):
-        from .conv import _epilogue
+        from .conv import _epilogue, grad_sink_enabled
+        ctx.params = (bias, nw, grad_sink_enabled())      # op.grad_sink(): bias / noise-strength gradients go straight to .grad
         n, c, h, w = x.shape
         kh, kw = taps.shape
         oh, ow = h + pad4[2] + pad4[3] - kh + 1, w + pad4[0] + pad4[1] - kw + 1
@@ -114,16 +115,19 @@ class _FirAct(Function):
         ctx.cfg = (slope, gain, (kw - pad4[0] - 1, w - ow + pad4[0], kh - pad4[2] - 1, h - oh + pad4[2]))
         return y
 
+
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        from .fused_act import _ActAdjoint
+        from .fused_act import _ActAdjoint, param_sink
         y, noise = ctx.saved_tensors
         slope, gain, adj = ctx.cfg
-        gz, gb, gw = _ActAdjoint.apply(g, y, noise, slope, gain, ctx.needs_input_grad[3], ctx.needs_input_grad[5])
+        bias, nw, sink = ctx.params
+        want_b, want_w = ctx.needs_input_grad[3], ctx.needs_input_grad[5]
+        gz, gb, gw = _ActAdjoint.apply(g, y, noise, slope, gain, want_b, want_w,
+                                       param_sink(bias, y.shape[1], sink and want_b), param_sink(nw, 1, sink and want_w))
         gx = _fir(gz, ctx.flipped, (1, 1), (1, 1), adj) if ctx.needs_input_grad[0] else None
-        return (gx, None, None, gb if ctx.needs_input_grad[3] else None, None,
-                gw if ctx.needs_input_grad[5] else None, None, None)
+        return (gx, None, None, gb, None, gw, None, None)
 
 
 def upfirdn2d_noise_bias_act(input, kernel, pad, bias, noise, noise_weight, negative_slope=0.2, gain=2 ** 0.5):

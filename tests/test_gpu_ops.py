@@ -1,5 +1,6 @@
 """GPU parity tests of the HIP ops (through the C ABI) against the CPU oracle and the
 reference-derived golden vectors.  Run with `-m gpu` on an MI355X."""
+import contextlib
 import math
 
 import numpy as np
@@ -551,3 +552,105 @@ def test_unused_reference_variants_downsample_modconv_and_scaled_lrelu():
     out = layer(xi.to(DEV))
     refo = F.leaky_relu(F.conv2d(xi.double(), layer[0].weight.detach().double().cpu() * layer[0].scale, padding=1), 0.2) * math.sqrt(2)
     assert rel_err(out, refo) < 3e-5
+
+
+def test_gradient_sink_equals_autograd_accumulation():
+    """op.grad_sink(): the bias / noise-strength sums of the activation adjoint (rick_bias_act_bwd_f32, accumulate), the
+    conv weight gradients and the ModulationBank gradients are ADDED straight into the parameters' .grad — the values
+    must equal what autograd's AccumulateGrad leaves there (same fp32 additions), starting from a non-zero .grad."""
+    from rick_amd import op
+    from rick_amd.models import Generator
+    from rick_amd.op.modconv import modulated_conv_fused
+    gen = torch.Generator().manual_seed(11)
+    mk = lambda *s: torch.randn(*s, generator=gen).to(DEV)         # noqa: E731
+    B, I, O, H = 2, 64, 64, 16
+    params = {'w1': mk(O, I, 3, 3), 'b1': mk(O), 'w2': mk(O, O, 3, 3), 'b2': mk(O), 'nw2': mk(1), 'b3': mk(O), 'nw3': mk(1), 'b4': mk(O)}
+    x = mk(B, I, H, H).contiguous(memory_format=torch.channels_last)
+    s, d = mk(B, O) * 0.5 + 1, torch.rand(B, O, generator=gen).to(DEV) + 0.5
+    noise = mk(B, 1, H, H)
+    k = torch.tensor([1., 3., 3., 1.])
+    k = (torch.outer(k, k) / 64).to(DEV)
+    init = {n: mk(*p.shape) for n, p in params.items()}
+    gout = mk(B, O, H, H)
+
+    def run(sink):
+        ps = {n: p.clone().requires_grad_(True) for n, p in params.items()}
+        for n, p in ps.items():
+            p.grad = init[n].clone()
+        ctx = op.grad_sink() if sink else contextlib.nullcontext()
+        with ctx:
+            y = op.conv2d_bias_act(x, ps['w1'], ps['b1'], 1, 1, wscale=0.05, key=(ps['w1'], 'w'))
+            y = modulated_conv_fused(y, ps['w2'], s, d, 0.04, False, (ps['w2'], 'mod'), (ps['b2'], noise, ps['nw2'], 0.2, 2 ** 0.5))
+            y = op.upfirdn2d_noise_bias_act(y, k * 4, (2, 1), ps['b3'], noise, ps['nw3'])
+            y = op.fused_leaky_relu(y, ps['b4'])
+            y.backward(gout)
+        return {n: p.grad.clone() for n, p in ps.items()}
+
+    ref, got = run(False), run(True)
+    for n in ref:
+        assert torch.equal(ref[n], got[n]), n
+        assert not torch.equal(ref[n], init[n]), n
+    # ModulationBank: weight / bias gradients of the trainable linears land in .grad, frozen layers are skipped
+    torch.manual_seed(3)
+    g = Generator(32, 512, 2).to(DEV)
+    bank = g._modulation_bank()
+    for m in bank.linears[1::3]:                       # freeze the ToRGB modulations (as the trainer does)
+        m.weight.requires_grad = m.bias.requires_grad = False
+    lat = torch.randn(2, g.n_latent, 512, device=DEV)
+    gs = None
+    res = []
+    for sink in (False, True):
+        for p in bank.params():
+            p.grad = torch.full_like(p, 0.25) if p.requires_grad else None
+        with (op.grad_sink() if sink else contextlib.nullcontext()):
+            outs = [o for o in bank(lat) if o.requires_grad]
+            gs = gs or [torch.randn_like(o) for o in outs]
+            torch.autograd.backward(outs, gs)
+        res.append([p.grad.clone() if p.grad is not None else None for p in bank.params()])
+    for a, b in zip(*res):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('B,K,O,act,pn', [(8, 512, 512, True, True), (1, 512, 512, True, False), (16, 512, 256, False, False),
+                                          (3, 64, 40, True, True)])
+def test_equal_linear_short_batch_kernel(B, K, O, act, pn):
+    """rick_equal_linear_f32 ([PixelNorm +] EqualLinear + bias * lr_mul + fused activation in one launch,
+    model_probe_tune.py:92-98, 139-173) vs the same formula in fp64."""
+    from rick_amd import op
+    gen = torch.Generator().manual_seed(B + K + O)
+    x = torch.randn(B, K, generator=gen).to(DEV)
+    w = (torch.randn(O, K, generator=gen) / 0.01).to(DEV)
+    b = torch.randn(O, generator=gen).to(DEV)
+    scale, lr_mul = (1 / math.sqrt(K)) * 0.01, 0.01
+    y = op.equal_linear(x, w, b, scale, lr_mul, act, pn)
+    xd = x.double()
+    if pn:
+        xd = xd * torch.rsqrt(xd.pow(2).mean(1, keepdim=True) + 1e-8)
+    ref = xd @ (w.double() * scale).t() + b.double() * lr_mul
+    if act:
+        ref = F.leaky_relu(ref, 0.2) * math.sqrt(2)
+    assert y.shape == ref.shape and rel_err(y, ref) < 2e-6
+
+
+def test_mapping_network_fast_path_equals_autograd_path():
+    """Generator.style without autograd (the train steps' latents) runs the one-launch-per-layer kernels; with autograd
+    (Fisher sweep, tests differentiating through the mapping network) the rocBLAS + fused-activation path.  Same values."""
+    from rick_amd.models import Generator
+    torch.manual_seed(9)
+    g = Generator(32, 512, 8).to(DEV)
+    z = torch.randn(8, 512, device=DEV)
+    with torch.no_grad():
+        fast = g.style(z)
+    slow = g.style(z.clone().requires_grad_(True))
+    assert slow.requires_grad and not fast.requires_grad
+    assert rel_err(fast, slow.detach().double()) < 5e-6
+    # randomize_noise draws every layer's noise map from one launch: right shapes, fresh values per call
+    for n, p in g.named_parameters():
+        if n.endswith('noise.weight'):
+            p.data.fill_(0.5)
+    with torch.no_grad():
+        a, _ = g([z[:2]])
+        b, _ = g([z[:2]])
+    assert a.shape == (2, 3, 32, 32) and torch.isfinite(a).all() and not torch.equal(a, b)
