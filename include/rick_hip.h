@@ -200,6 +200,14 @@ int rick_thin_fwd_f32(const float *x, const float *W, int64_t w_bstride, const f
                       float *t, int N, int64_t P, int C, int J, void *stream);
 int rick_thin_bwdx_f32(const float *t, const float *W, int64_t w_bstride, float *x,
                        int N, int64_t P, int C, int J, void *stream);
+/* ToRGB (model_probe_tune.py:246-248, 366-370) with the per-sample weight formed on the fly,
+ * W[n,j,c] = (wscale * w[j,c]) * s[n,c]  (w [J, C] shared, s [N, C] the style; both 16-byte aligned):
+ *   fwd :  t[n,j,p] = sum_c x[n,p,c] * W[n,j,c] + bias[j] (+ add[n,j,p])     (bias / add may be NULL)
+ *   bwdx:  gx[n,p,c] = sum_j g[n,j,p] * W[n,j,c] */
+int rick_torgb_fwd_f32(const float *x, const float *w, const float *s, float wscale, const float *bias,
+                       const float *add, float *t, int N, int64_t P, int C, int J, void *stream);
+int rick_torgb_bwdx_f32(const float *g, const float *w, const float *s, float wscale, float *gx, int N, int64_t P,
+                        int C, int J, void *stream);
 int rick_thin_wgrad_blocks(int64_t P);
 int rick_thin_wgrad_f32(const float *t, const float *x, float *G, int N, int64_t P, int C, int J,
                         float *partials, void *stream);

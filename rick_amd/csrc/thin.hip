@@ -7,13 +7,32 @@
 
 #define THIN_MAXJ 4
 
+// ToRGB form (model_probe_tune.py:246-248, 366-370): the per-sample weight is formed on the fly from the shared [J, C]
+// weight and the style, W[n,j,c] = (wscale * w[j,c]) * s[n,c] (the reference's association), and bias[j] is added to the
+// output before `add` (the upsampled skip image) — the [N, J, C] weight tensor, its two multiplies and the two
+// adds per layer never run as launches of their own.  smod == NULL: plain per-sample / shared W as given.
+struct ThinMod {
+    const float *smod;   // [N, C] or NULL
+    float wscale;
+    const float *bias;   // [J] or NULL
+};
+
+__device__ __forceinline__ float4 thin_w(const float *__restrict__ Wrow, const ThinMod &m, int n, int C, int c) {
+    float4 w = *reinterpret_cast<const float4 *>(Wrow + c);
+    if (m.smod) {
+        const float4 sv = *reinterpret_cast<const float4 *>(m.smod + (int64_t)n * C + c);
+        w = make_float4((m.wscale * w.x) * sv.x, (m.wscale * w.y) * sv.y, (m.wscale * w.z) * sv.z, (m.wscale * w.w) * sv.w);
+    }
+    return w;
+}
+
 // t[n,j,p] = sum_c x[n,p,c] * W[n,j,c] (+ add[n,j,p]);  LPP lanes cooperate on one pixel.
 // A lane owns the same NQ channel quads for every pixel it visits, so its W values live in registers
 // (NQ x J float4) and the loop body is one 16-byte load of x per quad; UNR pixels are in flight per lane.
 template <int NQ>
 __global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__ x, const float *__restrict__ W,
                                                        int64_t w_bstride, const float *__restrict__ add,
-                                                       float *__restrict__ t, int64_t P, int C, int J, int lpp) {
+                                                       float *__restrict__ t, int64_t P, int C, int J, int lpp, ThinMod m) {
     constexpr int UNR = 4;
     const int n = blockIdx.y;
     const int pix_per_block = 256 / lpp;
@@ -25,7 +44,7 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__
 #pragma unroll
         for (int j = 0; j < THIN_MAXJ; j++)
             // rows j >= J re-read row J-1 (their sums are never stored): no branch, so the 4 x NQ loads batch
-            wr[qd][j] = *reinterpret_cast<const float4 *>(Wn + (int64_t)(j < J ? j : J - 1) * C + (sub + qd * lpp) * 4);
+            wr[qd][j] = thin_w(Wn + (int64_t)(j < J ? j : J - 1) * C, m, n, C, (sub + qd * lpp) * 4);
     const float *xn = x + (int64_t)n * P * C + sub * 4;
     const int64_t stride = (int64_t)gridDim.x * pix_per_block;
     for (int64_t p0 = (int64_t)blockIdx.x * pix_per_block + pl; p0 < P; p0 += stride * UNR) {
@@ -57,6 +76,7 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__
                 if (sub == 2) v = acc[2];
                 if (sub == 3) v = acc[3];
                 const int64_t o = ((int64_t)n * J + sub) * P + p;
+                if (m.bias) v += m.bias[sub];
                 if (add) v += add[o];
                 t[o] = v;
             }
@@ -67,7 +87,8 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__
 // Generic form (any C % 4 == 0): lanes stride over the channel quads, W re-read through L1.
 __global__ __launch_bounds__(256) void thin_fwd_generic_kernel(const float *__restrict__ x, const float *__restrict__ W,
                                                                int64_t w_bstride, const float *__restrict__ add,
-                                                               float *__restrict__ t, int64_t P, int C, int J, int lpp) {
+                                                               float *__restrict__ t, int64_t P, int C, int J, int lpp,
+                                                               ThinMod m) {
     const int n = blockIdx.y;
     const int pix_per_block = 256 / lpp;
     const int sub = threadIdx.x % lpp, pl = threadIdx.x / lpp;
@@ -83,7 +104,7 @@ __global__ __launch_bounds__(256) void thin_fwd_generic_kernel(const float *__re
 #pragma unroll
                 for (int j = 0; j < THIN_MAXJ; j++)
                     if (j < J) {
-                        const float4 wv = *reinterpret_cast<const float4 *>(Wn + (int64_t)j * C + c4 * 4);
+                        const float4 wv = thin_w(Wn + (int64_t)j * C, m, n, C, c4 * 4);
                         acc[j] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
                     }
             }
@@ -97,14 +118,15 @@ __global__ __launch_bounds__(256) void thin_fwd_generic_kernel(const float *__re
             if (sub == 2) v = acc[2];
             if (sub == 3) v = acc[3];
             const int64_t o = ((int64_t)n * J + sub) * P + p;
+            if (m.bias) v += m.bias[sub];
             if (add) v += add[o];
             t[o] = v;
         }
     }
 }
 
-extern "C" int rick_thin_fwd_f32(const float *x, const float *W, int64_t w_bstride, const float *add, float *t,
-                                 int N, int64_t P, int C, int J, void *stream) {
+static int thin_fwd_launch(const float *x, const float *W, int64_t w_bstride, const float *add, float *t, int N, int64_t P, int C,
+                           int J, ThinMod m, void *stream) {
     if (!x || !W || !t || N <= 0 || P <= 0 || C <= 0 || C % 4 || J < 1 || J > THIN_MAXJ || N > 65535) return RICK_EINVAL;
     const int C4 = C / 4;
     hipStream_t st = (hipStream_t)stream;
@@ -119,14 +141,14 @@ extern "C" int rick_thin_fwd_f32(const float *x, const float *W, int64_t w_bstri
         int64_t nbg = cdiv64(P, 256 / lpp);
         if (nbg > 4096) nbg = 4096;
         hipLaunchKernelGGL(thin_fwd_generic_kernel, dim3((unsigned)nbg, N), dim3(256), 0, st, x, W, w_bstride, add, t, P, C,
-                           J, lpp);
+                           J, lpp, m);
         RICK_LAUNCH_STATUS();
     }
     int64_t nb = cdiv64(P, (int64_t)(256 / lpp) * 4);
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
     const dim3 grid((unsigned)nb, N), blk(256);
-#define THIN_FWD_LAUNCH(Q) hipLaunchKernelGGL(thin_fwd_kernel<Q>, grid, blk, 0, st, x, W, w_bstride, add, t, P, C, J, lpp)
+#define THIN_FWD_LAUNCH(Q) hipLaunchKernelGGL(thin_fwd_kernel<Q>, grid, blk, 0, st, x, W, w_bstride, add, t, P, C, J, lpp, m)
     switch (nq) {
     case 1: THIN_FWD_LAUNCH(1); break;
     case 2: THIN_FWD_LAUNCH(2); break;
@@ -141,9 +163,23 @@ extern "C" int rick_thin_fwd_f32(const float *x, const float *W, int64_t w_bstri
     RICK_LAUNCH_STATUS();
 }
 
+extern "C" int rick_thin_fwd_f32(const float *x, const float *W, int64_t w_bstride, const float *add, float *t,
+                                 int N, int64_t P, int C, int J, void *stream) {
+    const ThinMod none = {nullptr, 1.f, nullptr};
+    return thin_fwd_launch(x, W, w_bstride, add, t, N, P, C, J, none, stream);
+}
+
+extern "C" int rick_torgb_fwd_f32(const float *x, const float *w, const float *s, float wscale, const float *bias,
+                                  const float *add, float *t, int N, int64_t P, int C, int J, void *stream) {
+    if (!s || (((uintptr_t)s | (uintptr_t)w) & 15)) return RICK_EINVAL;
+    const ThinMod m = {s, wscale, bias};
+    return thin_fwd_launch(x, w, 0, add, t, N, P, C, J, m, stream);
+}
+
 // x[n,p,c] = sum_j t[n,j,p] * W[n,j,c]
 __global__ __launch_bounds__(256) void thin_bwdx_kernel(const float *__restrict__ t, const float *__restrict__ W,
-                                                        int64_t w_bstride, float *__restrict__ x, int64_t P, int C, int J) {
+                                                        int64_t w_bstride, float *__restrict__ x, int64_t P, int C, int J,
+                                                        ThinMod m) {
     const int n = blockIdx.y;
     const int C4 = C >> 2;
     const int64_t total4 = P * C4;
@@ -160,7 +196,7 @@ __global__ __launch_bounds__(256) void thin_bwdx_kernel(const float *__restrict_
         for (int j = 0; j < THIN_MAXJ; j++) {   // unconditional loads (row J-1 again for j >= J), zero weight after
             const int jj = j < J ? j : J - 1;
             tv[j] = tn[(int64_t)jj * P + p];
-            wv[j] = *reinterpret_cast<const float4 *>(Wn + (int64_t)jj * C + c4 * 4);
+            wv[j] = thin_w(Wn + (int64_t)jj * C, m, n, C, c4 * 4);
         }
 #pragma unroll
         for (int j = 0; j < THIN_MAXJ; j++) {
@@ -171,13 +207,26 @@ __global__ __launch_bounds__(256) void thin_bwdx_kernel(const float *__restrict_
     }
 }
 
-extern "C" int rick_thin_bwdx_f32(const float *t, const float *W, int64_t w_bstride, float *x, int N, int64_t P, int C,
-                                  int J, void *stream) {
+static int thin_bwdx_launch(const float *t, const float *W, int64_t w_bstride, float *x, int N, int64_t P, int C, int J, ThinMod m,
+                            void *stream) {
     if (!x || !W || !t || N <= 0 || P <= 0 || C <= 0 || C % 4 || J < 1 || J > THIN_MAXJ || N > 65535) return RICK_EINVAL;
     int64_t nb = cdiv64(P * (C / 4), 256);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(thin_bwdx_kernel, dim3((unsigned)nb, N), dim3(256), 0, (hipStream_t)stream, t, W, w_bstride, x, P, C, J);
+    hipLaunchKernelGGL(thin_bwdx_kernel, dim3((unsigned)nb, N), dim3(256), 0, (hipStream_t)stream, t, W, w_bstride, x, P, C, J, m);
     RICK_LAUNCH_STATUS();
+}
+
+extern "C" int rick_thin_bwdx_f32(const float *t, const float *W, int64_t w_bstride, float *x, int N, int64_t P, int C,
+                                  int J, void *stream) {
+    const ThinMod none = {nullptr, 1.f, nullptr};
+    return thin_bwdx_launch(t, W, w_bstride, x, N, P, C, J, none, stream);
+}
+
+extern "C" int rick_torgb_bwdx_f32(const float *g, const float *w, const float *s, float wscale, float *gx, int N, int64_t P,
+                                   int C, int J, void *stream) {
+    if (!s || (((uintptr_t)s | (uintptr_t)w) & 15)) return RICK_EINVAL;
+    const ThinMod m = {s, wscale, nullptr};
+    return thin_bwdx_launch(g, w, 0, gx, N, P, C, J, m, stream);
 }
 
 // G[n,j,c] = sum_p t[n,j,p] * x[n,p,c];  partials [blk][n][j][c]

@@ -152,7 +152,7 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
 
-    def forward(self, x, style, tail=None, s=None, d=None):
+    def forward(self, x, style, tail=None, s=None, d=None, rgb_tail=None):
         """tail = (bias, noise, noise_weight, negative_slope, gain): apply StyledConv's NoiseInjection + FusedLeakyReLU
         as part of this layer (fused into the blur launch of the upsampling variant; first-order mode only).
         s = modulation(style) (and d, the demodulation coefficients) when the Generator has already evaluated them for
@@ -161,8 +161,15 @@ class ModulatedConv2d(nn.Module):
             s = self.modulation(style)                               # [B, Ci]
         w = self.weight[0]                                           # [Co, Ci, k, k]
         if self.kernel_size == 1 and self.out_channel <= 4 and not self.demodulate:
+            if rgb_tail is not None and not op.second_order_enabled():
+                # ToRGB: weight modulation, bias and the skip addition inside the one launch (first-order steps)
+                return op.torgb(x, w.view(self.out_channel, self.in_channel), s, rgb_tail[0], rgb_tail[1], self.scale)
             Wn = (self.scale * w.view(1, self.out_channel, self.in_channel)) * s.unsqueeze(1)   # [B, 3, Ci]
-            return op.thin_fwd(x, Wn)                                # planar [B, 3, H, W]
+            out = op.thin_fwd(x, Wn)                                 # planar [B, 3, H, W]
+            if rgb_tail is not None:
+                out = out + rgb_tail[0]
+                out = out + rgb_tail[1] if rgb_tail[1] is not None else out
+            return out
         key = (self.weight, 'mod')
         if self.downsample:
             # blur -> stride-2 modulated conv (model_probe_tune.py:270-276), composed from the twice-differentiable
@@ -238,10 +245,8 @@ class ToRGB(nn.Module):
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
     def forward(self, x, style, skip=None, s=None):
-        out = self.conv(x, style, s=s) + self.bias
-        if skip is not None:
-            out = out + self.upsample(skip)
-        return out
+        # out = conv(x, style) + bias; out = out + upsample(skip)   (model_probe_tune.py:366-370)
+        return self.conv(x, style, s=s, rgb_tail=(self.bias, self.upsample(skip) if skip is not None else None))
 
 
 class _Mapping(nn.Sequential):

@@ -201,6 +201,58 @@ class _ThinWgrad(Function):
         return gt, gx
 
 
+class _ToRGB(Function):
+    """rgb = ToRGB's modulated 1x1 conv + bias (+ upsampled skip) in ONE launch (model_probe_tune.py:246-248, 366-370):
+    the per-sample weight (scale * w) * s is formed inside the kernel.  First-order autograd; the data gradient is one
+    launch too, the weight / style / bias gradients (the training steps never need them: the optimiser owns no ToRGB
+    parameter, train_dynamic_update_prune.py:908-917) are composed from thin_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, bias, add, wscale):
+        xc = _nhwc(x)
+        n, c, h, wd = _thin_shapes(xc, w.shape[0])
+        J = w.shape[0]
+        wc, sc = w.contiguous(), s.contiguous()
+        bc = bias.reshape(-1).contiguous() if bias is not None else None
+        ac = add.contiguous() if add is not None else None
+        if sc.shape != (n, c) or wc.shape != (J, c) or (ac is not None and ac.shape != (n, J, h, wd)):
+            raise RuntimeError('torgb: shape mismatch')
+        t = torch.empty((n, J, h, wd), device=x.device, dtype=x.dtype)
+        check(lib.rick_torgb_fwd_f32(ptr(xc), ptr(wc), ptr(sc), wscale, ptr(bc), ptr(ac), ptr(t), n, h * wd, c, J, stream_ptr()),
+              'rick_torgb_fwd_f32')
+        ctx.save_for_backward(x, w, s)
+        ctx.wscale, ctx.bias_shape = wscale, (bias.shape if bias is not None else None)
+        return t
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, w, s = ctx.saved_tensors
+        g = g.contiguous()
+        n, J, h, wd = g.shape
+        c = w.shape[1]
+        gx = gw = gs = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((n, c, h, wd), device=g.device, dtype=g.dtype, memory_format=torch.channels_last)
+            check(lib.rick_torgb_bwdx_f32(ptr(g), ptr(w.contiguous()), ptr(s.contiguous()), ctx.wscale, ptr(gx), n, h * wd, c, J,
+                                          stream_ptr()), 'rick_torgb_bwdx_f32')
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            G = _ThinWgrad.apply(g, x)                                  # [n, J, c] = d loss / d W[n]
+            if ctx.needs_input_grad[1]:
+                gw = ctx.wscale * torch.einsum('njc,nc->jc', G, s)
+            if ctx.needs_input_grad[2]:
+                gs = torch.einsum('njc,jc->nc', G, ctx.wscale * w)
+        if ctx.bias_shape is not None and ctx.needs_input_grad[3]:
+            gb = g.sum((0, 2, 3)).view(ctx.bias_shape)
+        return gx, gw, gs, gb, (g if ctx.needs_input_grad[4] else None), None
+
+
+def torgb(x, w, s, bias=None, add=None, wscale=1.0):
+    """sum_c x[n,c,h,w] * (wscale * w[j,c]) * s[n,c] + bias[j] + add[n,j,h,w]  -> planar [N, J, H, W]."""
+    require_cuda_f32(x, w, s, bias, add)
+    return _ToRGB.apply(x, w, s, bias, add, float(wscale))
+
+
 def thin_fwd(x, W):
     require_cuda_f32(x, W)
     return _ThinFwd.apply(x, W)

@@ -654,3 +654,32 @@ def test_mapping_network_fast_path_equals_autograd_path():
         a, _ = g([z[:2]])
         b, _ = g([z[:2]])
     assert a.shape == (2, 3, 32, 32) and torch.isfinite(a).all() and not torch.equal(a, b)
+
+
+@pytest.mark.parametrize('B,C,H,skip', [(2, 512, 8, False), (4, 128, 64, True), (3, 40, 17, True)])
+def test_torgb_fused_equals_composed(B, C, H, skip):
+    """rick_torgb_{fwd,bwdx}_f32 (weight modulation + bias + skip addition inside the thin product's launch) vs the
+    composed ToRGB (per-sample weight tensor, thin_fwd, two adds: the path second-order autograd keeps): identical
+    values and data gradient, parameter / style gradients to rounding."""
+    from rick_amd import op
+    from rick_amd.models import ToRGB
+    torch.manual_seed(B + C + H)
+    m = ToRGB(C, 64, upsample=skip).to(DEV)
+    m.bias.data.normal_()
+    x = torch.randn(B, C, H, H, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    st = torch.randn(B, 64, device=DEV, requires_grad=True)
+    sk = torch.randn(B, 3, H // 2, H // 2, device=DEV, requires_grad=True) if skip and H % 2 == 0 else None
+    if skip and sk is None:
+        sk = torch.randn(B, 3, (H + 1) // 2, (H + 1) // 2, device=DEV, requires_grad=True)
+        x = torch.randn(B, C, 2 * sk.shape[2], 2 * sk.shape[2], device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ins = [x, st] + ([sk] if sk is not None else []) + [m.conv.weight, m.bias, m.conv.modulation.weight]
+    y1 = m(x, st, sk)
+    with op.second_order():
+        y2 = m(x, st, sk)
+    assert torch.equal(y1, y2)
+    g = torch.randn_like(y1)
+    g1 = torch.autograd.grad(y1, ins, g)
+    g2 = torch.autograd.grad(y2, ins, g)
+    assert torch.equal(g1[0], g2[0])
+    for a, b in zip(g1[1:], g2[1:]):
+        assert rel_err(a, b.double()) < 1e-5
