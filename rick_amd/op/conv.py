@@ -424,6 +424,36 @@ def grad_sink_enabled():
     return getattr(_tls, 'grad_sink', False)
 
 
+_param_grads_off = False     # process-wide on purpose: read by backward passes on the autograd engine's thread
+
+
+class no_param_grads:
+    """Around an ``autograd.grad(outputs, inputs=<activations / latents>, create_graph=True)`` call (the inner gradient of
+    the R1 and path-length terms, train_dynamic_update_prune.py:89-96, 104-118): the backward passes of the conv /
+    transposed-conv / fused-activation ops skip the gradients of operands that are leaf parameters (or views of one).
+    torch's own conv backward is told by the engine which outputs the call needs; a custom Function is not — its
+    ``needs_input_grad`` only mirrors ``requires_grad`` — so without this switch every conv layer runs a full weight-
+    gradient kernel whose result the inner call discards (a third of the weight-gradient time of a path-length step).
+    Gradients of non-leaf operands (anything that may depend on the differentiation inputs) are always produced."""
+
+    def __enter__(self):
+        global _param_grads_off
+        self.prev, _param_grads_off = _param_grads_off, True
+
+    def __exit__(self, *a):
+        global _param_grads_off
+        _param_grads_off = self.prev
+
+
+def param_like(t):
+    """Leaf tensor or a view of one (``Parameter[0]``, ``.view``) — evaluated in an op's forward."""
+    return t is not None and (t.is_leaf or (t._is_view() and t._base is not None and t._base.is_leaf))
+
+
+def skip_param_grad(is_param_like):
+    return _param_grads_off and is_param_like
+
+
 def _sink_target(key, shape, enabled):
     """The [O, I, kh, kw] view of the parameter's .grad a weight gradient may be added into, or None.  `enabled` is the
     switch as the op's forward saw it."""
@@ -478,6 +508,7 @@ class _Conv(Function):
             raise RuntimeError(f'conv: input has {x.shape[1]} channels, weight expects {I}')
         ctx.save_for_backward(x, w)
         ctx.cfg = (s, p, wscale, key)
+        ctx.w_param = param_like(w)
         return _conv_launch(x, _pack(w, wscale, key and (key[0], key[1] + '/conv')), O, kh, kw, s, p)
 
     @staticmethod
@@ -488,7 +519,7 @@ class _Conv(Function):
         if ctx.needs_input_grad[0]:
             gx = _ConvT.apply(g, w.transpose(0, 1), s, p, wscale, (x.shape[2], x.shape[3]),
                               key and (key[0], key[1] + '/T'))
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not skip_param_grad(ctx.w_param):
             gw = _WGrad.apply(g, x, w.shape[2], w.shape[3], s, p, wscale)
         return gx, gw, None, None, None, None
 
@@ -501,6 +532,7 @@ class _ConvT(Function):
             raise RuntimeError(f'convT: input has {x.shape[1]} channels, weight expects {I}')
         ctx.save_for_backward(x, w)
         ctx.cfg = (s, p, wscale, key)
+        ctx.w_param = param_like(w)
         return _convT_launch(x, _pack(w, wscale, key and (key[0], key[1] + '/convT')), O, kh, kw, s, p, out_hw)
 
     @staticmethod
@@ -510,7 +542,7 @@ class _ConvT(Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = _Conv.apply(g, w.transpose(0, 1), s, p, wscale, key and (key[0], key[1] + '/T'))
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not skip_param_grad(ctx.w_param):
             # wgrad(a = x [I ch], b = g [O ch]) -> [I, O, kh, kw]; transpose back to w's [O, I, ..]
             gw = _WGrad.apply(x, g, w.shape[2], w.shape[3], s, p, wscale).transpose(0, 1)
         return gx, gw, None, None, None, None, None

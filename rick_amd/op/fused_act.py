@@ -26,6 +26,16 @@ def grad_sink_enabled():
     return f()
 
 
+def param_like(t):
+    from .conv import param_like as f
+    return f(t)
+
+
+def skip_param_grad(flag):
+    from .conv import skip_param_grad as f
+    return f(flag)
+
+
 def _as_rows(x):
     """-> (tensor in [rows, C] memory order, rows, C, hw)."""
     if x.ndim == 2:
@@ -134,6 +144,7 @@ class _Act(Function):
         ctx.cfg = (slope, scale)
         ctx.need = (bias is not None, noise is not None)
         ctx.params = (bias, nw, grad_sink_enabled())      # the switch as the forward's thread sees it (op/conv.py)
+        ctx.param_like = (param_like(bias), param_like(nw))
         return y
 
     @staticmethod
@@ -141,7 +152,8 @@ class _Act(Function):
         y, noise = ctx.saved_tensors
         slope, scale = ctx.cfg
         bias, nw, sink = ctx.params
-        want_b, want_w = ctx.need[0] and ctx.needs_input_grad[1], ctx.need[1] and ctx.needs_input_grad[3]
+        want_b = ctx.need[0] and ctx.needs_input_grad[1] and not skip_param_grad(ctx.param_like[0])
+        want_w = ctx.need[1] and ctx.needs_input_grad[3] and not skip_param_grad(ctx.param_like[1])
         sink = sink and not torch.is_grad_enabled()       # a twice-differentiable backward keeps its gradients in the graph
         gx, gb, gw = _ActAdjoint.apply(g, y, noise, slope, scale, want_b, want_w,
                                        param_sink(bias, y.shape[1], sink and want_b), param_sink(nw, 1, sink and want_w))

@@ -33,7 +33,8 @@ def g_nonsaturating_loss(fake_pred):
 
 def d_r1_loss(real_pred, real_img):
     """train_dynamic_update_prune.py:89-96 (needs op.second_order())."""
-    (grad_real,) = autograd.grad(outputs=real_pred.sum(), inputs=real_img, create_graph=True)
+    with op.no_param_grads():      # the inner gradient is w.r.t. the image only: no weight-gradient launches for it
+        (grad_real,) = autograd.grad(outputs=real_pred.sum(), inputs=real_img, create_graph=True)
     return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
 
 
@@ -43,7 +44,8 @@ def g_path_regularize(fake_img, latents, mean_path_length, decay=0.01, noise=Non
     if noise is None:
         noise = torch.randn_like(fake_img)
     noise = noise / math.sqrt(fake_img.shape[2] * fake_img.shape[3])
-    (grad,) = autograd.grad(outputs=(fake_img * noise).sum(), inputs=latents, create_graph=True)
+    with op.no_param_grads():      # the inner gradient is w.r.t. the latents only
+        (grad,) = autograd.grad(outputs=(fake_img * noise).sum(), inputs=latents, create_graph=True)
     path_lengths = torch.sqrt(grad.pow(2).sum(2).mean(1))
     path_mean = mean_path_length + decay * (path_lengths.mean() - mean_path_length)
     path_penalty = (path_lengths - path_mean).pow(2).mean()
