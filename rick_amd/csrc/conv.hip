@@ -814,13 +814,14 @@ static void launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *
     // production path (bf16x3, vector loads), 3x3 layers with a full grid: the straight-line 9-tap k-loop.  Its
     // loop body carries 0.65 non-MFMA VALU + 0.2 SALU instructions per MFMA against 1.4 + 1.2 (stride 1) / 2.2 + 2.3
     // (stride 2) of the generic tap loop (SQ_INSTS_* counters, profiles/r02_pmc_conv.json): +3..8 % on the Ci >= 256
-    // stride-1 layers, +7 % at Ci = 128, +7..13 % on the stride-2 layers (tools/abl_u9.sh); slower on split-K launches.
+    // stride-1 layers, +7 % at Ci = 128, +7..13 % on the stride-2 layers (tools/abl_u9.sh).
     static const int no_unroll = ablation_env("RICK_IGEMM_NOUNROLL", 0);
     static const int u9_minchunks = ablation_env("RICK_U9_MINCHUNKS", 4), u9_s2 = ablation_env("RICK_U9_S2", 1);
+    static const int u9_split = ablation_env("RICK_U9_SPLIT", 4);    // split-K launches too when a split keeps >= 4 chunks (+5..13 %)
     const bool u9 = SPLIT == 2 && VEC && g->ntaps == 9 && !no_unroll && !t.debug && igemm_tile_positions(g) == CV_BN &&
-                    t.NPP <= IG_DEEP_NPP && t.nsplit == 1 && t.nchunks >= u9_minchunks;
+                    t.NPP <= IG_DEEP_NPP && (t.nsplit == 1 || (u9_split && t.cps >= u9_split)) && t.cps >= u9_minchunks;
     const bool u9s2 = SPLIT == 2 && VEC && g->ntaps == 9 && u9_s2 && igemm_tile_positions(g) == 64 && t.NPP <= 32 * IG_PMAX &&
-                      t.nsplit == 1 && t.nchunks >= u9_minchunks;
+                      (t.nsplit == 1 || (u9_split && t.cps >= u9_split)) && t.cps >= u9_minchunks;
     if (u9s2) launch_igemm_k<2, true, false, 2, 9>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
     else if (igemm_tile_positions(g) == 64) launch_igemm_k<SPLIT, VEC, false, 2>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
     else if (u9) launch_igemm_k<2, true, false, 4, 9>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
