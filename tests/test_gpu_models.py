@@ -505,3 +505,38 @@ def test_graph_replay_matches_eager_steps():
     for k in ('d', 'g', 'r1', 'path'):
         assert torch.equal(a.losses[k], b.losses[k])
     assert float(dict(b.d.named_parameters())['convs.2.skip.1.weight'][[0, 3]].abs().max()) == 0.0
+
+
+def test_lazy_graph_capture_through_iteration():
+    """enable_graphs() + iteration() with a warm-up length that is no multiple of the regulariser periods: step types are
+    captured lazily at different iterations, with eager steps of other types (which register new packed-weight requests)
+    in between.  The pack-descriptor table must stay valid for the graphs captured earlier: after the run the cached
+    packed weights must equal a fresh pack of the current parameters, and every state tensor must be finite."""
+    from rick_amd import op
+    from rick_amd.train import RickTrainer, TrainConfig
+    size, B = 32, 2
+    g, d = build(size)
+    cfg = TrainConfig(size=size, batch=B, warmup_iter=3, d_reg_every=5, g_reg_every=3, num_fisher_img=1)
+    tr = RickTrainer(cfg, g, d, *build(size))
+    tr.enable_graphs(True)
+    torch.manual_seed(0)
+    real = synth_reals(B, size=size, seed=5).to(DEV)
+    for i in range(20):
+        tr.iteration(i, real)
+    torch.cuda.synchronize()
+    assert set(tr._gs) == {'d', 'r1', 'g', 'plr'} and all('graphs' in v for v in tr._gs.values())
+    for flat in (tr.g_flat, tr.d_flat, tr.g_ema_flat):
+        assert torch.isfinite(flat.flat).all()
+    assert all(torch.isfinite(v).all() for v in tr.losses.values())
+    # cached packs (refreshed on the host side of the replays) vs packs made from scratch from the same parameters
+    z = torch.randn(B, 512, device=DEV)
+    noises = [getattr(g.noises, f'noise_{i}') for i in range(g.num_layers)]
+    with torch.no_grad():
+        for grp in tr._pack_groups:
+            grp.refresh()
+        img_cached, _ = g([z], noise=noises)
+        pred_cached, _ = d(img_cached)
+        op.bump_weights_epoch()                      # every cached pack is stale now: the next launches repack everything
+        img_fresh, _ = g([z], noise=noises)
+        pred_fresh, _ = d(img_fresh)
+    assert torch.equal(img_cached, img_fresh) and torch.equal(pred_cached, pred_fresh)
