@@ -139,9 +139,9 @@ def main():
     reals = [synth_reals(cfg.batch, cfg.size, seed=100 * rank + j).to(dev) for j in range(4)]
     # steady state: a Fisher sweep has run, masks are active (untimed; it recurs every fisher_freq iterations)
     mine = [j for j in range(cfg.num_fisher_img) if j % world == rank]
+    fisher_in = ([synth_latents(1, seed=500 + j).to(dev) for j in mine], [synth_reals(1, cfg.size, seed=600 + j).to(dev) for j in mine])
     if not args.no_fisher:
-        tr.fisher_sweep([synth_latents(1, seed=500 + j).to(dev) for j in mine],
-                        [synth_reals(1, cfg.size, seed=600 + j).to(dev) for j in mine], first=True)
+        tr.fisher_sweep(*fisher_in, first=True)
 
     i0 = cfg.warmup_iter + 1
     use_graphs = not args.no_graphs
@@ -153,6 +153,17 @@ def main():
             print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); issuing launches eagerly', file=sys.stderr)
             use_graphs = False
             tr.enable_graphs(False)
+
+    fisher_ms = None
+    if not args.no_fisher and use_graphs:
+        # the sweep itself (untimed in `value`: it recurs every fisher_freq = 50 iterations): once more to capture its
+        # per-sample graph, then timed.  Every rank runs it (its per-filter all-reduce must stay matched).
+        tr.fisher_sweep(*fisher_in, first=True)
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        tr.fisher_sweep(*fisher_in, first=True)
+        torch.cuda.synchronize()
+        fisher_ms = 1e3 * (time.perf_counter() - tf)
 
     def run(n, start):
         for k in range(n):
@@ -186,6 +197,12 @@ def main():
                    'global_batch': cfg.batch * world, 'parallelism': f'dp{world}', 'hip_graphs': use_graphs,
                    'first_iteration': i0 + args.warmup},
     }
+
+    if fisher_ms is not None:
+        out['fisher_sweep'] = {'ms': fisher_ms, 'samples_this_rank': len(mine), 'samples': cfg.num_fisher_img,
+                               'note': 'whole sweep (per-sample G/D forward + both gradients at batch 1 replayed from a captured '
+                                       'graph, grad^2 accumulate, per-filter reduce, percentile decisions, mask upload); not part '
+                                       'of `value`; the README recipe runs 5 samples every 50 iterations'}
 
     # ---- per-step-type times (untimed extra pass, every rank runs it so collectives stay matched): HIP events on the
     # launch stream after every step of 16 more iterations = one full R1 period (4 path-length steps, 1 R1 step)

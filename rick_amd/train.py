@@ -217,6 +217,10 @@ class FisherAccumulator:
         for v in self.acc.values():
             v.mul_(s)
 
+    def zero_(self):
+        for v in self.acc.values():
+            v.zero_()
+
 
 def filter_mean(t, filter_dim):
     """Mean over every dim except `filter_dim` with one wavefront per filter
@@ -310,20 +314,20 @@ def build_mask(flat, freeze_idx, zero_idx):
     """Flat uint8 mask for MaskedFlatAdam from per-key filter index sets: bit0 = freeze
     (grad := 0), bit1 = zero/prune (param := 0, grad := 0).  5-D generator conv weights are
     indexed on dim 1, everything else on dim 0 (train_dynamic_update_prune.py:524-537, 429-435)."""
-    mask = torch.zeros(flat.total, dtype=torch.uint8)
+    mask = np.zeros(flat.total, dtype=np.uint8)      # plain NumPy on the host: a few thousand contiguous filter rows
     for bit, table in ((1, freeze_idx), (2, zero_idx)):
         for name, idx in table.items():
             if name not in flat.index or len(idx) == 0:
                 continue
             lo, hi = flat.segment(name)
             p = flat.params[flat.index[name]]
-            view = mask[lo:hi].view(p.shape)
-            ii = torch.as_tensor(np.asarray(idx), dtype=torch.long)
+            view = mask[lo:hi].reshape(tuple(p.shape))
+            ii = np.asarray(idx, dtype=np.int64)
             if p.ndim == 5:
                 view[:, ii] |= bit
             else:
                 view[ii] |= bit
-    return mask.to(flat.flat.device)
+    return torch.from_numpy(mask).to(flat.flat.device)
 
 
 # --------------------------------------------------------------------------- trainer
@@ -367,8 +371,7 @@ class RickTrainer:
         self.device = next(generator.parameters()).device
         # packed conv weights: one refresh launch per network
         self._pack_groups = [op.register_pack_group(net) for net in (generator, discriminator)]
-        for net in (g_ema, d_ema):
-            op.register_pack_group(net)
+        self._ema_pack_groups = [op.register_pack_group(net) for net in (g_ema, d_ema)]
         self.g_flat = FlatParams(generator.named_parameters(), g_optim_filter)
         self.d_flat = FlatParams(discriminator.named_parameters(), d_optim_filter)
         self.g_ema_flat = FlatParams(g_ema.named_parameters())
@@ -388,6 +391,7 @@ class RickTrainer:
         self.use_graphs = False
         self.step_events = None     # list of (step name, event) while bench.py times step types
         self._gs, self._inject, self._layer_idx, self._real = {}, {}, None, None
+        self._fisher_state = None   # persistent accumulators / static inputs / captured per-sample graph of the Fisher sweep
         if dp is not None:
             dp.attach(self.g_flat, self.d_flat)
 
@@ -537,6 +541,7 @@ class RickTrainer:
         """Drop every captured step (after loading a checkpoint or changing optimiser hyper-parameters)."""
         for st in self._gs.values():
             st.pop('graphs', None)
+        self._fisher_state = None
 
     # ---- steps (each returns the loss tensor; no host sync)
     def d_step(self, real_img, noise, i=10 ** 9, g_noise=None, graph=False):
@@ -644,21 +649,58 @@ class RickTrainer:
         ema_flat(self.d_ema_flat, self.d_flat, self.cfg.ema_decay)
 
     # ---- Fisher sweep (:214-393)
+    def _fisher_sample(self, z, real, acc_g, acc_d, g_params, d_params, fixed_noise):
+        """One sample of the sweep (:225-263): G / D forward at batch 1, both losses, grad^2 added to the accumulators."""
+        fake, _ = self.g_ema([z.view(1, -1)], randomize_noise=not fixed_noise)
+        fake_pred, _ = self.d_ema(fake)
+        real_pred, _ = self.d_ema(real.view(1, 3, self.cfg.size, self.cfg.size))
+        g_loss = g_nonsaturating_loss(fake_pred)
+        d_loss = d_logistic_loss(real_pred, fake_pred)
+        acc_g.add(autograd.grad(g_loss, g_params, retain_graph=True, allow_unused=True))
+        acc_d.add(autograd.grad(d_loss, d_params, allow_unused=True))
+
     def fisher_sweep(self, latents, reals, first, fixed_noise=False):
-        """latents: list of [1,512] tensors for THIS rank's samples; reals: matching [1,3,H,W]."""
+        """latents: list of [1,512] tensors for THIS rank's samples; reals: matching [1,3,H,W].
+
+        A sample is ~1 500 batch-1 launches issued through Python autograd — host-bound (21.5 ms per sample measured, of
+        which the GPU works less than half).  With `use_graphs` the per-sample body is captured once (second sample of the
+        first sweep; the first runs eagerly so that every packed-weight request and descriptor table exists) and replayed
+        with the sample copied into static input buffers; the grad^2 accumulators are persistent tensors the captured
+        launches add into.  Same kernels on the same data as the eager loop."""
         cfg = self.cfg
         requires_grad(self.g_ema, True)
         requires_grad(self.d_ema, True)
         g_named, d_named = list(self.g_ema.named_parameters()), list(self.d_ema.named_parameters())
-        acc_g, acc_d = FisherAccumulator(g_named), FisherAccumulator(d_named)
+        g_params, d_params = [p for _, p in g_named], [p for _, p in d_named]
+        st = self._fisher_state
+        if st is None or st['fixed_noise'] != fixed_noise:
+            st = self._fisher_state = {'fixed_noise': fixed_noise, 'acc': (FisherAccumulator(g_named), FisherAccumulator(d_named)),
+                                       'z': torch.empty(1, cfg.latent, device=self.device),
+                                       'real': torch.empty(1, 3, cfg.size, cfg.size, device=self.device), 'runs': 0, 'graph': None}
+        acc_g, acc_d = st['acc']
+        acc_g.zero_()
+        acc_d.zero_()
         for z, real in zip(latents, reals):
-            fake, _ = self.g_ema([z.view(1, -1)], randomize_noise=not fixed_noise)
-            fake_pred, _ = self.d_ema(fake)
-            real_pred, _ = self.d_ema(real.view(1, 3, cfg.size, cfg.size))
-            g_loss = g_nonsaturating_loss(fake_pred)
-            d_loss = d_logistic_loss(real_pred, fake_pred)
-            acc_g.add(autograd.grad(g_loss, [p for _, p in g_named], retain_graph=True, allow_unused=True))
-            acc_d.add(autograd.grad(d_loss, [p for _, p in d_named], allow_unused=True))
+            if not self.use_graphs:
+                self._fisher_sample(z, real, acc_g, acc_d, g_params, d_params, fixed_noise)
+                continue
+            st['z'].copy_(z.view(1, -1))
+            st['real'].copy_(real.view(1, 3, cfg.size, cfg.size))
+            if st['graph'] is None and st['runs'] >= 1:
+                for grp in self._ema_pack_groups:
+                    grp.refresh()
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._fisher_sample(st['z'], st['real'], acc_g, acc_d, g_params, d_params, fixed_noise)
+                st['graph'] = graph
+            if st['graph'] is not None:
+                for grp in self._ema_pack_groups:         # the EMA weights move every iteration: repack on the host side
+                    grp.refresh()
+                st['graph'].replay()
+            else:
+                self._fisher_sample(st['z'], st['real'], acc_g, acc_d, g_params, d_params, fixed_noise)
+            st['runs'] += 1
         scale = 1.0 / (cfg.num_fisher_img * cfg.batch)                 # :266-269
         acc_g.scale_(scale)
         acc_d.scale_(scale)

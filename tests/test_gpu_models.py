@@ -540,3 +540,39 @@ def test_lazy_graph_capture_through_iteration():
         img_fresh, _ = g([z], noise=noises)
         pred_fresh, _ = d(img_fresh)
     assert torch.equal(img_cached, img_fresh) and torch.equal(pred_cached, pred_fresh)
+
+
+def test_fisher_sweep_graph_replay_equals_eager():
+    """With use_graphs the per-sample body of the Fisher sweep is captured once and replayed from static input buffers
+    into persistent grad^2 accumulators: the accumulated Fisher information, the decisions and the masks equal the eager
+    sweep's exactly — also for a second sweep after the weights have moved (pack refresh on the host side)."""
+    from rick_amd.train import RickTrainer, TrainConfig
+    size, n = 32, 4
+    zs = [synth_tensor(f'fg/z/{j}', (1, 512)).to(DEV) for j in range(n)]
+    rs = [synth_reals(1, size=size, seed=90 + j).to(DEV) for j in range(n)]
+
+    def run(use_graphs):
+        g, d = build(size)
+        tr = RickTrainer(TrainConfig(size=size, batch=2, warmup_iter=0, num_fisher_img=n, prune_quantile=1.0), g, d, *build(size))
+        tr.enable_graphs(use_graphs)
+        out = []
+        for sweep in range(2):
+            acc_g, acc_d = tr.fisher_sweep(zs, rs, first=(sweep == 0), fixed_noise=True)
+            out.append(({k: v.clone() for k, v in acc_g.acc.items()}, {k: v.clone() for k, v in acc_d.acc.items()},
+                        tr.g_optim.mask.clone(), tr.d_optim.mask.clone()))
+            with torch.no_grad():                              # move the EMA weights like an iteration would
+                tr.g_ema_flat.flat.mul_(1.01)
+                tr.d_ema_flat.flat.mul_(0.99)
+            from rick_amd import op
+            op.bump_weights_epoch(tr.g_ema_flat.params)
+            op.bump_weights_epoch(tr.d_ema_flat.params)
+        if use_graphs:
+            assert tr._fisher_state['graph'] is not None
+        return out
+    a, b = run(False), run(True)
+    for (ga, da, mga, mda), (gb, db, mgb, mdb) in zip(a, b):
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
+        for k in da:
+            assert torch.equal(da[k], db[k]), k
+        assert torch.equal(mga, mgb) and torch.equal(mda, mdb)
