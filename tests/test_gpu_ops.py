@@ -683,3 +683,23 @@ def test_torgb_fused_equals_composed(B, C, H, skip):
     assert torch.equal(g1[0], g2[0])
     for a, b in zip(g1[1:], g2[1:]):
         assert rel_err(a, b.double()) < 1e-5
+
+
+@pytest.mark.parametrize('O,I,k', [(512, 512, 3), (128, 256, 3), (24, 16, 3), (130, 70, 3), (256, 128, 1), (40, 24, 1)])
+def test_group_pack_equals_single_pack(O, I, k):
+    """rick_conv_pack_weights_multi (one launch per network; source read through LDS in its own memory order) writes
+    the same bytes as the per-weight pack kernel — for the parameter's own layout, its transposed view (data-gradient
+    operand) and ragged channel counts."""
+    from rick_amd.op import conv as cv
+    torch.manual_seed(O + I + k)
+    lin = torch.nn.Linear(1, 1)                      # a module to hang the parameter on (PackGroup is per network)
+    lin.w = torch.nn.Parameter(torch.randn(O, I, k, k, device=DEV))
+    grp = cv.register_pack_group(lin)
+    for view, tag in ((lin.w, 'a'), (lin.w.transpose(0, 1), 'b')):
+        first = cv._pack(view, 0.37, (lin.w, tag)).clone()      # registration packs this one with the single kernel
+        lin.w.data.mul_(1.5)
+        cv.bump_weights_epoch([lin.w])
+        assert grp.refresh()                                     # group launch over every registered request
+        multi = cv._pack(view, 0.37, (lin.w, tag)).clone()
+        single = cv._pack(view, 0.37, None)
+        assert torch.equal(multi, single) and not torch.equal(multi, first)
