@@ -252,7 +252,7 @@ __device__ __forceinline__ void cv_lds_barrier() {   // raw barrier: no vmcnt(0)
     asm volatile("" ::: "memory");
 }
 
-template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, bool WDMA = false>
+template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, int WDMA = 0>
 __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const unsigned char *__restrict__ wpk,
                                            float *__restrict__ out, const float *__restrict__ iscale,
                                            const float *__restrict__ oscale, float *__restrict__ ws,
@@ -260,7 +260,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                                            const rick_conv_epilogue &epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *wbuf = smem;                               // [2][16 KB]
-    unsigned char *ph = smem + (WDMA ? 3 : 2) * CV_WSTEP_BYTES;   // [NPP + 1][64 B]  (WDMA: a ring of 3 weight tiles)
+    unsigned char *ph = smem + (WDMA == 3 ? 3 : 2) * CV_WSTEP_BYTES;   // [NPP + 1][64 B]  (WDMA = 3: a ring of 3 weight tiles)
     unsigned char *pl = ph + (t.NPP + 1) * 64;                // (+1: spare row for out-of-patch items)
     unsigned *ptab = reinterpret_cast<unsigned *>(pl + (t.NPP + 1) * 64);             // [NPP]
     float *sct = reinterpret_cast<float *>(ptab + ((t.NPP + 3) & ~3));                // [nbe][cps * 32] input scales
@@ -435,9 +435,12 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             pq[K] = load4<VEC>(ok ? xt + p_rel[K] + chunk * CV_CK : (VEC ? g_zero_page : x), ok, chunk * CV_CK + c4 * 4, g.Ci);
         };
         // WDMA: the packed weight tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write
-        // pass) into a ring of three slots, the tile of k-step ks + 2 is issued right behind the barrier that opens
-        // k-step ks and stays in flight across the next barrier (counted s_waitcnt vmcnt, raw s_barrier).
-        static_assert(!WDMA || (NT % 3 == 0 && SPLIT == 2), "ring slot = tap % 3");
+        // pass).  WDMA = 3: a ring of three slots, the tile of k-step ks + 2 is issued right behind the barrier that
+        // opens k-step ks and stays in flight across the next barrier (counted s_waitcnt vmcnt, raw s_barrier).
+        // WDMA = 2 (stride-2 form, whose 37 KB patch leaves no room for a third slot at two blocks per CU): the two
+        // existing slots, tile ks + 1 issued behind the barrier of k-step ks.
+        static_assert(WDMA == 0 || WDMA == 2 || (WDMA == 3 && NT % 3 == 0), "ring slot = tap % 3");
+        static_assert(WDMA == 0 || SPLIT == 2, "the DMA copies whole hi + lo tiles");
         const int wave = threadIdx.x >> 6;
         auto issue_wdma = [&](int wchunk, int wtap, int slot) {
             const unsigned char *src = wbase + ((int64_t)wchunk * g.nslices + g.wt[wtap]) * CV_WSTEP_BYTES;
@@ -447,9 +450,9 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 __builtin_amdgcn_global_load_lds((cv_gbl_u8 *)(src + (q * 256 + threadIdx.x) * 16),
                                                  (cv_lds_u8 *)(dst + (q * 256 + wave * 64) * 16), 16, 0, 0);
         };
-        if constexpr (WDMA) {
+        if constexpr (WDMA != 0) {
             issue_wdma(c_begin, 0, 0);
-            issue_wdma(c_begin, 1, 1);
+            if constexpr (WDMA == 3) issue_wdma(c_begin, 1, 1);
             issue_patch(c_begin, S0{});
             commit_patch(c_begin, S0{});          // (first use of the patch registers: hipcc drains the VM counter here)
         } else {
@@ -468,7 +471,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             const int par = ((chunk - c_begin) * NT) & 1;
             auto kstep = [&](auto TC) {
                 constexpr int tap = decltype(TC)::value;
-                if constexpr (WDMA) {
+                if constexpr (WDMA == 3) {
                     // tile `tap` was issued two k-steps ago; behind it in the VM queue: that k-step's patch items, the 4
                     // DMA instructions of tile tap + 1 and the previous k-step's patch items
                     constexpr int t1 = (tap + NT - 1) % NT, t2 = (tap + NT - 2) % NT;
@@ -478,6 +481,14 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                     cv_lds_barrier();                 // all pieces of tile `tap` landed; slot (tap + 2) % 3 has no reader left
                     const int wchunk = tap + 2 < NT ? chunk : cnext, wtap = tap + 2 < NT ? tap + 2 : tap + 2 - NT;
                     issue_wdma(wchunk, wtap, (tap + 2) % 3);
+                } else if constexpr (WDMA == 2) {
+                    // tile `tap` was issued one k-step ago; behind it: that k-step's patch items
+                    constexpr int t1 = (tap + NT - 1) % NT;
+                    constexpr int p1 = PSET - t1 * IPT < 0 ? 0 : (PSET - t1 * IPT < IPT ? PSET - t1 * IPT : IPT);
+                    cv_wait_vm<p1>();
+                    cv_lds_barrier();                 // tile `tap` landed; the other slot (read in the previous k-step) is free
+                    const int wchunk = tap + 1 < NT ? chunk : cnext, wtap = tap + 1 < NT ? tap + 1 : 0;
+                    issue_wdma(wchunk, wtap, (par + tap + 1) & 1);
                 } else {   // weights of the next k-step -> registers
                     const int wchunk = tap + 1 < NT ? chunk : cnext, wtap = tap + 1 < NT ? tap + 1 : 0;
                     const uint4 *src = reinterpret_cast<const uint4 *>(
@@ -497,7 +508,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                     static_for<0, 8>(rest);
                 }
                 {
-                    const unsigned char *wb = wbuf + (WDMA ? tap % 3 : (par + tap) & 1) * CV_WSTEP_BYTES;
+                    const unsigned char *wb = wbuf + (WDMA == 3 ? tap % 3 : (par + tap) & 1) * CV_WSTEP_BYTES;
                     const int toff = (g.dy[tap] - t.dymin) * t.PW + (g.dx[tap] - t.dxmin);
                     bf16x8 ahi[4], alo[4], bhi[NJ], blo[NJ];
 #pragma unroll
@@ -523,7 +534,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
                         }
                 }
-                if constexpr (WDMA) {
+                if constexpr (WDMA != 0) {
                     if constexpr (tap == NT - 1) {   // chunk boundary: all waves are done with the patch
                         cv_lds_barrier();
                         commit_patch(cnext, S0{});
@@ -710,7 +721,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     else epilogue(std::false_type{}, std::false_type{});
 }
 
-template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, bool WDMA = false>
+template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, int WDMA = 0>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restrict__ x,
                                                             const unsigned char *__restrict__ wpk,
                                                             float *__restrict__ out, const float *__restrict__ iscale,
@@ -847,13 +858,13 @@ extern "C" int64_t rick_conv_igemm_workspace_bytes(const rick_conv_geom *g) {
     return t.nsplit > 1 ? (int64_t)t.nsplit * g->N * g->GH * g->GW * g->Co * 4 : 0;
 }
 
-template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT = 0, bool WDMA = false>
+template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT = 0, int WDMA = 0>
 static void launch_igemm_k(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
                            const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
                            const ConvTiling &t, const rick_conv_epilogue &epi) {
     (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT, WDMA>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT, WDMA>), dim3(nwg), dim3(256), lds + (WDMA ? CV_WSTEP_BYTES : 0), st,
+    hipLaunchKernelGGL((conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT, WDMA>), dim3(nwg), dim3(256), lds + (WDMA == 3 ? CV_WSTEP_BYTES : 0), st,
                        x, wp, out, iscale, oscale, ws, *g, t, epi);
 }
 
@@ -872,11 +883,14 @@ static void launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *
                     t.NPP <= IG_DEEP_NPP && (t.nsplit == 1 || (u9_split && t.cps >= u9_split)) && t.cps >= u9_minchunks;
     const bool u9s2 = SPLIT == 2 && VEC && g->ntaps == 9 && u9_s2 && igemm_tile_positions(g) == 64 && t.NPP <= 32 * IG_PMAX &&
                       (t.nsplit == 1 || (u9_split && t.cps >= u9_split)) && t.cps >= u9_minchunks;
-    if (u9s2) launch_igemm_k<2, true, false, 2, 9>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
+    // (stride 2: a k-step has half the MFMAs per weight tile, so the register-staged weight store weighed twice as much:
+    // +11..17 % with the tiles by LDS-DMA into the two existing slots)
+    if (u9s2 && ablation_env("RICK_WDMA2", 1)) launch_igemm_k<2, true, false, 2, 9, 2>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
+    else if (u9s2) launch_igemm_k<2, true, false, 2, 9>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
     else if (igemm_tile_positions(g) == 64) launch_igemm_k<SPLIT, VEC, false, 2>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
     // weights by LDS-DMA into a 3-slot ring (+3..5 % on the Ci >= 256 layers; keeps two blocks per CU)
     else if (u9 && ablation_env("RICK_WDMA", 1) && lds + CV_WSTEP_BYTES <= 80 * 1024)
-        launch_igemm_k<2, true, false, 4, 9, true>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
+        launch_igemm_k<2, true, false, 4, 9, 3>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
     else if (u9) launch_igemm_k<2, true, false, 4, 9>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
     else if (t.NPP <= IG_DEEP_NPP) launch_igemm_k<SPLIT, VEC, true, 4>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
     else launch_igemm_k<SPLIT, VEC, false, 4>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
