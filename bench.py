@@ -12,7 +12,7 @@ random-init (torch.manual_seed(1); the FFHQ checkpoint is a download), reals are
 batches already resident in HBM.  value = global batch * K / max-over-ranks wall time.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel (conv_igemm_kernel, bf16x3 MFMA): algorithmic FLOPs / time,
+  roofline      the dominant kernel (conv_igemm_kernel, fp16x3 MFMA): algorithmic FLOPs / time,
                 timed per launch with HIP events on the launch stream in an instrumented repeat of
                 the same steps (the timed region itself carries no events)
   cpu_baseline  the CPU oracle (port of the reference's CPU formulation) timed on this box's host
@@ -92,7 +92,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--batch', type=int, default=4, help='per-GPU batch (BASELINE configs[1])')
     ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
+    ap.add_argument('--precision', default='fp16x3', choices=['fp16x3', 'fp16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-step-times', action='store_true')
@@ -190,7 +190,7 @@ def main():
         'metric': 'G+D train-step images/sec @256px', 'value': cfg.batch * world * args.steps / elapsed,
         'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32 (bf16x3 split MFMA, fp32 accumulate)' if args.precision == 'bf16x3' else 'bf16',
+        'vs_baseline': None, 'dtype': 'f32 (fp16x3 split MFMA, fp32 accumulate)' if args.precision == 'fp16x3' else 'f16',
         'data': 'synthetic',
         'config': {'workload': f'FFHQ-256 StyleGAN2 G+D RICK iteration (D step, R1/16, G step, PLR/4, EMA, masks on), '
                                f'batch {cfg.batch}/GPU, {cfg.size}px, channel_multiplier 2, random-init weights',
@@ -257,7 +257,7 @@ def main():
                       file=sys.stderr)
         ig = agg.get('igemm', [0.0, 1.0, 1])
         ach = ig[0] / ig[1] / 1e12
-        mult = 3.0 if args.precision == 'bf16x3' else 1.0
+        mult = 3.0 if args.precision == 'fp16x3' else 1.0
         out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel', 'achieved': ach,
                            'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 'traffic': load_traffic(),
@@ -266,7 +266,7 @@ def main():
                            'algorithmic_gflop_per_launch': ig[0] / max(ig[2], 1) / 1e9,
                            'note': 'achieved = algorithmic FLOPs (2*N*OH*OW*Co*Ci*taps) / event-timed duration over '
                                    '16 instrumented iterations (forward, data-gradient and transposed launches of the '
-                                   'igemm family incl. their split-K second stage); bf16x3 issues 3 MFMA FLOPs per '
+                                   'igemm family incl. their split-K second stage); fp16x3 issues 3 MFMA FLOPs per '
                                    'algorithmic FLOP; traffic = HBM bytes per launch from profiles/r02_pmc_traffic.json'}
         if 'wgrad' in agg:
             wg = agg['wgrad']

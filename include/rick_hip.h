@@ -78,9 +78,11 @@ int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx, float *gb
  * Convolution family (replaces the F.conv2d / F.conv_transpose2d calls of
  * model_probe_tune.py:122,265,274,280 and their autograd).  One implicit-GEMM MFMA kernel,
  * parameterised by a tap table, covers 3x3/1x1, stride 1/2, transposed stride 2, and the
- * data-gradient of each.  fp32 in HBM; operands are split into bf16 hi + bf16 lo on the
- * way into LDS and multiplied as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with
- * fp32 accumulation (split = 2), or hi*hi only (split = 1).
+ * data-gradient of each.  fp32 in HBM; on the way into LDS an operand is multiplied by a
+ * power of two (chosen per block from a sample of the block's own data, per packed tensor for
+ * the weights) and split into fp16 hi + fp16 lo; the products hi*hi + hi*lo + lo*hi run on
+ * v_mfma_f32_16x16x32_f16 with fp32 accumulation (split = 2: 2^-22 relative per product) or
+ * hi*hi only (split = 1); the exponents are removed again in the epilogue (exact).
  *
  * Geometry: activations NHWC.  The launch covers a grid of GH x GW "positions" per image;
  * position (gy, gx) writes output pixel (gy*os + oy0, gx*os + ox0) of [N, OH, OW, Co] and
@@ -98,14 +100,16 @@ typedef struct {
     int ntaps;              /* taps used by this launch */
     int nslices;            /* tap slices in the packed weight / in gw (wt[t] < nslices) */
     int dy[RICK_MAX_TAPS], dx[RICK_MAX_TAPS], wt[RICK_MAX_TAPS];
-    int split;              /* 1 = bf16, 2 = bf16x3 (fp32-grade) */
+    int split;              /* 1 = fp16, 2 = fp16x3 (fp32-grade) */
     float alpha;
 } rick_conv_geom;
 
-/* Packed-weight buffer size in bytes for `nslices` tap slices of a [Co, Ci] matrix. */
+/* Packed-weight buffer size in bytes for `nslices` tap slices of a [Co, Ci] matrix (tiles + a 64-byte
+ * trailer that holds the tensor's pack exponent). */
 int64_t rick_conv_packed_bytes(int Co, int Ci, int nslices);
 /* Pack W (element (co, ci, slice s) at w[co*s_co + ci*s_ci + s*s_t]) * scale into the MFMA
- * A-operand LDS image (bf16 hi/lo, swizzled, zero padded to 128 x 32 tiles). */
+ * A-operand LDS image (fp16 hi/lo of W * scale * 2^e, swizzled, zero padded to 128 x 32 tiles; e from a
+ * device-side sample of the tensor, stored in the trailer).  Two launches, no host synchronisation. */
 int rick_conv_pack_weight(const float *w, int64_t s_co, int64_t s_ci, int64_t s_t,
                           int Co, int Ci, int nslices, float scale, int split, void *packed, void *stream);
 /* The same packing for MANY weights in one launch (every convolution of a network after an optimiser step;

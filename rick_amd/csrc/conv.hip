@@ -1,4 +1,4 @@
-// Implicit-GEMM convolution family on gfx950 MFMA (v_mfma_f32_16x16x32_bf16).
+// Implicit-GEMM convolution family on gfx950 MFMA (v_mfma_f32_16x16x32_f16).
 //
 // One kernel covers every convolution of the StyleGAN2 G/D hot path and its data gradient
 // (model_probe_tune.py:122,265,274,280): the host describes a launch as a grid of output
@@ -6,19 +6,20 @@
 //
 // GEMM view per block:  D[128 co][128 positions] += W[128 co][K] * X[K][128 positions],
 // K = (32-channel chunk, tap).  fp32 activations are read from HBM ONCE per block and chunk
-// as a spatial patch (tile + halo), converted to bf16 hi/lo on the way into LDS and re-used
-// by all taps (9x re-use for 3x3), so neither im2col traffic nor the fp32->bf16x2 split is
+// as a spatial patch (tile + halo), converted to fp16 hi/lo on the way into LDS and re-used
+// by all taps (9x re-use for 3x3), so neither im2col traffic nor the fp32->fp16x2 split is
 // paid per tap.  Weights are pre-packed (rick_conv_pack_weight) into the exact swizzled LDS
 // image of the A operand, so staging them is a linear 16-byte copy.
 //
-// Precision: split=2 multiplies hi*hi + hi*lo + lo*hi with fp32 accumulation (~2^-16
-// relative per product, fp32-grade for the 1e-3 parity bar); split=1 is plain bf16.
+// Precision: split=2 multiplies hi*hi + hi*lo + lo*hi with fp32 accumulation, operands scaled by a per-block
+// power of two so that the fp16 range is centred on the block's data (conv_common.h: ~2^-22 relative per
+// product, 64x finer than a bf16 hi/lo split at the same three MFMAs); split=1 is plain fp16.
 //
 // Wave tiling: 256 threads = 4 waves in 2(co) x 2(pos); each wave owns 64 co x 64 positions
 // = 4x4 MFMA tiles (16 accumulators of 4 VGPRs).  Output rows (co) land 4-consecutive per
 // lane, so NHWC stores are float4.
 //
-// LDS bank conflicts: both operands are [row][32 k] bf16 (64 B rows) read as ds_read_b128 per
+// LDS bank conflicts: both operands are [row][32 k] fp16 (64 B rows) read as ds_read_b128 per
 // lane (row = lane&15, k-group = lane>>4).  16-byte slot index is XOR-swizzled with bit 2 of
 // the row: slot = kg ^ (((row>>2)&1)<<1)  -> conflict-free for 16 consecutive rows at any
 // offset (checked by simulation against the gfx950 ds_read_b128 lane groups).
@@ -27,16 +28,66 @@
 
 // ------------------------------------------------------------------------------------------
 // Weight packing.  Packed layout: block (cotile, chunk, slice) at
-//   ((cotile * nchunks + chunk) * nslices + slice) * 16 KB : [hi 128x32 bf16][lo 128x32 bf16],
-//   element (row r, k) at byte r*64 + cv_swz(k>>3, r)*16 + (k&7)*2.
-extern "C" int64_t rick_conv_packed_bytes(int Co, int Ci, int nslices) {
+//   ((cotile * nchunks + chunk) * nslices + slice) * 16 KB : [hi 128x32 fp16][lo 128x32 fp16],
+//   element (row r, k) at byte r*64 + cv_swz(k>>3, r)*16 + (k&7)*2,
+// followed by a 64-byte trailer {float unscale = 2^-e, float scale = 2^e}: the tensor is packed as (w * scale) * 2^e
+// with e from a sample of the tensor (cv_pow2_scale), and every kernel that multiplies with the packed image folds
+// `unscale` into its output factor.  "Weights" are not always O(1) parameters: the second-order terms (R1, path length)
+// run gradients through the A operand, so the exponent is taken from the data, on the device, per pack.
+__host__ __device__ static inline int64_t packed_tile_bytes(int Co, int Ci, int nslices) {
     return (int64_t)cdiv(Co, CV_BM) * cdiv(Ci, CV_CK) * nslices * CV_WSTEP_BYTES;
+}
+extern "C" int64_t rick_conv_packed_bytes(int Co, int Ci, int nslices) {
+    return packed_tile_bytes(Co, Ci, nslices) + CV_WTRAILER_BYTES;
+}
+
+#define PK_SAMPLES 32    // per thread: up to 8192 strided samples of the tensor
+
+// One block: sampled amax of (w * scale) -> {2^-e, 2^e} into the trailer.
+__device__ __forceinline__ void pack_exponent(const float *__restrict__ w, int64_t s_co, int64_t s_ci, int64_t s_t, int Co,
+                                              int Ci, int nslices, float scale, float *__restrict__ trailer) {
+    __shared__ float red[4];
+    const int64_t total = (int64_t)Co * Ci * nslices;
+    int64_t stride = total / (PK_SAMPLES * 256);
+    if (stride < 1) stride = 1;
+    stride |= 1;                                    // odd: walks every tap slice and channel residue
+    float m = 0.f;
+    for (int j = 0; j < PK_SAMPLES; j++) {
+        const int64_t i = ((int64_t)j * 256 + threadIdx.x) * stride;
+        if (i < total) {
+            const int sl = (int)(i % nslices);
+            const int64_t r = i / nslices;
+            const int ci = (int)(r % Ci), co = (int)(r / Ci);
+            m = fmaxf(m, fabsf(w[co * s_co + ci * s_ci + sl * s_t] * scale));
+        }
+    }
+    m = block_amax(m, red);
+    if (threadIdx.x == 0) {
+        float sc, un;
+        cv_pow2_scale(m, sc, un);
+        trailer[0] = un;
+        trailer[1] = sc;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_exponent_kernel(const float *__restrict__ w, int64_t s_co, int64_t s_ci,
+                                                            int64_t s_t, int Co, int Ci, int nslices, float scale,
+                                                            float *__restrict__ trailer) {
+    pack_exponent(w, s_co, s_ci, s_t, Co, Ci, nslices, scale, trailer);
+}
+
+__global__ __launch_bounds__(256) void pack_exponent_multi_kernel(const rick_pack_desc *__restrict__ descs) {
+    const rick_pack_desc ds = descs[blockIdx.x];
+    pack_exponent(ds.w, ds.s_co, ds.s_ci, ds.s_t, ds.Co, ds.Ci, ds.nslices, ds.scale,
+                  reinterpret_cast<float *>((unsigned char *)ds.packed + packed_tile_bytes(ds.Co, ds.Ci, ds.nslices)));
 }
 
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, int64_t s_co, int64_t s_ci,
                                                           int64_t s_t, int Co, int Ci, int nslices, float scale,
-                                                          unsigned short *__restrict__ packed, int64_t total, int split) {
+                                                          unsigned short *__restrict__ packed, int64_t total, int split,
+                                                          const float *__restrict__ trailer) {
     const int nchunks = (Ci + CV_CK - 1) / CV_CK;
+    const float pscale = trailer[1];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int k = (int)(i & 31);
         const int r = (int)((i >> 5) & 127);
@@ -47,15 +98,9 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
         const int cot = (int)(blk / nchunks);
         const int co = cot * CV_BM + r, ci = chunk * CV_CK + k;
         float v = 0.f;
-        if (co < Co && ci < Ci) v = w[co * s_co + ci * s_ci + slice * s_t] * scale;
+        if (co < Co && ci < Ci) v = w[co * s_co + ci * s_ci + slice * s_t] * scale * pscale;
         unsigned short h, l;
-        if (split == 1) {
-            h = f32_to_bf16_rne(v);
-            l = 0;
-        } else {
-            h = (unsigned short)(__float_as_uint(v) >> 16);
-            l = f32_to_bf16_rne(v - bf16_to_f32(h));
-        }
+        split1(v, h, l, split);
         const int64_t base = (i >> 12) * (CV_WSTEP_BYTES / 2);
         const int off = r * 32 + cv_swz(k >> 3, r) * 8 + (k & 7);
         packed[base + off] = h;
@@ -67,10 +112,13 @@ extern "C" int rick_conv_pack_weight(const float *w, int64_t s_co, int64_t s_ci,
                                      int nslices, float scale, int split, void *packed, void *stream) {
     if (!w || !packed || Co <= 0 || Ci <= 0 || nslices <= 0 || (split != 1 && split != 2)) return RICK_EINVAL;
     const int64_t total = (int64_t)cdiv(Co, CV_BM) * cdiv(Ci, CV_CK) * nslices * CV_BM * CV_CK;
+    float *trailer = reinterpret_cast<float *>((unsigned char *)packed + packed_tile_bytes(Co, Ci, nslices));
     int64_t nb = cdiv64(total, 256);
     if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(pack_exponent_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w, s_co, s_ci, s_t, Co, Ci, nslices,
+                       scale, trailer);
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, s_co, s_ci, s_t, Co,
-                       Ci, nslices, scale, (unsigned short *)packed, total, split);
+                       Ci, nslices, scale, (unsigned short *)packed, total, split, (const float *)trailer);
     RICK_LAUNCH_STATUS();
 }
 
@@ -83,6 +131,8 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const rick_pack_
         if ((int)blockIdx.x >= descs[i].blk_begin) d = i;
     const rick_pack_desc ds = descs[d];
     const int nchunks = (ds.Ci + CV_CK - 1) / CV_CK;
+    const float pscale =
+        reinterpret_cast<const float *>((const unsigned char *)ds.packed + packed_tile_bytes(ds.Co, ds.Ci, ds.nslices))[1];
     const int i = ((int)blockIdx.x - ds.blk_begin) * 256 + threadIdx.x;   // over (cotile, chunk, r, k)
     const int k = i & 31, r = (i >> 5) & 127, tile = i >> 12;
     const int chunk = tile % nchunks, cot = tile / nchunks;
@@ -92,16 +142,10 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const rick_pack_
     unsigned short *dst = (unsigned short *)ds.packed + (int64_t)tile * ds.nslices * (CV_WSTEP_BYTES / 2) +
                           r * 32 + cv_swz(k >> 3, r) * 8 + (k & 7);
     for (int sl = 0; sl < ds.nslices; sl++) {
-        float v = src[sl * ds.s_t] * ds.scale;
+        float v = src[sl * ds.s_t] * ds.scale * pscale;
         if (!ok) v = 0.f;
         unsigned short h, l;
-        if (split == 1) {
-            h = f32_to_bf16_rne(v);
-            l = 0;
-        } else {
-            h = (unsigned short)(__float_as_uint(v) >> 16);
-            l = f32_to_bf16_rne(v - bf16_to_f32(h));
-        }
+        split1(v, h, l, split);
         dst[(int64_t)sl * (CV_WSTEP_BYTES / 2)] = h;
         dst[(int64_t)sl * (CV_WSTEP_BYTES / 2) + CV_WTILE_BYTES / 2] = l;
     }
@@ -112,6 +156,7 @@ extern "C" int rick_conv_pack_blocks(int Co, int Ci) { return cdiv(Co, CV_BM) * 
 extern "C" int rick_conv_pack_weights_multi(const rick_pack_desc *descs_device, int n, int total_blocks, int split,
                                             void *stream) {
     if (!descs_device || n < 1 || total_blocks < 1 || (split != 1 && split != 2)) return RICK_EINVAL;
+    hipLaunchKernelGGL(pack_exponent_multi_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, descs_device);
     hipLaunchKernelGGL(pack_weight_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
                        descs_device, n, split);
     RICK_LAUNCH_STATUS();
@@ -279,13 +324,46 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     const int tn_i = pt / t.nty;
     const int gx0 = tx_i << t.tw_log2, gy0 = ty_i << t.th_log2, n0 = tn_i * t.nbe;
     const int iy0 = gy0 * g.is + t.dymin, ix0 = gx0 * g.is + t.dxmin;
-    // per-(image, input channel) scales of this block's images and channel range (1 when the conv has none):
-    // read from HBM once, then applied from LDS while the patch is converted — no global-load round trip
-    // and no branch per patch item
     const int cspan = t.cps * CV_CK;
+    __syncthreads();   // patch table complete
+
+    // ---- operand exponent of this block (conv_common.h): amax over a sample of the block's own patch — 8 items per
+    // thread spread over its channel chunks and patch pixels (8192 values, with the input scale applied) -> x * 2^e.
+    float xscale, xunscale;
+    {
+        const int c4s = threadIdx.x & 7;
+        const int ncl = c_end - c_begin;
+        float m = 0.f;
+#pragma unroll
+        for (int sidx = 0; sidx < 8; sidx++) {
+            const int pix = (threadIdx.x >> 3) + 32 * ((sidx * 5 + 1) % (DEEP || (NT > 0 && NJ == 4) ? IG_PSET_DEEP : IG_PMAX));
+            const int chunk = c_begin + (sidx * ncl) / 8;
+            const int ci = chunk * CV_CK + c4s * 4;
+            bool ok = pix < t.NPP && ci < g.Ci;
+            int n = 0, iy = 0, ix = 0;
+            if (ok) {
+                const unsigned e = ptab[pix];
+                n = n0 + (int)(e >> 20);
+                iy = iy0 + (int)((e >> 10) & 1023);
+                ix = ix0 + (int)(e & 1023);
+                ok = n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+            }
+            float4 v = load4<VEC>(ok ? x + (((int64_t)n * g.IH + iy) * g.IW + ix) * g.Ci + ci : (VEC ? g_zero_page : x), ok, ci, g.Ci);
+            if (iscale) v = mul4(v, load4<VEC>(ok ? iscale + (int64_t)n * g.Ci + ci : (VEC ? g_zero_page : iscale), ok, ci, g.Ci));
+            m = amax4(m, v);
+        }
+        m = block_amax(m, reinterpret_cast<float *>(wbuf));
+        cv_pow2_scale(m, xscale, xunscale);
+        xscale = cv_uniform(xscale);
+    }
+    // packed-weight exponent (trailer of the packed image)
+    const float wunscale = *reinterpret_cast<const float *>(wpk + (int64_t)t.ncot * t.nchunks * g.nslices * CV_WSTEP_BYTES);
+    const float unscale = cv_uniform(xunscale * wunscale);
+    // per-(image, input channel) scales of this block's images and channel range, times 2^e: read from HBM once, then
+    // applied from LDS while the patch is converted — no global-load round trip and no branch per patch item
     for (int i = threadIdx.x; i < t.nbe * cspan; i += 256) {
         const int nbi = i / cspan, c = c_begin * CV_CK + (i - nbi * cspan);
-        sct[i] = !iscale ? 1.f : (n0 + nbi < g.N && c < g.Ci) ? iscale[(int64_t)(n0 + nbi) * g.Ci + c] : 0.f;
+        sct[i] = !iscale ? xscale : (n0 + nbi < g.N && c < g.Ci) ? iscale[(int64_t)(n0 + nbi) * g.Ci + c] * xscale : 0.f;
     }
     __syncthreads();
 
@@ -356,19 +434,25 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     };
     auto commit_patch = [&](int chunk, auto SET) {
         constexpr int S = decltype(SET)::value;
+        // input scale x block exponent.  ONE block-uniform branch around the whole item loop (two straight-line copies):
+        // layers without an input scale multiply by the exponent from an SGPR and read no table.  With vector loads an
+        // out-of-range item has read the zero page and needs no select.
+        auto items = [&](auto ISC) {
 #pragma unroll
-        for (int k = 0; k < PSET; k++) {
-            const bool ok = (cur_ok[S] >> k) & 1u;
-            float4 v = pq[S * PSET + k];
-            // (block-uniform branch around VALU work only) layers without an input scale skip the multiply; with vector
-            // loads an out-of-range item has read the zero page and needs no select
-            if (iscale) v = mul4(v, *reinterpret_cast<const float4 *>(sct + p_sc[k] + (chunk - c_begin) * CV_CK));
-            if (!VEC && !ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            uint2 hi, lo;
-            split4<SPLIT>(v, hi, lo);
-            *reinterpret_cast<uint2 *>(ph + p_lds[k]) = hi;
-            if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds[k]) = lo;
-        }
+            for (int k = 0; k < PSET; k++) {
+                const bool ok = (cur_ok[S] >> k) & 1u;
+                float4 v = pq[S * PSET + k];
+                if constexpr (decltype(ISC)::value) v = mul4(v, *reinterpret_cast<const float4 *>(sct + p_sc[k] + (chunk - c_begin) * CV_CK));
+                else v = scale4(v, xscale);
+                if (!VEC && !ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                uint2 hi, lo;
+                split4<SPLIT>(v, hi, lo);
+                *reinterpret_cast<uint2 *>(ph + p_lds[k]) = hi;
+                if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds[k]) = lo;
+            }
+        };
+        if (iscale) items(std::true_type{});
+        else items(std::false_type{});
         if (!DEEP) {
             // patches larger than IG_PMAX*32 pixels (stride-2 geometry): remaining items, synchronously
             for (int it = threadIdx.x + 256 * PSET; it < p_items; it += 256) {
@@ -510,28 +594,28 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 {
                     const unsigned char *wb = wbuf + (WDMA == 3 ? tap % 3 : (par + tap) & 1) * CV_WSTEP_BYTES;
                     const int toff = (g.dy[tap] - t.dymin) * t.PW + (g.dx[tap] - t.dxmin);
-                    bf16x8 ahi[4], alo[4], bhi[NJ], blo[NJ];
+                    f16x8 ahi[4], alo[4], bhi[NJ], blo[NJ];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        ahi[i] = *reinterpret_cast<const bf16x8 *>(wb + a_off[i]);
-                        if (SPLIT == 2) alo[i] = *reinterpret_cast<const bf16x8 *>(wb + CV_WTILE_BYTES + a_off[i]);
+                        ahi[i] = *reinterpret_cast<const f16x8 *>(wb + a_off[i]);
+                        if (SPLIT == 2) alo[i] = *reinterpret_cast<const f16x8 *>(wb + CV_WTILE_BYTES + a_off[i]);
                     }
 #pragma unroll
                     for (int j = 0; j < NJ; j++) {
                         const int pp = pb[j] + toff;
                         const int off = pp * 64 + cv_swz(kg, pp) * 16;
-                        bhi[j] = *reinterpret_cast<const bf16x8 *>(ph + off);
-                        if (SPLIT == 2) blo[j] = *reinterpret_cast<const bf16x8 *>(pl + off);
+                        bhi[j] = *reinterpret_cast<const f16x8 *>(ph + off);
+                        if (SPLIT == 2) blo[j] = *reinterpret_cast<const f16x8 *>(pl + off);
                     }
 #pragma unroll
                     for (int i = 0; i < 4; i++)
 #pragma unroll
                         for (int j = 0; j < NJ; j++) {
                             if (SPLIT == 2) {
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
                             }
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
                         }
                 }
                 if constexpr (WDMA != 0) {
@@ -584,28 +668,28 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             if (!(t.debug & 1)) {
                 const unsigned char *wb = wbuf + (ks & 1) * CV_WSTEP_BYTES;
                 const int toff = (g.dy[tap] - t.dymin) * t.PW + (g.dx[tap] - t.dxmin);
-                bf16x8 ahi[4], alo[4], bhi[NJ], blo[NJ];
+                f16x8 ahi[4], alo[4], bhi[NJ], blo[NJ];
     #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    ahi[i] = *reinterpret_cast<const bf16x8 *>(wb + a_off[i]);
-                    if (SPLIT == 2) alo[i] = *reinterpret_cast<const bf16x8 *>(wb + CV_WTILE_BYTES + a_off[i]);
+                    ahi[i] = *reinterpret_cast<const f16x8 *>(wb + a_off[i]);
+                    if (SPLIT == 2) alo[i] = *reinterpret_cast<const f16x8 *>(wb + CV_WTILE_BYTES + a_off[i]);
                 }
     #pragma unroll
                 for (int j = 0; j < NJ; j++) {
                     const int pp = pb[j] + toff;
                     const int off = pp * 64 + cv_swz(kg, pp) * 16;
-                    bhi[j] = *reinterpret_cast<const bf16x8 *>(ph + off);
-                    if (SPLIT == 2) blo[j] = *reinterpret_cast<const bf16x8 *>(pl + off);
+                    bhi[j] = *reinterpret_cast<const f16x8 *>(ph + off);
+                    if (SPLIT == 2) blo[j] = *reinterpret_cast<const f16x8 *>(pl + off);
                 }
     #pragma unroll
                 for (int i = 0; i < 4; i++)
     #pragma unroll
                     for (int j = 0; j < NJ; j++) {
                         if (SPLIT == 2) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
                         }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
                     }
             }
             if (more) {
@@ -626,6 +710,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     // ---- epilogue.  Instantiated twice (with / without output scales) so the scale loads of a j-column
     // are unconditional in their variant: hipcc otherwise sinks each into its own branch + vmcnt(0).
     const bool covec = (g.Co & 3) == 0;
+    const float oalpha = g.alpha * unscale;   // exact: the exponents are powers of two
     const float nwv = epi.noise ? epi.noise_w[0] : 0.f;
     auto epilogue = [&](auto HAS_OS, auto HAS_EP) {
         constexpr bool OS = decltype(HAS_OS)::value;
@@ -642,14 +727,15 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 for (int i = 0; i < 4; i++) {
                     const int co = cot * CV_BM + wm * 64 + i * 16 + kg * 4;
                     if (co >= g.Co) continue;
+                    // (partial sums leave the block without its operand exponents: blocks of one output tile may differ)
                     if (covec) {
                         *reinterpret_cast<float4 *>(wrow + co) =
-                            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                            make_float4(acc[i][j][0] * unscale, acc[i][j][1] * unscale, acc[i][j][2] * unscale, acc[i][j][3] * unscale);
                     } else {
-                        wrow[co] = acc[i][j][0];
-                        if (co + 1 < g.Co) wrow[co + 1] = acc[i][j][1];
-                        if (co + 2 < g.Co) wrow[co + 2] = acc[i][j][2];
-                        if (co + 3 < g.Co) wrow[co + 3] = acc[i][j][3];
+                        wrow[co] = acc[i][j][0] * unscale;
+                        if (co + 1 < g.Co) wrow[co + 1] = acc[i][j][1] * unscale;
+                        if (co + 2 < g.Co) wrow[co + 2] = acc[i][j][2] * unscale;
+                        if (co + 3 < g.Co) wrow[co + 3] = acc[i][j][3] * unscale;
                     }
                 }
                 continue;
@@ -661,10 +747,10 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int co = cot * CV_BM + wm * 64 + i * 16 + kg * 4;
-                    sc[i] = make_float4(g.alpha, g.alpha, g.alpha, g.alpha);
+                    sc[i] = make_float4(oalpha, oalpha, oalpha, oalpha);
                     if (OS) {
                         const float4 o = *reinterpret_cast<const float4 *>(oscale + (int64_t)n * g.Co + (co < g.Co ? co : 0));
-                        sc[i] = make_float4(o.x * g.alpha, o.y * g.alpha, o.z * g.alpha, o.w * g.alpha);
+                        sc[i] = make_float4(o.x * oalpha, o.y * oalpha, o.z * oalpha, o.w * oalpha);
                     }
                 }
                 float nv = 0.f;
@@ -699,7 +785,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             for (int i = 0; i < 4; i++) {
                 const int co = cot * CV_BM + wm * 64 + i * 16 + kg * 4;
                 if (co >= g.Co) continue;
-                f32x4 v = acc[i][j] * g.alpha;
+                f32x4 v = acc[i][j] * oalpha;
                 if (OS) {
                     const float *sp = oscale + (int64_t)n * g.Co + co;
                     v[0] *= sp[0];
@@ -872,7 +958,7 @@ template <int SPLIT, bool VEC>
 static void launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
                          const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
                          const ConvTiling &t, const rick_conv_epilogue &epi) {
-    // production path (bf16x3, vector loads), 3x3 layers with a full grid: the straight-line 9-tap k-loop.  Its
+    // production path (fp16x3, vector loads), 3x3 layers with a full grid: the straight-line 9-tap k-loop.  Its
     // loop body carries 0.65 non-MFMA VALU + 0.2 SALU instructions per MFMA against 1.4 + 1.2 (stride 1) / 2.2 + 2.3
     // (stride 2) of the generic tap loop (SQ_INSTS_* counters, profiles/r02_pmc_conv.json): +3..8 % on the Ci >= 256
     // stride-1 layers, +7 % at Ci = 128, +7..13 % on the stride-2 layers (tools/abl_u9.sh).
@@ -1030,18 +1116,21 @@ extern "C" int rick_conv_igemm_multi_f32(const float *x, const void *packed_w, f
 // K = positions (64 per tile, two 32-deep MFMA k-steps), split-K over position tiles.
 // Both operands are k-strided in NHWC memory (k = position), so they are staged row-major
 // [position][channel] and consumed through ds_read_b64_tr_b16 transposing reads.
-//   gy image : [64 pos][128 co] bf16, 256 B rows, 32-byte granules XOR-swizzled with
+//   gy image : [64 pos][128 co] fp16, 256 B rows, 32-byte granules XOR-swizzled with
 //              key(r) = ((r>>3)&1)*4 + (r&3)  (conflict-free for the 8 rows a half-wave reads)
 //   x  patch : same image as the igemm kernel ([pixel][32 ci], cv_swz slots)
 #define WG_TILE 64
 #define WG_GY_BYTES (WG_TILE * CV_BM * 2)   // 16 KB (one of hi / lo)
 
-typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
-__device__ __forceinline__ bf16x8 tr_read2(const unsigned char *base, int off0, int off1) {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_ptr)(base + off0));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_ptr)(base + off1));
-    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+__device__ __forceinline__ f16x8 tr_read2(const unsigned char *base, int off0, int off1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + off0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + off1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 r = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(f16x8, r);
 }
 
 __device__ __forceinline__ int wg_key(int r) { return (((r >> 3) & 1) << 2) + (r & 3); }
@@ -1049,11 +1138,11 @@ __device__ __forceinline__ int wg_key(int r) { return (((r >> 3) & 1) << 2) + (r
 // FAST (pipelined form; the host selects it for layers whose position grid is an exact multiple of the tile and whose
 // channel counts fill the 128 x 32 block — every 3x3 / 1x1 convolution of both networks at >= 8x8): staging is stripped to
 // what such a layer needs.  gy items are always valid (one unconditional load, no mask bookkeeping); x items test two
-// unsigned compares (halo of the padding) and read the zero page when outside; conversion is the bf16 split plus, for
+// unsigned compares (halo of the padding) and read the zero page when outside; conversion is the fp16 split plus, for
 // the modulated layers only, the scale multiply — no zero-select.  ~15 / ~22 instructions per item instead of ~30.  The
 // kernel is bound by the ISSUE of exactly these instructions (one wave per SIMD, 2-3 of them per MFMA, and an MFMA
 // leaves room for ~2), not by the matrix pipe: measured +20...27 % (280 -> 330-345 TFLOP/s on the 64^2...256^2 layers).
-template <int NT, int SPLIT, bool VEC, int PMAX, bool PIPE, bool FAST = false>
+template <int NT, int SPLIT, bool VEC, int PMAX, bool PIPE, int FAST = 0>   // FAST: 1 = no per-channel scales, 2 = with
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                          float *__restrict__ ws, const float *__restrict__ ascale,
                                                          const float *__restrict__ bscale, const rick_conv_geom g,
@@ -1155,8 +1244,64 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         }
     }
 
+    // ---- operand exponents of this block (conv_common.h): amax of gy * ascale and of x * bscale over 4 of the block's
+    // position tiles x 2 staging items each (4096 values per operand), then 2^e is folded into the LDS scale tables.
+    float punscale;   // 2^-(e_gy + e_x): applied to the partial tile on its way to the workspace
+    float xsa, xsb;   // 2^e_gy, 2^e_x (SGPRs: the multiplier of layers without per-channel scales)
+    {
+        float ma = 0.f, mb = 0.f;
+        const int nt = tile_end - tile_begin;
+#pragma unroll
+        for (int sidx = 0; sidx < 4; sidx++) {
+            int pt = tile_begin + (sidx * nt) / 4;
+            const int tx_i = pt % t.ntx;
+            pt /= t.ntx;
+            const int ty_i = pt % t.nty;
+            const int tn_i = pt / t.nty;
+            const int gx0 = tx_i << t.tw_log2, gy0 = ty_i << t.th_log2, n0 = tn_i * t.nbe;
+            const int iy0 = gy0 * g.is + t.dymin, ix0 = gx0 * g.is + t.dxmin;
+            const float *gbase = gy + (((int64_t)n0 * g.OH + gy0 * g.os + g.oy0) * g.OW + gx0 * g.os + g.ox0) * g.Co + gco;
+            const float *xbase = x + (((int64_t)n0 * g.IH + iy0) * g.IW + ix0) * g.Ci + pci;
+            const int nrem = g.N - n0, yrem = g.GH - gy0, xrem = g.GW - gx0;
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                {
+                    const int k = (2 * sidx + 5 * kk + 1) & 7;
+                    const unsigned e = g_pyx[k];
+                    const int nbi = (int)(e >> 20), py = (int)((e >> 10) & 1023), px = (int)(e & 1023);
+                    const bool ok = nt > 0 && e != 0xffffffffu && nbi < nrem && py < yrem && px < xrem;
+                    float4 v = load4<VEC>(ok ? gbase + g_rel[k] : (VEC ? g_zero_page : gy), ok, gco, g.Co);
+                    v = mul4(v, *reinterpret_cast<const float4 *>(sA + (ok ? (n0 + nbi) * CV_BM : 0) + gc4 * 4));
+                    if (ok) ma = amax4(ma, v);
+                }
+                {
+                    const int k = (3 * sidx + 7 * kk + 2) % PMAX;
+                    const unsigned e = p_pyx[k];
+                    const int nbi = (int)(e >> 20), iy = iy0 + (int)((e >> 10) & 1023), ix = ix0 + (int)(e & 1023);
+                    const bool ok = nt > 0 && e != 0xffffffffu && nbi < nrem && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+                    float4 v = load4<VEC>(ok ? xbase + p_rel[k] : (VEC ? g_zero_page : x), ok, pci, g.Ci);
+                    v = mul4(v, *reinterpret_cast<const float4 *>(sB + (ok ? (n0 + nbi) * CV_CK : 0) + pc4 * 4));
+                    if (ok) mb = amax4(mb, v);
+                }
+            }
+        }
+        float *red = reinterpret_cast<float *>(smem);      // (operand buffers are not in use yet)
+        ma = block_amax(ma, red);
+        mb = block_amax(mb, red + 8);
+        float sa, ua, sb, ub;
+        cv_pow2_scale(ma, sa, ua);
+        cv_pow2_scale(mb, sb, ub);
+        punscale = cv_uniform(ua * ub);
+        xsa = cv_uniform(sa);
+        xsb = cv_uniform(sb);
+        __syncthreads();                                    // every thread has read `red`
+        for (int i = threadIdx.x; i < g.N * CV_BM; i += 256) sA[i] *= sa;
+        for (int i = threadIdx.x; i < g.N * CV_CK; i += 256) sB[i] *= sb;
+        __syncthreads();
+    }
+
     // load_tile only ISSUES raw 16-byte loads (safe address for out-of-range items) and records a validity
-    // bitmask; every consumer of the loaded registers (scale, zero-select, bf16 split) lives in store_tile,
+    // bitmask; every consumer of the loaded registers (scale, zero-select, fp16 split) lives in store_tile,
     // which runs after the MFMA phase of the previous tile — so the loads stay in flight behind the MFMAs.
     unsigned okmask = 0;
     int st_n0 = 0;
@@ -1227,7 +1372,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             if (t.debug & 1) continue;
     #pragma unroll
             for (int kk = 0; kk < 2; kk++) {
-                bf16x8 ahi[4], alo[4];
+                f16x8 ahi[4], alo[4];
     #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int cb = (wm * 64 + i * 16 + p * 4) * 2;
@@ -1243,16 +1388,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                         const int pp0 = pbase[kk][0] + toff, pp1 = pbase[kk][1] + toff;
                         const int o0 = pp0 * 64 + cv_swz(b_kg, pp0) * 16 + b_sub;
                         const int o1 = pp1 * 64 + cv_swz(b_kg, pp1) * 16 + b_sub;
-                        const bf16x8 bhi = tr_read2(ph, o0, o1);
-                        bf16x8 blo;
+                        const f16x8 bhi = tr_read2(ph, o0, o1);
+                        f16x8 blo;
                         if (SPLIT == 2) blo = tr_read2(pl, o0, o1);
     #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             if (SPLIT == 2) {
-                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi, acc[i][tt], 0, 0, 0);
-                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo, acc[i][tt], 0, 0, 0);
+                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[i], bhi, acc[i][tt], 0, 0, 0);
+                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], blo, acc[i][tt], 0, 0, 0);
                             }
-                            acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi, acc[i][tt], 0, 0, 0);
+                            acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], bhi, acc[i][tt], 0, 0, 0);
                         }
                     }
                 }
@@ -1272,7 +1417,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         // a tile inside ONE image (every layer >= 8x8) has one gy / x scale vector per thread: kept in registers,
         // fetched from the LDS table once per tile instead of once per staged item
         const bool one_img = t.nbe == 1;
-        const bool scaled = ascale != nullptr || bscale != nullptr;
         float4 sa_cv = make_float4(1.f, 1.f, 1.f, 1.f), sb_cv = sa_cv;
         auto set_tile = [&](int tile) {
             int pt = tile;
@@ -1316,7 +1460,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                 pq[P] = load4<VEC>(ok ? xbase + p_rel[P] : x, ok, pci, g.Ci);
             }
         };
-        auto convert_item = [&](auto KC, unsigned char *buf, auto ONE) {   // raw register K -> scaled bf16 hi/lo in `buf`
+        auto convert_item = [&](auto KC, unsigned char *buf, auto ONE) {   // raw register K -> scaled fp16 hi/lo in `buf`
             constexpr int K = decltype(KC)::value;
             constexpr bool ONE_IMG = decltype(ONE)::value;
             const bool ok = (mask_cv >> K) & 1u;
@@ -1324,19 +1468,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                 uint2 hi, lo;
                 if constexpr (K < 8) {
                     float4 v = gq[K];
-                    if (scaled) {     // block-uniform: modulated layers (G) carry per-(image, channel) scales
+                    if constexpr (FAST == 2) {     // modulated layers (G) carry per-(image, channel) scales (x block exponent)
                         if constexpr (ONE_IMG) v = mul4(v, sa_cv);
                         else v = mul4(v, *reinterpret_cast<const float4 *>(sA + (cv_n0 + (int)(g_pyx[K] >> 20)) * CV_BM + gc4 * 4));
-                    }
+                    } else v = scale4(v, xsa);   // block exponent from an SGPR
                     split4<SPLIT>(v, hi, lo);
                     *reinterpret_cast<uint2 *>(buf + g_lds[K]) = hi;
                     *reinterpret_cast<uint2 *>(buf + WG_GY_BYTES + g_lds[K]) = lo;
                 } else {
                     float4 v = pq[K - 8];
-                    if (scaled) {     // (an out-of-range item read the zero page: 0 * scale stays 0)
+                    if constexpr (FAST == 2) {     // (an out-of-range item read the zero page: 0 * scale stays 0)
                         if constexpr (ONE_IMG) v = mul4(v, sb_cv);
                         else v = mul4(v, *reinterpret_cast<const float4 *>(sB + (cv_n0 + (int)((p_pyx[K - 8] >> 20) & 15)) * CV_CK + pc4 * 4));
-                    }
+                    } else v = scale4(v, xsb);
                     split4<SPLIT>(v, hi, lo);
                     *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + p_lds[K - 8]) = hi;
                     *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + (t.NPP + 1) * 64 + p_lds[K - 8]) = lo;
@@ -1408,7 +1552,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                 // (never consumed).  With straight-line VMEM traffic hipcc's waitcnt pass keeps exact counts
                 // (vmcnt(NITEM-1) per converted register); any branch here makes it fall back to vmcnt(0) per slot.
                 set_tile(tile + 2 < tile_end ? tile + 2 : tile_end - 1);
-                bf16x8 ahi[4], alo[4];
+                f16x8 ahi[4], alo[4];
                 for_slots([&](auto SC) {
                     constexpr int S = decltype(SC)::value, kk = S / NT, tt = S % NT;
                     if constexpr (tt == 0) {
@@ -1429,16 +1573,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                         const int pp0 = pbase[kk][0] + toff, pp1 = pbase[kk][1] + toff;
                         const int o0 = pp0 * 64 + cv_swz(b_kg, pp0) * 16 + b_sub;
                         const int o1 = pp1 * 64 + cv_swz(b_kg, pp1) * 16 + b_sub;
-                        const bf16x8 bhi = tr_read2(bph, o0, o1);
-                        bf16x8 blo;
+                        const f16x8 bhi = tr_read2(bph, o0, o1);
+                        f16x8 blo;
                         if (SPLIT == 2) blo = tr_read2(bpl, o0, o1);
     #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             if (SPLIT == 2) {
-                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi, acc[i][tt], 0, 0, 0);
-                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo, acc[i][tt], 0, 0, 0);
+                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[i], bhi, acc[i][tt], 0, 0, 0);
+                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], blo, acc[i][tt], 0, 0, 0);
                             }
-                            acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi, acc[i][tt], 0, 0, 0);
+                            acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], bhi, acc[i][tt], 0, 0, 0);
                         }
                     }
                 });
@@ -1460,7 +1604,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                 const int co = wm * 64 + i * 16 + G * 4;
                 const int ci = wn * 16 + (lane & 15);
                 *reinterpret_cast<float4 *>(wsb + (tt * CV_CK + ci) * CV_BM + co) =
-                    make_float4(acc[i][tt][0], acc[i][tt][1], acc[i][tt][2], acc[i][tt][3]);
+                    make_float4(acc[i][tt][0] * punscale, acc[i][tt][1] * punscale, acc[i][tt][2] * punscale, acc[i][tt][3] * punscale);
             }
         }
     }
@@ -1520,7 +1664,7 @@ extern "C" int64_t rick_conv_wgrad_workspace_bytes(const rick_conv_geom *g) {
     return (int64_t)nsplit * t.ncot * t.nchunks * g->ntaps * CV_BM * CV_CK * 4;
 }
 
-template <int NT, int SPLIT, bool VEC, int PMAX, bool PIPE, bool FAST = false>
+template <int NT, int SPLIT, bool VEC, int PMAX, bool PIPE, int FAST = 0>
 static void launch_wgrad_k(const float *x, const float *gy, float *ws, const float *ascale, const float *bscale,
                            const rick_conv_geom *g, const ConvTiling &t, int nsplit, int tps, size_t lds, hipStream_t st) {
     const unsigned nwg = (unsigned)(nsplit * t.ncot * t.nchunks);
@@ -1534,7 +1678,7 @@ static size_t wgrad_lds_bytes(const rick_conv_geom *g, const ConvTiling &t, bool
     const size_t buf = 2 * WG_GY_BYTES + 2 * (size_t)(t.NPP + 1) * 64;
     return (pipe ? 2 : 1) * buf + (size_t)((t.NPP + 3) & ~3) * 4 + (size_t)g->N * (CV_BM + CV_CK) * 4;
 }
-// The software-pipelined form needs two operand buffers in LDS; production path only (bf16x3, vector loads).
+// The software-pipelined form needs two operand buffers in LDS; production path only (fp16x3, vector loads).
 static bool wgrad_use_pipe(const rick_conv_geom *g, const ConvTiling &t) {
     static const int off = ablation_env("RICK_WGRAD_NOPIPE", 0);
     return !off && g->split == 2 && ((g->Ci | g->Co) & 3) == 0 && wgrad_lds_bytes(g, t, true) <= 160 * 1024;
@@ -1547,13 +1691,17 @@ static void launch_wgrad(const float *x, const float *gy, float *ws, const float
     const bool small = t.NPP <= 4 * 32;
     const bool pipe = wgrad_use_pipe(g, t);
     const size_t lds = wgrad_lds_bytes(g, t, pipe);
-    if (g->split == 1 && vec) launch_wgrad_k<NT, 1, true, 12, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
-    else if (!vec) launch_wgrad_k<NT, 2, false, 12, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
-    // FAST: no operand scales, position grid an exact multiple of the tile, full 128 x 32 channel blocks
+    // FAST: position grid an exact multiple of the tile, full 128 x 32 channel blocks
     const bool fast = pipe && !(g->Co % CV_BM) && !(g->Ci % CV_CK) && !(g->GH & ((1 << t.th_log2) - 1)) &&
                       !(g->GW & ((1 << t.tw_log2) - 1)) && !(g->N % t.nbe) && (t.nb == t.nbe);
-    if (fast && small) launch_wgrad_k<NT, 2, true, 4, true, true>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
-    else if (fast) launch_wgrad_k<NT, 2, true, 12, true, true>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    const bool scaled = ascale != nullptr || bscale != nullptr;
+    // ONE chain: exactly one kernel per call
+    if (g->split == 1 && vec) launch_wgrad_k<NT, 1, true, 12, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (!vec) launch_wgrad_k<NT, 2, false, 12, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (fast && small && scaled) launch_wgrad_k<NT, 2, true, 4, true, 2>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (fast && small) launch_wgrad_k<NT, 2, true, 4, true, 1>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (fast && scaled) launch_wgrad_k<NT, 2, true, 12, true, 2>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (fast) launch_wgrad_k<NT, 2, true, 12, true, 1>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
     else if (small && pipe) launch_wgrad_k<NT, 2, true, 4, true>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
     else if (small) launch_wgrad_k<NT, 2, true, 4, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
     else if (pipe) launch_wgrad_k<NT, 2, true, 12, true>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
@@ -1570,7 +1718,7 @@ extern "C" int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw, i
     int nsplit, tps;
     wgrad_plan(g, &t, &nsplit, &tps);
     if (wgrad_lds_bytes(g, t, false) > 160 * 1024 || t.NPP > 12 * 32 || t.PH > 1023 || t.PW > 1023) return RICK_EINVAL;
-    if (g->split == 1 && (((g->Ci | g->Co) & 3) != 0)) return RICK_EINVAL;   // plain-bf16 option: vector path only
+    if (g->split == 1 && (((g->Ci | g->Co) & 3) != 0)) return RICK_EINVAL;   // plain-fp16 option: vector path only
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
     if (g->ntaps == 1) launch_wgrad<1>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);

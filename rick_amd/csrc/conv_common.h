@@ -1,53 +1,96 @@
-// Device helpers shared by the MFMA convolution kernels (conv.hip, convt2.hip): bf16 hi/lo split, the swizzled
+// Device helpers shared by the MFMA convolution kernels (conv.hip, convt2.hip): fp16 hi/lo split, the swizzled
 // [row][32 k] LDS image, vector loads, XCD-aware block remap.
 #pragma once
 #include "common.h"
 #include <type_traits>
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 #define CV_BM 128
 #define CV_BN 128
 #define CV_CK 32
 #define CV_WTILE_BYTES (CV_BM * CV_CK * 2)      // one of hi / lo: 8 KB
 #define CV_WSTEP_BYTES (2 * CV_WTILE_BYTES)     // hi + lo: 16 KB
+#define CV_WTRAILER_BYTES 64                    // behind the packed tiles: float[0] = 2^-e of the tensor's pack exponent
 
 __host__ __device__ __forceinline__ int cv_swz(int kg, int row) { return kg ^ (((row >> 2) & 1) << 1); }
 
-__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+// ---- fp16 hi/lo split with a power-of-two operand exponent ------------------------------------------------------
+// An fp32 operand x is multiplied by 2^e (e chosen per block from a sample of the block's own data, so that the sampled
+// maximum lands in [2^CV_EXP_TARGET, 2^(CV_EXP_TARGET+1))), then split  x*2^e = hi + lo  with hi = fp16(x*2^e) (RNE) and
+// lo = fp16(x*2^e - hi) (the difference is exact in fp32).  The three products hi*hi + hi*lo + lo*hi accumulate in ONE
+// fp32 accumulator (lo carries no extra factor), the result is multiplied by 2^-e in the epilogue (exact).
+//   * values within 2^(CV_EXP_TARGET+3) = 128x of the sampled maximum: |x - hi - lo| <= 2^-22 |x|  (fp16 has 11
+//     significant bits, twice) - fp32-grade, 64x finer than the bf16 hi/lo split (2^-16) at the same three MFMAs;
+//   * smaller values: lo becomes an fp16 subnormal, absolute error <= 2^-25 / 2^e = 2^-29 of the sampled maximum;
+//   * overflow needs a value 2^(15 - CV_EXP_TARGET) = 2048x above the sampled maximum (>= 4096 samples per block).
+#define CV_EXP_TARGET 4
 
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned pack_bf16_rne(float a, float b) {   // v_cvt_pk_bf16_f32
-    bf16x2_t r = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+__device__ __forceinline__ unsigned pack_f16_rne(float a, float b) {   // v_cvt_pk_f16_f32
+    f16x2 r = __builtin_convertvector((f32x2_t){a, b}, f16x2);
     return *reinterpret_cast<unsigned *>(&r);
 }
 
-// x = hi + lo with hi = x truncated to bf16 (exactly representable, so lo = x - hi is exact in
-// fp32) and lo rounded to nearest bf16: |x - hi - lo| <= 2^-17 |x|, unbiased.  10 VALU ops per 4
-// elements (v_and, v_perm, v_pk_add, v_cvt_pk).  SPLIT == 1 (plain bf16): hi is rounded to nearest.
+// amax (>= 0, finite) -> scale = 2^e and unscale = 2^-e with  amax * scale in [2^T, 2^(T+1));  amax == 0 -> 1, 1.
+__device__ __forceinline__ void cv_pow2_scale(float amax, float &scale, float &unscale) {
+    int eb = (int)((__float_as_uint(amax) >> 23) & 0xffu);           // biased exponent (0 for zero / fp32 subnormals)
+    if (amax == 0.f) eb = 127 + CV_EXP_TARGET;
+    eb = eb < CV_EXP_TARGET + 1 ? CV_EXP_TARGET + 1 : eb;            // keeps both exponent fields in [1, 254]
+    eb = eb > 253 ? 253 : eb;                                         // (inf / nan samples: finite scale, the nan propagates)
+    scale = __uint_as_float((unsigned)(254 + CV_EXP_TARGET - eb) << 23);
+    unscale = __uint_as_float((unsigned)(eb - CV_EXP_TARGET) << 23);
+}
+
+// a block-uniform float as an SGPR operand (the exponents come out of an LDS reduction, which the compiler treats as
+// divergent: without this every scale multiply would hold VGPRs)
+__device__ __forceinline__ float cv_uniform(float v) {
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
+}
+__device__ __forceinline__ float4 scale4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+
+__device__ __forceinline__ float amax4(float m, const float4 v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+
+// wave64 max, then across the block's waves through `red` (>= blockDim.x / 64 floats of LDS); result in every thread.
+// Contains two barriers.
+__device__ __forceinline__ float block_amax(float v, float *red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    const int nw = (int)blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = red[0];
+    for (int i = 1; i < nw; i++) m = fmaxf(m, red[i]);
+    return m;
+}
+
+// v (already multiplied by 2^e) -> fp16 hi / lo pairs.  SPLIT == 1 (plain fp16, speed option): hi only.
+// 10 VALU per 4 elements: 2 v_cvt_pk_f16_f32, 4 v_cvt_f32_f16, 2 v_pk_add_f32, 2 v_cvt_pk_f16_f32.
 template <int SPLIT>
 __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
+    f16x2 h0 = __builtin_convertvector((f32x2_t){v.x, v.y}, f16x2);
+    f16x2 h1 = __builtin_convertvector((f32x2_t){v.z, v.w}, f16x2);
+    hi.x = *reinterpret_cast<unsigned *>(&h0);
+    hi.y = *reinterpret_cast<unsigned *>(&h1);
     if (SPLIT == 1) {
-        hi.x = pack_bf16_rne(v.x, v.y);
-        hi.y = pack_bf16_rne(v.z, v.w);
         lo.x = lo.y = 0;
         return;
     }
-    const unsigned ux = __float_as_uint(v.x), uy = __float_as_uint(v.y), uz = __float_as_uint(v.z),
-                   uw = __float_as_uint(v.w);
-    hi.x = __builtin_amdgcn_perm(uy, ux, 0x07060302);
-    hi.y = __builtin_amdgcn_perm(uw, uz, 0x07060302);
-    lo.x = pack_bf16_rne(v.x - __uint_as_float(ux & 0xffff0000u), v.y - __uint_as_float(uy & 0xffff0000u));
-    lo.y = pack_bf16_rne(v.z - __uint_as_float(uz & 0xffff0000u), v.w - __uint_as_float(uw & 0xffff0000u));
+    lo.x = pack_f16_rne(v.x - (float)h0[0], v.y - (float)h0[1]);
+    lo.y = pack_f16_rne(v.z - (float)h1[0], v.w - (float)h1[1]);
+}
+
+__device__ __forceinline__ void split1(float v, unsigned short &hi, unsigned short &lo, int split) {
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    hi = *reinterpret_cast<const unsigned short *>(&h);
+    lo = split == 1 ? (unsigned short)0 : *reinterpret_cast<const unsigned short *>(&l);
 }
 
 // XCD-aware bijective remap of the linear block id: blocks that share an XCD (id % 8) get a

@@ -5,7 +5,7 @@
 // This is F.conv_transpose2d(stride=2) of the upsampling StyledConvs (model_probe_tune.py:257-268) and the data
 // gradient of the discriminator's stride-2 3x3 convolutions (:608-630).  An output pixel of parity (py, px) only
 // receives the taps with ky = py (mod 2), kx = px (mod 2): 4 / 2 / 2 / 1 of the 9 taps.  The generic kernel
-// (conv.hip) runs the four classes as four block ranges and each of them stages and converts (fp32 -> bf16 hi/lo)
+// (conv.hip) runs the four classes as four block ranges and each of them stages and converts (fp32 -> fp16 hi/lo)
 // the same input patch again; here a 512-thread block owns one tile of the input-aligned position grid
 // (gy, gx) in [0, IH] x [0, IW], stages the (TH+1) x (TW+1) patch ONCE per 32-channel chunk, and its 8 waves are
 // (parity class) x (64-channel half of the 128-channel co tile), each with a 64 co x 128 positions accumulator:
@@ -18,7 +18,8 @@
 // loads its A fragments straight from the packed image in global memory — the packed layout makes every such
 // load one contiguous, fully used 1 KB — one tap ahead, into the registers the previous tap has just released.
 // The only LDS traffic is the B operand (patch), and the only barrier is one per channel chunk (double-buffered
-// patch).  Precision: bf16x3 (hi*hi + hi*lo + lo*hi, fp32 accumulate) or plain bf16, as in conv.hip.
+// patch).  Precision: fp16x3 (hi*hi + hi*lo + lo*hi with a per-block power-of-two operand exponent, fp32 accumulate)
+// or plain fp16, as in conv.hip.
 #include "conv_common.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -63,10 +64,6 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     const int gx0 = tx_i * P.TW, gy0 = ty_i * P.TH, n0 = tn_i * P.NB;
 
     const int cspan = P.cps * CV_CK;
-    for (int i = threadIdx.x; i < P.NB * cspan; i += CT_THREADS) {
-        const int nbi = i / cspan, c = c_begin * CV_CK + (i - nbi * cspan);
-        sct[i] = !iscale ? 1.f : (n0 + nbi < P.N && c < P.Ci) ? iscale[(int64_t)(n0 + nbi) * P.Ci + c] : 0.f;
-    }
 
     // ---- roles
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -104,6 +101,36 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
             }
         }
     }
+    // ---- operand exponent of this block (conv_common.h): amax of iscale * x over 8 sampled items per thread
+    // (its patch pixels x channel chunks spread over the block's range: 16384 values) -> x * 2^e
+    float unscale, xscale;
+    {
+        const int ncl = c_end - c_begin;
+        float m = 0.f;
+#pragma unroll
+        for (int sidx = 0; sidx < 8; sidx++) {
+            const int k = sidx % CT_PITEMS;
+            const int chunk = c_begin + (sidx * ncl) / 8;
+            const int ci = chunk * CV_CK + c4 * 4;
+            const bool ok = ((p_ok >> k) & 1u) && ci < P.Ci;
+            float4 v = *reinterpret_cast<const float4 *>(ok ? xt + p_rel[k] + chunk * CV_CK : g_ct2_zero_page);
+            if (iscale)
+                v = mul4(v, *reinterpret_cast<const float4 *>(ok ? iscale + (int64_t)(n0 + ((p_nbi >> (8 * k)) & 255u)) * P.Ci + ci
+                                                                 : g_ct2_zero_page));
+            m = amax4(m, v);
+        }
+        m = block_amax(m, reinterpret_cast<float *>(smem));
+        float xunscale;
+        cv_pow2_scale(m, xscale, xunscale);
+        xscale = cv_uniform(xscale);
+        // packed-weight exponent (trailer of the packed image)
+        unscale = cv_uniform(xunscale * *reinterpret_cast<const float *>(wpk + (int64_t)P.ncot * P.nchunks * 9 * CV_WSTEP_BYTES));
+        __syncthreads();                                      // every thread has read the reduction scratch
+        for (int i = threadIdx.x; i < P.NB * cspan; i += CT_THREADS) {
+            const int nbi = i / cspan, c = c_begin * CV_CK + (i - nbi * cspan);
+            sct[i] = !iscale ? xscale : (n0 + nbi < P.N && c < P.Ci) ? iscale[(int64_t)(n0 + nbi) * P.Ci + c] * xscale : 0.f;
+        }
+    }
     float4 pq[CT_PITEMS];
     unsigned cur_ok = 0;
     auto issue_patch = [&](int chunk) {
@@ -118,17 +145,22 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     auto commit_patch = [&](int chunk, unsigned char *ph) {
         unsigned char *pl = ph + pbuf;
         const float *sc = sct + (chunk - c_begin) * CV_CK + c4 * 4;
+        auto items = [&](auto ISC) {   // one block-uniform branch around the item loop: input scale x 2^e from the table, or 2^e from an SGPR
 #pragma unroll
-        for (int k = 0; k < CT_PITEMS; k++) {
-            float4 v = pq[k];       // (an out-of-range item has read the zero page)
-            if (iscale) v = mul4(v, *reinterpret_cast<const float4 *>(sc + ((p_nbi >> (8 * k)) & 255u) * cspan));
-            uint2 hi, lo;
-            split4<SPLIT>(v, hi, lo);
-            if (pix0 + (CT_THREADS / 8) * k < P.NPP) {        // (a branch around an LDS store is harmless; loads stay unconditional)
-                *reinterpret_cast<uint2 *>(ph + p_lds0 + k * 4096) = hi;
-                if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds0 + k * 4096) = lo;
+            for (int k = 0; k < CT_PITEMS; k++) {
+                float4 v = pq[k];       // (an out-of-range item has read the zero page)
+                if constexpr (decltype(ISC)::value) v = mul4(v, *reinterpret_cast<const float4 *>(sc + ((p_nbi >> (8 * k)) & 255u) * cspan));
+                else v = scale4(v, xscale);
+                uint2 hi, lo;
+                split4<SPLIT>(v, hi, lo);
+                if (pix0 + (CT_THREADS / 8) * k < P.NPP) {        // (a branch around an LDS store is harmless; loads stay unconditional)
+                    *reinterpret_cast<uint2 *>(ph + p_lds0 + k * 4096) = hi;
+                    if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds0 + k * 4096) = lo;
+                }
             }
-        }
+        };
+        if (iscale) items(std::true_type{});
+        else items(std::false_type{});
     };
 
     // ---- B operand (patch) read offsets: position j*16 + l15 of the tile -> patch pixel (ty + 1, tx + 1)
@@ -167,22 +199,22 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     // and its registers are reloaded at once — 48 MFMAs (>= 768 cycles) before the next tap touches them again.
     // The order of the groups is pinned with sched_barrier (hipcc otherwise interleaves the groups and ends up waiting
     // vmcnt(0) for all eight loads at the top of every tap).
-    bf16x8 ahi[4], alo[4];
+    f16x8 ahi[4], alo[4];
     auto load_a = [&](auto IC, const unsigned char *wt) {
         constexpr int i = decltype(IC)::value;
-        ahi[i] = *reinterpret_cast<const bf16x8 *>(wt + i * 1024);
-        if (SPLIT == 2) alo[i] = *reinterpret_cast<const bf16x8 *>(wt + CV_WTILE_BYTES + i * 1024);
+        ahi[i] = *reinterpret_cast<const f16x8 *>(wt + i * 1024);
+        if (SPLIT == 2) alo[i] = *reinterpret_cast<const f16x8 *>(wt + CV_WTILE_BYTES + i * 1024);
     };
     auto mma_tap = [&](const unsigned char *ph, const unsigned char *pl, int toff, const unsigned char *wnext) {
 #pragma unroll
         for (int jh = 0; jh < 2; jh++) {
-            bf16x8 bhi[4], blo[4];
+            f16x8 bhi[4], blo[4];
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
                 const int pp = pb[jh * 4 + jj] + toff;
                 const int off = pp * 64 + cv_swz(kg, pp) * 16;
-                bhi[jj] = *reinterpret_cast<const bf16x8 *>(ph + off);
-                if (SPLIT == 2) blo[jj] = *reinterpret_cast<const bf16x8 *>(pl + off);
+                bhi[jj] = *reinterpret_cast<const f16x8 *>(ph + off);
+                if (SPLIT == 2) blo[jj] = *reinterpret_cast<const f16x8 *>(pl + off);
             }
             static_for<0, 4>([&](auto IC) {
                 constexpr int i = decltype(IC)::value;
@@ -190,10 +222,10 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
                 for (int jj = 0; jj < 4; jj++) {
                     f32x4 &a = acc[i][jh * 4 + jj];
                     if (SPLIT == 2) {
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi[jj], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo[jj], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[i], bhi[jj], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], blo[jj], a, 0, 0, 0);
                     }
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi[jj], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], bhi[jj], a, 0, 0, 0);
                 }
                 if (jh == 1) load_a(IC, wnext);
                 __builtin_amdgcn_sched_barrier(0);
@@ -230,6 +262,7 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     // ---- epilogue: class (py, px), position (gy, gx) -> output pixel (2*gy + py, 2*gx + px)
     const int GHc = P.IH + 1 - py, GWc = P.IW + 1 - px;
     const int64_t osz = (int64_t)P.N * P.OH * P.OW * P.Co;
+    const float oalpha = P.alpha * unscale;                   // exact: the exponents are powers of two
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int pos = j * 16 + l15;
@@ -245,7 +278,8 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
             for (int i = 0; i < 4; i++) {
                 const int co = cot * CV_BM + h * 64 + i * 16 + kg * 4;
                 if (co < P.Co)
-                    *reinterpret_cast<float4 *>(wrow + co) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    *reinterpret_cast<float4 *>(wrow + co) = make_float4(acc[i][j][0] * unscale, acc[i][j][1] * unscale,
+                                                                         acc[i][j][2] * unscale, acc[i][j][3] * unscale);
             }
             continue;
         }
@@ -254,10 +288,10 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int co = cot * CV_BM + h * 64 + i * 16 + kg * 4;
-            sc[i] = make_float4(P.alpha, P.alpha, P.alpha, P.alpha);
+            sc[i] = make_float4(oalpha, oalpha, oalpha, oalpha);
             if (oscale) {
                 const float4 o = *reinterpret_cast<const float4 *>(oscale + (int64_t)n * P.Co + (co < P.Co ? co : 0));
-                sc[i] = make_float4(o.x * P.alpha, o.y * P.alpha, o.z * P.alpha, o.w * P.alpha);
+                sc[i] = make_float4(o.x * oalpha, o.y * oalpha, o.z * oalpha, o.w * oalpha);
             }
         }
 #pragma unroll

@@ -14,8 +14,8 @@ are closed under differentiation, so R1 / path-length second-order terms need no
 
 (w^T swaps the two channel axes; no spatial flips are needed because the tap geometry is
 explicit.)  All activations are channels-last; weights are any [O, I, kh, kw] view whose last
-two dims are jointly contiguous.  `precision()` selects bf16x3 (default, fp32-grade) or
-plain bf16 MFMA.
+two dims are jointly contiguous.  `set_precision()` selects fp16x3 (default: fp16 hi/lo split with a
+per-block power-of-two operand exponent, 2^-22 per product, fp32 accumulate) or plain fp16 MFMA.
 """
 import ctypes
 import threading
@@ -27,7 +27,7 @@ from torch.autograd.function import once_differentiable
 
 from .._lib import MAX_TAPS, ConvEpilogue, ConvGeom, check, lib, ptr, require_cuda_f32, stream_ptr
 
-_SPLIT = 2          # 2: bf16 hi/lo split, 3 MFMAs per product (fp32-grade); 1: plain bf16
+_SPLIT = 2          # 2: fp16 hi/lo split, 3 MFMAs per product (fp32-grade); 1: plain fp16
 _weights_epoch = 0  # bumped by optimisers that update parameters through raw pointers
 
 
@@ -62,13 +62,14 @@ def _launch(kind, flops, fn, *args, tag=''):
 
 
 def set_precision(name):
-    """'bf16x3' (default; parity-grade) or 'bf16' (single pass, ~3x the MFMA rate, ~2^-9 relative)."""
+    """'fp16x3' (default; parity-grade, ~2^-22 relative per product) or 'fp16' (single pass, ~3x the MFMA rate,
+    ~2^-12 relative)."""
     global _SPLIT
-    _SPLIT = {'bf16x3': 2, 'bf16': 1}[name]
+    _SPLIT = {'fp16x3': 2, 'fp16': 1}[name]
 
 
 def get_precision():
-    return 'bf16x3' if _SPLIT == 2 else 'bf16'
+    return 'fp16x3' if _SPLIT == 2 else 'fp16'
 
 
 def bump_weights_epoch(params=None):
