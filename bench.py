@@ -2,7 +2,9 @@
 """Headline benchmark: G+D train-step images/sec @256 px (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher — python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+     — or bare: without WORLD_SIZE in the environment the script starts its own N rank processes, one per GPU, before
+     anything touches the GPU, waits for them and exits non-zero if any rank failed)
 
 A "step" is one iteration of the RICK adaptation loop in steady state (i >= warmup_iter,
 train_dynamic_update_prune.py:395-589,697-698): D step, [R1 every 16], G step, [path length
@@ -85,6 +87,39 @@ def load_traffic():
         return json.load(f).get('conv_igemm', {}).get('hbm_bytes_per_launch')
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, rendezvous on 127.0.0.1), one per GPU, as CHILDREN of this process — which has not touched the GPU and
+    never will (no exec of a GPU-initialised process) — let rank 0 print the JSON line on the inherited stdout, and return
+    the first non-zero exit code (the other ranks are terminated: a lost rank would leave them in a collective)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f'[bench] rank {r} exited with code {code}; stopping the other ranks', file=sys.stderr)
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -104,6 +139,8 @@ def main():
     ap.add_argument('--eval', action='store_true', help='also time G inference (BASELINE config 4: batches of 25)')
     ap.add_argument('--fisher-img', type=int, default=2, help='samples of the (untimed) Fisher sweep that sets the masks')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     from rick_amd import op
     from rick_amd.dist import DataParallelGrads, init_from_env
@@ -114,6 +151,18 @@ def main():
     import torch.distributed as dist
 
     rank, local, world = init_from_env()
+    if os.environ.get('RICK_BENCH_DRYRUN'):
+        # launcher check for hosts without a GPU (tests/test_host_logic.py): rendezvous, one all-reduce over the ranks,
+        # rank 0 prints a line; no kernel runs and nothing is measured
+        t = torch.tensor([float(rank + 1)])
+        if world > 1:
+            dist.all_reduce(t)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({'dry_run': True, 'n_gpus': world, 'rank_sum': float(t), 'backend': dist.get_backend() if world > 1 else None}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if world != args.gpus and not (world == 1 and args.gpus == 1):
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     if os.environ.get('RICK_FORCE_DEVICE') is not None:      # functional test: several ranks on one GPU (gloo)
@@ -181,10 +230,13 @@ def main():
     run(args.steps, i0 + args.warmup)
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = [1e3 * elapsed / args.steps]
     if world > 1:
-        t = torch.tensor([elapsed], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+        t = torch.zeros(world, device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
+        t[rank] = elapsed
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rank_ms = [1e3 * float(v) / args.steps for v in t]
+        elapsed = float(t.max())
 
     out = {
         'metric': 'G+D train-step images/sec @256px', 'value': cfg.batch * world * args.steps / elapsed,
@@ -196,6 +248,9 @@ def main():
                                f'batch {cfg.batch}/GPU, {cfg.size}px, channel_multiplier 2, random-init weights',
                    'global_batch': cfg.batch * world, 'parallelism': f'dp{world}', 'hip_graphs': use_graphs,
                    'first_iteration': i0 + args.warmup},
+        'ranks': {'backend': dist.get_backend() if world > 1 else None, 'world_size': world,
+                  'rccl_ranks': world if world > 1 and dist.get_backend() == 'nccl' else (0 if world > 1 else None),
+                  'ms_per_step_per_rank': rank_ms},
     }
 
     if fisher_ms is not None:

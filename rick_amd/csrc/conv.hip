@@ -68,6 +68,7 @@ __device__ __forceinline__ void pack_exponent(const float *__restrict__ w, int64
         trailer[0] = un;
         trailer[1] = sc;
     }
+    if (threadIdx.x >= 2 && threadIdx.x < CV_WTRAILER_BYTES / 4) trailer[threadIdx.x] = 0.f;   // (packed images compare equal byte for byte)
 }
 
 __global__ __launch_bounds__(256) void pack_exponent_kernel(const float *__restrict__ w, int64_t s_co, int64_t s_ci,

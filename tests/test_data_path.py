@@ -108,3 +108,40 @@ def test_device_batch_bit_exact():
     stream = rd.train_batches(ds, 4, num_workers=8)
     b0, b1 = next(stream), next(stream)
     assert b0.shape == (4, 3, 64, 64) and float(b0.abs().max()) <= 1.0 and not torch.equal(b0, b1)
+
+
+# ------------------------------------------------------------- independent producer / consumer: PIL (Pillow 12.2)
+@pytest.mark.parametrize('mode', ['RGB', 'L', 'RGBA', 'P'])
+@pytest.mark.parametrize('size', [(29, 37), (64, 64)])
+def test_png_decoder_reads_pil_written_files(mode, size):
+    """decode_png against PNG files written by an INDEPENDENT encoder (Pillow — the library prepare_data.py:14-21 uses to
+    write the LMDB values): RGB, grayscale, RGBA and palette images; PIL picks its own per-row filters and zlib level."""
+    import io
+    Image = pytest.importorskip('PIL.Image')
+    w, h = size
+    rgb = synth_images(1, max(w, h), seed=7)[0][:h, :w]
+    if mode == 'RGB':
+        im = Image.fromarray(rgb, 'RGB')
+    elif mode == 'L':
+        im = Image.fromarray(rgb[..., 0], 'L')
+    elif mode == 'RGBA':
+        a = ((rgb[..., :1].astype(np.int32) * 3 + 11) % 256).astype(np.uint8)
+        im = Image.fromarray(np.concatenate([rgb, a], -1), 'RGBA')
+    else:
+        im = Image.fromarray(rgb, 'RGB').quantize(colors=64)
+    buf = io.BytesIO()
+    im.save(buf, format='PNG', optimize=(mode == 'L'))
+    got = rd.decode_png(buf.getvalue())
+    want = np.asarray(im.convert('RGB'))           # the loader hands RGB to the network (dataset.py:33-38)
+    assert got.shape == want.shape and got.dtype == np.uint8
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize('ft', [0, 1, 2, 3, 4])
+def test_pil_reads_png_encoder_output(ft):
+    """encode_png's files opened by an independent decoder (Pillow)."""
+    import io
+    Image = pytest.importorskip('PIL.Image')
+    img = synth_images(1, 41, seed=9)[0][:, :33]
+    back = np.asarray(Image.open(io.BytesIO(rd.encode_png(img, ft))).convert('RGB'))
+    assert np.array_equal(back, img)

@@ -227,3 +227,26 @@ def test_two_rank_gradients_equal_single_process_global_batch(graphs):
     # in the other tiling — isolated entries move by ~1e-3 of the largest gradient, the L2 criterion below stays tight)
     assert np.abs(a['g_grad'] - ref).max() <= 2e-3 * np.abs(ref).max(), np.abs(a['g_grad'] - ref).max() / np.abs(ref).max()
     assert np.linalg.norm(a['g_grad'] - ref) <= 1e-3 * np.linalg.norm(ref)
+
+
+def test_bench_self_launch_two_ranks_one_gpu():
+    """`python bench.py --gpus 2` with no launcher: the script starts two rank processes itself (here both on cuda:0 with
+    gloo + host staging, because RCCL refuses two ranks on one device), runs the real benchmark loop at a small size
+    through the split-graph data-parallel path and prints one JSON line; exit code 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RICK_DIST_BACKEND='gloo', RICK_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--size', '32', '--batch', '2',
+                        '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--fisher-img', '2'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and out['config']['global_batch'] == 4
+    assert out['ranks']['world_size'] == 2 and len(out['ranks']['ms_per_step_per_rank']) == 2
+    assert out['ranks']['backend'] == 'gloo' and out['ranks']['rccl_ranks'] == 0

@@ -219,3 +219,37 @@ def test_data_parallel_grads_gloo_world2():
         n0 = 64 * 300
         assert np.allclose(o[5][n0:], ref[n0:], rtol=1e-5, atol=1e-7)     # frozen first weight excluded
     assert np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` as the driver calls it (no launcher, no WORLD_SIZE): the script starts its own two rank
+    processes, they rendezvous on 127.0.0.1 (gloo here) and rank 0 prints ONE JSON line; exit code 0.  RICK_BENCH_DRYRUN
+    stops each rank after the rendezvous + one all-reduce (this host has no GPU); the measured path of the same launcher
+    is covered by tests/test_gpu_dp.py::test_bench_self_launch_two_ranks_one_gpu."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RICK_BENCH_DRYRUN='1', RICK_DIST_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out == {'dry_run': True, 'n_gpus': 2, 'rank_sum': 3.0, 'backend': 'gloo'}
+
+
+def test_bench_self_launch_propagates_failure():
+    """A rank that dies makes the launcher exit non-zero (and stops the surviving rank instead of leaving it in a
+    collective)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RICK_BENCH_DRYRUN='1', RICK_DIST_BACKEND='no-such-backend')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0

@@ -155,7 +155,8 @@ def grad_summ(named, grads):
     return {k: float((g.double() ** 2).sum()) if g is not None else 0.0 for (k, _), g in zip(named, grads)}
 
 
-def model_case(mpt, size, B, dtype, out, tag, latents=None, full_arrays=False):
+def model_case(mpt, size, B, dtype, out, tag, latents=None, full_arrays=False, store=None):
+    np32 = store or globals()['np32']     # (gen_spread keeps the fp64 run's values in fp64)
     g, d = build(mpt, size, dtype)
     z = (latents if latents is not None else synth_latents(B, seed=size)).to(dtype)
     real = synth_reals(B, size=size, seed=size).to(dtype)
@@ -574,27 +575,14 @@ def gen_rick(mpt):
 
 
 def gen_spread(mpt):
-    """The 256-px case of gen_full once more in fp64: how far the REFERENCE's own fp32 run sits from its fp64 run,
-    per parameter key (LeakyReLU sign flips of ~0 pre-activations) — the yardstick for check_grad2's per-key bound."""
+    """The 256-px case of gen_full once more in fp64 — every quantity of model_case incl. the second-order ones (R1,
+    path length and their parameter gradients): how far the REFERENCE's own fp32 run sits from its fp64 run, per
+    parameter key (LeakyReLU sign flips of ~0 pre-activations) — the yardstick for the GPU tests' bounds."""
     out = {}
     lat = torch.cat([torch.load(os.path.join(REF, '_noise', f'{j:04d}.pt')) for j in range(2)], 0)
-    g, d = build(mpt, 256, torch.float64)
-    z, real = lat.double(), synth_reals(2, size=256, seed=256).double()
-    gp, dp = list(g.named_parameters()), list(d.named_parameters())
-    fake, _ = g([z], randomize_noise=False)
-    fake_pred, _ = d(fake)
-    real_pred, _ = d(real)
-    d_loss = softplus(-real_pred).mean() + softplus(fake_pred).mean()
-    g_loss = softplus(-fake_pred).mean()
-    gd = torch.autograd.grad(d_loss, [p for _, p in dp], retain_graph=True, allow_unused=True)
-    gg = torch.autograd.grad(g_loss, [p for _, p in gp], allow_unused=True)
-    out['f256_f64/d_loss'], out['f256_f64/g_loss'] = np.float64(d_loss), np.float64(g_loss)
-    idx = torch.from_numpy(np.random.RandomState(0).randint(0, fake[0].numel(), size=4096))
-    out['f256_f64/img_samples'] = fake.reshape(2, -1)[:, idx].detach().numpy()
-    for k, v in grad_summ(dp, gd).items():
-        out[f'f256_f64/d_grad2/{k}'] = np.float64(v)
-    for k, v in grad_summ(gp, gg).items():
-        out[f'f256_f64/g_grad2/{k}'] = np.float64(v)
+    model_case(mpt, 256, 2, torch.float64, out, 'f256_f64', latents=lat,
+               store=lambda t: t.detach().to(torch.float64).numpy().copy())
+    del out['f256_f64/img_idx']          # (same indices as full256.npz)
     np.savez_compressed(os.path.join(OUT, 'spread256.npz'), **out)
     print('spread256.npz', len(out), 'arrays')
 
