@@ -346,9 +346,12 @@ static int ct2_plan(int N, int IH, int IW, int Ci, int Co, int OH, int OW, float
             if (nb > N) nb = N;
             const int npp = nb * (th + 1) * (tw + 1);
             if (npp > CT_MAX_NPP) continue;
+
             const long tiles = (long)cdiv(GW, tw) * cdiv(GH, th) * cdiv(N, nb) * p->ncot;
             for (int s = 1; s <= p->nchunks && s <= 16; s++) {
                 const int cps = cdiv(p->nchunks, s), se = cdiv(p->nchunks, cps);
+                // (two double-buffered hi/lo patch images + the [nb][cps * 32] scale table must fit the LDS)
+                if (4 * (size_t)npp * 64 + (size_t)nb * cps * CV_CK * 4 > 160 * 1024) continue;
                 const long waves = (tiles * se + 255) / 256;
                 // rough time model in ns: a block needs ~6 us per channel chunk (9 taps x 96 MFMAs per wave) + ~4 us fixed;
                 // a split writes and re-reads se partial copies of the output (~4 TB/s) plus a second launch.  Patch rows

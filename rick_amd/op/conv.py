@@ -330,14 +330,17 @@ def _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha):
     ent = _geom_cache.get(key)
     if ent is None:
         nbytes = lib.rick_convt2_workspace_bytes(N, IH, IW, I, O, OH, OW)
-        if nbytes < 0:
-            raise RuntimeError('rick_convt2_workspace_bytes: invalid geometry')
+        if nbytes < 0:               # tensor of >= 2^31 elements, or no tile whose patch + scale table fits the LDS
+            _geom_cache[key] = (None, 0.0, '')
+            return None
         # algorithmic FLOPs: every (input pixel, tap) pair whose output pixel exists
         ny = [sum(1 for iy in range(IH) if 2 * iy + k < OH) for k in range(3)]
         nx = [sum(1 for ix in range(IW) if 2 * ix + k < OW) for k in range(3)]
         ent = (nbytes, 2.0 * N * O * I * sum(ny) * sum(nx), f'convT {I}->{O} k3 s2 N{N} {IH}x{IW}')
         _geom_cache[key] = ent
     nbytes, flops, tag = ent
+    if nbytes is None:
+        return None
     y = _empty_nhwc(N, O, OH, OW, x)
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     check(_launch('igemm', flops, lib.rick_convt2_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), N, IH, IW, I, O,
@@ -352,7 +355,9 @@ def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alph
     OH, OW = out_hw
     if (_USE_CT2 and kh == 3 and kw == 3 and s == 2 and p == 0 and I % 4 == 0 and O % 4 == 0
             and OH in (2 * IH, 2 * IH + 1) and OW in (2 * IW, 2 * IW + 1)):
-        return _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha)
+        y = _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha)
+        if y is not None:            # (None: the single-staging kernel has no plan for this size -> generic launch below)
+            return y
     key = ('t', N, I, IH, IW, O, kh, kw, s, p, OH, OW, alpha, _SPLIT)
     ent = _geom_cache.get(key)
     if ent is None:

@@ -420,6 +420,15 @@ class RickTrainer:
         if self.dp is not None:
             self.dp.all_reduce(flat)
 
+    def _sink(self):
+        """op.grad_sink() — except in the eager data-parallel mode, whose bucket all-reduces are launched from the
+        parameters' post-accumulate-grad hooks while backward is still running: a sunk gradient fires no hook, so every
+        bucket with a conv weight would only leave at the end of backward and nothing would overlap."""
+        import contextlib
+        if self.dp is not None and getattr(self.dp, 'hooks_enabled', False) and getattr(self.dp, 'world', 1) > 1:
+            return contextlib.nullcontext()
+        return op.grad_sink()
+
     def _zero_grad(self, flat):
         flat.zero_grad()
         if self.dp is not None:
@@ -482,14 +491,18 @@ class RickTrainer:
         st = None
         if key is not None and self.use_graphs:
             st = self._gs.setdefault(key, {'n': 0})
+            if 'graphs' in st and st['sig'] != self._graph_signature(optim):
+                # optimiser state / stage changed under the capture: drop it AND run the two eager warm-up steps again —
+                # a new requires_grad pattern needs new descriptor tables (PackGroup, ModulationBank), which must not be
+                # built inside a capture
+                del st['graphs']
+                st['n'] = 0
             st['n'] += 1
         if st is None or st['n'] <= 2:                        # eager (also the warm-up of a graph: caches, allocator)
             fb()
             self._reduce(flat)
             optim.step()
             return
-        if 'graphs' in st and st['sig'] != self._graph_signature(optim):
-            del st['graphs']                                  # optimiser state / stage changed under the capture: redo it
         # packed weights are refreshed HERE, on the host side of the graph: a network is repacked once per update of its
         # weights (the D step's graph used to repack G again although the G step's graph had just done so, and vice versa)
         for grp in self._pack_groups:
@@ -522,8 +535,8 @@ class RickTrainer:
             gs[1].replay()
         optim.last_runs = st['runs']
         optim.note_replayed_step()
-        # the replay updated the parameters through raw pointers: packed weights cached by EAGER launches are stale
-        # (graphs re-pack inside themselves; this is a host-side counter only)
+        # the replay updated the parameters through raw pointers: packed weights are stale (a host-side counter; the next
+        # _run / fisher_sweep refreshes the pack group before it replays anything)
         op.bump_weights_epoch(flat.params)
         self.losses.update(st['losses'])                      # eager steps in between may have re-bound the entries
 
@@ -541,6 +554,7 @@ class RickTrainer:
         """Drop every captured step (after loading a checkpoint or changing optimiser hyper-parameters)."""
         for st in self._gs.values():
             st.pop('graphs', None)
+            st['n'] = 0                                       # two eager warm-up steps before the next capture
         self._fisher_state = None
 
     # ---- steps (each returns the loss tensor; no host sync)
@@ -557,7 +571,7 @@ class RickTrainer:
                     fake_img, _ = self.g(noise, noise=g_noise)
             # one pass over cat(fake, real): identical to the reference's two calls (per-call minibatch-stddev
             # statistics are kept), half the launches and twice the GEMM rows per launch
-            with op.grad_sink():                 # conv weight gradients are added straight into the flat buffer
+            with self._sink():                   # conv weight gradients are added straight into the flat buffer
                 pred, _ = self.d(torch.cat([fake_img, real_img], 0), calls=2)
                 fake_pred, real_pred = pred.chunk(2, 0)
                 d_loss = d_logistic_loss(real_pred, fake_pred)
@@ -588,7 +602,7 @@ class RickTrainer:
         batch = self.cfg.batch
 
         def fb():
-            with op.grad_sink(), self._d_frozen():
+            with self._sink(), self._d_frozen():
                 if graph:
                     fake_img, _ = self.g([self._graph_latents(key, batch)], input_is_latent=True, noise=g_noise)
                 else:
@@ -666,15 +680,20 @@ class RickTrainer:
         which the GPU works less than half).  With `use_graphs` the per-sample body is captured once (second sample of the
         first sweep; the first runs eagerly so that every packed-weight request and descriptor table exists) and replayed
         with the sample copied into static input buffers; the grad^2 accumulators are persistent tensors the captured
-        launches add into.  Same kernels on the same data as the eager loop."""
+        launches add into.  Same kernels on the same data as the eager loop.
+
+        Returns the two PERSISTENT accumulators (scaled grad^2 per parameter): the next sweep zeroes and refills them in
+        place — clone what must outlive it."""
         cfg = self.cfg
         requires_grad(self.g_ema, True)
         requires_grad(self.d_ema, True)
         g_named, d_named = list(self.g_ema.named_parameters()), list(self.d_ema.named_parameters())
         g_params, d_params = [p for _, p in g_named], [p for _, p in d_named]
         st = self._fisher_state
-        if st is None or st['fixed_noise'] != fixed_noise:
-            st = self._fisher_state = {'fixed_noise': fixed_noise, 'acc': (FisherAccumulator(g_named), FisherAccumulator(d_named)),
+        # what a captured per-sample graph bakes in: arithmetic mode, image size, which parameters take gradients
+        sig = (fixed_noise, op.get_precision(), cfg.size, tuple(p.requires_grad for p in g_params + d_params))
+        if st is None or st['sig'] != sig:
+            st = self._fisher_state = {'sig': sig, 'acc': (FisherAccumulator(g_named), FisherAccumulator(d_named)),
                                        'z': torch.empty(1, cfg.latent, device=self.device),
                                        'real': torch.empty(1, 3, cfg.size, cfg.size, device=self.device), 'runs': 0, 'graph': None}
         acc_g, acc_d = st['acc']

@@ -181,14 +181,16 @@ def test_decisions_restated(golden):
 
 def test_reference_fp32_vs_fp64_spread(golden):
     """How far the REFERENCE's own fp32 run (tests/golden/full256.npz, the arithmetic it trains in) sits from its own
-    fp64 run (spread256.npz) at 256 px, per parameter key of the D / G loss gradients: the yardstick the GPU parity
+    fp64 run (spread256.npz) at 256 px, per parameter key of the D / G loss gradients and of the R1 / path-length
+    gradients (second order): the yardstick the GPU parity
     bounds are quoted against (tests/test_gpu_models.py::check_grad2).  LeakyReLU sign flips of ~0 pre-activations are
     the only mechanism that can move a key by more than rounding; at fp32 they move it by <= 5e-5 (noise strengths,
     scalar sums over a whole feature map with heavy cancellation: <= 2e-2)."""
     a, b = golden('full256'), golden('spread256')
     assert abs(float(a['f256/d_loss']) - float(b['f256_f64/d_loss'])) < 2e-6 * float(b['f256_f64/d_loss'])
     assert np.abs(a['f256/img_samples'] - b['f256_f64/img_samples']).max() < 1e-5 * np.abs(b['f256_f64/img_samples']).max()
-    for pre in ('d_grad2', 'g_grad2'):
+
+    def keys(pre):
         rels, noise = [], []
         for k in b.files:
             if not k.startswith(f'f256_f64/{pre}/'):
@@ -196,5 +198,18 @@ def test_reference_fp32_vs_fp64_spread(golden):
             r64, r32 = float(b[k]), float(a[k.replace('f256_f64', 'f256')])
             if r64 > 0:
                 (noise if k.endswith('noise.weight') else rels).append(abs(r32 - r64) / r64)
+        return rels, noise
+    for pre in ('d_grad2', 'g_grad2'):
+        rels, noise = keys(pre)
         assert len(rels) > 30 and np.median(rels) < 1e-5 and max(rels) < 5e-5, (pre, np.median(rels), max(rels))
         assert not noise or max(noise) < 2e-2, (pre, max(noise))
+    # second order (R1: train_dynamic_update_prune.py:89-96; path length: :104-118) — measured 1.4e-6 / 7.4e-5 / 3.7e-5 on the
+    # values, per-key grad^2 median 1.3e-6 (max 3.0e-4) for R1 and 1.8e-4 (max 1.1e-3, noise strengths 1.0e-2) for path length
+    def srel(name):
+        x, y = np.asarray(a[f'f256/{name}'], dtype=np.float64), np.asarray(b[f'f256_f64/{name}'], dtype=np.float64)
+        return np.abs(x - y).max() / np.abs(y).max()
+    assert srel('r1') < 5e-6 and srel('pl_loss') < 2e-4 and srel('pl_lengths') < 1e-4, (srel('r1'), srel('pl_loss'), srel('pl_lengths'))
+    rels, noise = keys('r1_grad2')
+    assert len(rels) > 30 and np.median(rels) < 5e-6 and max(rels) < 1e-3, (np.median(rels), max(rels))
+    rels, noise = keys('pl_grad2')
+    assert len(rels) > 60 and np.median(rels) < 5e-4 and max(rels) < 3e-3 and max(noise) < 3e-2, (np.median(rels), max(rels), max(noise))
