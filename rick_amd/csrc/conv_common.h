@@ -21,17 +21,21 @@ __host__ __device__ __forceinline__ int cv_swz(int kg, int row) { return kg ^ ((
 
 // ---- fp16 hi/lo split with a power-of-two operand exponent ------------------------------------------------------
 // An fp32 operand x is multiplied by 2^e (e chosen per block from a sample of the block's own data, so that the sampled
-// maximum lands in [2^T, 2^(T+1)), T = CV_EXP_TARGET), then split  x*2^e = hi + lo  with hi = fp16(x*2^e) rounded
-// TOWARDS ZERO (v_cvt_pkrtz_f16_f32: saturates at 65504 instead of rounding to infinity) and lo = fp16(x*2^e - hi)
-// rounded to nearest (the difference is exact in fp32).  The three products hi*hi + hi*lo + lo*hi accumulate in ONE
-// fp32 accumulator (lo carries no extra factor), the result is multiplied by 2^-e in the epilogue (exact).
-//   * values within 2^(T+3) = 32x of the sampled maximum: |x - hi - lo| <= 2^-21 |x|, unbiased (fp16 has 11 significant
-//     bits, twice) - fp32-grade, 32x finer than a bf16 hi/lo split (2^-16) at the same three MFMAs; measured on
-//     MI355X: 2-4e-7 of the output maximum on every layer shape, the level of an fp32 CPU convolution (tools/diag_precision.py);
+// maximum lands in [2^T, 2^(T+1)), T = CV_EXP_TARGET), then split  x*2^e = hi + lo  with hi = fp16(x*2^e) and
+// lo = fp16(x*2^e - hi), both rounded to nearest even (the difference is exact in fp32).  The three products
+// hi*hi + hi*lo + lo*hi accumulate in ONE fp32 accumulator (lo carries no extra factor), the result is multiplied by
+// 2^-e in the epilogue (exact).
+//   * values within 2^(T+3) = 32x of the sampled maximum: |x - hi - lo| <= 2^-22 |x| (fp16 has 11 significant bits,
+//     twice) - fp32-grade, 64x finer than a bf16 hi/lo split (2^-16) at the same three MFMAs; measured on MI355X:
+//     2-4e-7 of the output maximum on every layer shape, the level of an fp32 CPU convolution (tools/diag_precision.py);
+//   * both roundings are to NEAREST on purpose: with hi rounded towards zero (v_cvt_pkrtz_f16_f32, which would saturate
+//     instead of overflowing) lo always has the sign of x, the dropped lo*lo term always has the sign of the product,
+//     and every product comes out ~1.2e-7 short - a bias that compounds through 25 layers (measured: logits 3e-6 off,
+//     second-order bias gradients 3e-3 off); nearest rounding makes the dropped term sign-random;
 //   * smaller values: lo becomes an fp16 subnormal (the MFMA does not flush them - measured), absolute error
 //     <= 2^-25 / 2^T = 2^-27 of the sampled maximum;
-//   * overflow needs a value 2^(17 - T) = 32768x above the sampled maximum of >= 4096 samples per block; such a value
-//     turns lo into infinity and the outputs it touches into inf / nan (loud, never silently wrong).
+//   * overflow needs a value 2^(15 - T) = 8192x above the sampled maximum of >= 4096 samples per block; such a value
+//     becomes infinity and the outputs it touches inf / nan (loud, never silently wrong).
 #define CV_EXP_TARGET 2
 
 __device__ __forceinline__ unsigned pack_f16_rne(float a, float b) {   // v_cvt_pk_f16_f32
@@ -75,11 +79,11 @@ __device__ __forceinline__ float block_amax(float v, float *red) {
 }
 
 // v (already multiplied by 2^e) -> fp16 hi / lo pairs.  SPLIT == 1 (plain fp16, speed option): hi only.
-// 10 VALU per 4 elements: 2 v_cvt_pkrtz_f16_f32, 4 v_cvt_f32_f16, 2 v_pk_add_f32, 2 v_cvt_pk_f16_f32.
+// 10 VALU per 4 elements: 2 v_cvt_pk_f16_f32, 4 v_cvt_f32_f16, 2 v_pk_add_f32, 2 v_cvt_pk_f16_f32.
 template <int SPLIT>
 __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
-    typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
-    const h16x2 h0 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h1 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+    const f16x2 h0 = __builtin_convertvector((f32x2_t){v.x, v.y}, f16x2);
+    const f16x2 h1 = __builtin_convertvector((f32x2_t){v.z, v.w}, f16x2);
     hi.x = *reinterpret_cast<const unsigned *>(&h0);
     hi.y = *reinterpret_cast<const unsigned *>(&h1);
     if (SPLIT == 1) {
@@ -91,11 +95,9 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
 }
 
 __device__ __forceinline__ void split1(float v, unsigned short &hi, unsigned short &lo, int split) {
-    typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
-    const h16x2 hh = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
-    const float hf = (float)hh[0];
-    const _Float16 l = (_Float16)(v - hf);
-    hi = *reinterpret_cast<const unsigned short *>(&hh);
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    hi = *reinterpret_cast<const unsigned short *>(&h);
     lo = split == 1 ? (unsigned short)0 : *reinterpret_cast<const unsigned short *>(&l);
 }
 
