@@ -326,47 +326,19 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     const int gx0 = tx_i << t.tw_log2, gy0 = ty_i << t.th_log2, n0 = tn_i * t.nbe;
     const int iy0 = gy0 * g.is + t.dymin, ix0 = gx0 * g.is + t.dxmin;
     const int cspan = t.cps * CV_CK;
-    __syncthreads();   // patch table complete
 
-    // ---- operand exponent of this block (conv_common.h): amax over a sample of the block's own patch — 8 items per
-    // thread spread over its channel chunks and patch pixels (8192 values, with the input scale applied) -> x * 2^e.
-    float xscale, xunscale;
-    {
-        const int c4s = threadIdx.x & 7;
-        const int ncl = c_end - c_begin;
-        float m = 0.f;
-#pragma unroll
-        for (int sidx = 0; sidx < 8; sidx++) {
-            const int pix = (threadIdx.x >> 3) + 32 * ((sidx * 5 + 1) % (DEEP || (NT > 0 && NJ == 4) ? IG_PSET_DEEP : IG_PMAX));
-            const int chunk = c_begin + (sidx * ncl) / 8;
-            const int ci = chunk * CV_CK + c4s * 4;
-            bool ok = pix < t.NPP && ci < g.Ci;
-            int n = 0, iy = 0, ix = 0;
-            if (ok) {
-                const unsigned e = ptab[pix];
-                n = n0 + (int)(e >> 20);
-                iy = iy0 + (int)((e >> 10) & 1023);
-                ix = ix0 + (int)(e & 1023);
-                ok = n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
-            }
-            float4 v = load4<VEC>(ok ? x + (((int64_t)n * g.IH + iy) * g.IW + ix) * g.Ci + ci : (VEC ? g_zero_page : x), ok, ci, g.Ci);
-            if (iscale) v = mul4(v, load4<VEC>(ok ? iscale + (int64_t)n * g.Ci + ci : (VEC ? g_zero_page : iscale), ok, ci, g.Ci));
-            m = amax4(m, v);
+    // per-(image, input channel) scales of this block's images and channel range (1 without an input scale): read from HBM
+    // once, multiplied by the block exponent below, then applied from LDS while the patch is converted — no global-load
+    // round trip and no branch per patch item
+    if (iscale) {
+        for (int i = threadIdx.x; i < t.nbe * cspan; i += 256) {
+            const int nbi = i / cspan, c = c_begin * CV_CK + (i - nbi * cspan);
+            sct[i] = (n0 + nbi < g.N && c < g.Ci) ? iscale[(int64_t)(n0 + nbi) * g.Ci + c] : 0.f;
         }
-        m = block_amax(m, reinterpret_cast<float *>(wbuf));
-        cv_pow2_scale(m, xscale, xunscale);
-        xscale = cv_uniform(xscale);
     }
-    // packed-weight exponent (trailer of the packed image)
-    const float wunscale = *reinterpret_cast<const float *>(wpk + (int64_t)t.ncot * t.nchunks * g.nslices * CV_WSTEP_BYTES);
-    const float unscale = cv_uniform(xunscale * wunscale);
-    // per-(image, input channel) scales of this block's images and channel range, times 2^e: read from HBM once, then
-    // applied from LDS while the patch is converted — no global-load round trip and no branch per patch item
-    for (int i = threadIdx.x; i < t.nbe * cspan; i += 256) {
-        const int nbi = i / cspan, c = c_begin * CV_CK + (i - nbi * cspan);
-        sct[i] = !iscale ? xscale : (n0 + nbi < g.N && c < g.Ci) ? iscale[(int64_t)(n0 + nbi) * g.Ci + c] * xscale : 0.f;
-    }
-    __syncthreads();
+    __syncthreads();   // patch table and scale table complete
+    // operand exponent of this block (conv_common.h), set by block_exponent() below once the first chunk is in registers
+    float xscale = 1.f, unscale = 1.f;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -443,11 +415,11 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             for (int k = 0; k < PSET; k++) {
                 const bool ok = (cur_ok[S] >> k) & 1u;
                 float4 v = pq[S * PSET + k];
-                if constexpr (decltype(ISC)::value) v = mul4(v, *reinterpret_cast<const float4 *>(sct + p_sc[k] + (chunk - c_begin) * CV_CK));
-                else v = scale4(v, xscale);
                 if (!VEC && !ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 hi, lo;
-                split4<SPLIT>(v, hi, lo);
+                if constexpr (decltype(ISC)::value)
+                    split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sct + p_sc[k] + (chunk - c_begin) * CV_CK), hi, lo);
+                else split4s<SPLIT>(v, xscale, hi, lo);
                 *reinterpret_cast<uint2 *>(ph + p_lds[k]) = hi;
                 if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds[k]) = lo;
             }
@@ -463,14 +435,62 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 const int ci = chunk * CV_CK + c4 * 4;
                 const bool ok = n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW && ci < g.Ci;
                 float4 v = load4<VEC>(ok ? x + (((int64_t)n * g.IH + iy) * g.IW + ix) * g.Ci + ci : x, ok, ci, g.Ci);
-                v = mul4(v, *reinterpret_cast<const float4 *>(sct + (int)(e >> 20) * cspan + (chunk - c_begin) * CV_CK + c4 * 4));
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 hi, lo;
-                split4<SPLIT>(v, hi, lo);
+                split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sct + (int)(e >> 20) * cspan + (chunk - c_begin) * CV_CK + c4 * 4), hi, lo);
                 const int off = pix * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
                 *reinterpret_cast<uint2 *>(ph + off) = hi;
                 if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + off) = lo;
             }
+        }
+    };
+    // ---- operand exponent of this block: amax of |input scale * x| over the first channel chunk's patch, which
+    // issue_patch has just put into the registers of set 0 (no extra loads: 32 channels x the whole patch), reduced over
+    // the block -> x * 2^e (conv_common.h).  An all-zero first chunk (padding, pruned channels) falls back to explicit
+    // samples over all of the block's chunks.  Called between issue_patch(c_begin) and commit_patch(c_begin).
+    auto block_exponent = [&]() {
+        float *red = reinterpret_cast<float *>(pl + t.NPP * 64);      // the spare row: not written before the first commit
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < PSET; k++) {
+            float4 v = pq[k];
+            if (!VEC && !((cur_ok[0] >> k) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iscale) v = mul4(v, *reinterpret_cast<const float4 *>(sct + p_sc[k]));
+            m = amax4(m, v);
+        }
+        m = block_amax(m, red);
+        if (m == 0.f) {                 // block-uniform
+            const int ncl = c_end - c_begin;
+#pragma unroll 1
+            for (int sidx = 0; sidx < 8; sidx++) {
+                const int pix = (threadIdx.x >> 3) + 32 * ((sidx * 5 + 1) % PSET);
+                const int chunk = c_begin + (sidx * ncl) / 8;
+                const int ci = chunk * CV_CK + c4 * 4;
+                bool ok = pix < t.NPP && ci < g.Ci;
+                int nbi = 0, n = 0, iy = 0, ix = 0;
+                if (ok) {
+                    const unsigned e = ptab[pix];
+                    nbi = (int)(e >> 20);
+                    n = n0 + nbi;
+                    iy = iy0 + (int)((e >> 10) & 1023);
+                    ix = ix0 + (int)(e & 1023);
+                    ok = n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+                }
+                float4 v = load4<VEC>(ok ? x + (((int64_t)n * g.IH + iy) * g.IW + ix) * g.Ci + ci : (VEC ? g_zero_page : x), ok, ci, g.Ci);
+                if (iscale) v = mul4(v, *reinterpret_cast<const float4 *>(sct + nbi * cspan + (chunk - c_begin) * CV_CK + c4 * 4));
+                if (ok) m = amax4(m, v);
+            }
+            __syncthreads();            // every thread has read `red`
+            m = block_amax(m, red);
+        }
+        float xs, xu;
+        cv_pow2_scale(m, xs, xu);
+        xscale = cv_uniform(xs);
+        // packed-weight exponent (trailer of the packed image)
+        unscale = cv_uniform(xu * *reinterpret_cast<const float *>(wpk + (int64_t)t.ncot * t.nchunks * g.nslices * CV_WSTEP_BYTES));
+        if (iscale) {                   // fold 2^e into the scale table
+            for (int i = threadIdx.x; i < t.nbe * cspan; i += 256) sct[i] *= xscale;
+            __syncthreads();
         }
     };
     using S0 = std::integral_constant<int, 0>;
@@ -539,7 +559,8 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             issue_wdma(c_begin, 0, 0);
             if constexpr (WDMA == 3) issue_wdma(c_begin, 1, 1);
             issue_patch(c_begin, S0{});
-            commit_patch(c_begin, S0{});          // (first use of the patch registers: hipcc drains the VM counter here)
+            block_exponent();                     // (first use of the patch registers: hipcc drains the VM counter here)
+            commit_patch(c_begin, S0{});
         } else {
         issue_patch(c_begin, S0{});
         {
@@ -548,6 +569,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             CV_WLOAD(src);
             CV_WSTORE(wbuf);
         }
+        block_exponent();
         commit_patch(c_begin, S0{});
         __syncthreads();
         }
@@ -645,6 +667,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             CV_WLOAD(src);
             CV_WSTORE(wbuf);
         }
+        block_exponent();
         commit_patch(c_begin, S0{});
         __syncthreads();
 
@@ -1342,10 +1365,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         for (int k = 0; k < 8; k++) {
             const bool ok = (okmask >> k) & 1u;
             float4 v = gq[k];
-            v = mul4(v, *reinterpret_cast<const float4 *>(sA + (ok ? (st_n0 + (int)(g_pyx[k] >> 20)) * CV_BM : 0) + gc4 * 4));
             if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 hi, lo;
-            split4<SPLIT>(v, hi, lo);
+            split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sA + (ok ? (st_n0 + (int)(g_pyx[k] >> 20)) * CV_BM : 0) + gc4 * 4), hi, lo);
             *reinterpret_cast<uint2 *>(gh + g_lds[k]) = hi;
             if (SPLIT == 2) *reinterpret_cast<uint2 *>(gl + g_lds[k]) = lo;
         }
@@ -1353,10 +1375,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         for (int k = 0; k < PMAX; k++) {
             const bool ok = (okmask >> (8 + k)) & 1u;
             float4 v = pq[k];
-            v = mul4(v, *reinterpret_cast<const float4 *>(sB + (ok ? (st_n0 + (int)(p_pyx[k] >> 20)) * CV_CK : 0) + pc4 * 4));
             if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 hi, lo;
-            split4<SPLIT>(v, hi, lo);
+            split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sB + (ok ? (st_n0 + (int)(p_pyx[k] >> 20)) * CV_CK : 0) + pc4 * 4), hi, lo);
             *reinterpret_cast<uint2 *>(ph + p_lds[k]) = hi;
             if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds[k]) = lo;
         }
@@ -1468,41 +1489,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             if constexpr (FAST) {
                 uint2 hi, lo;
                 if constexpr (K < 8) {
-                    float4 v = gq[K];
+                    const float4 v = gq[K];
                     if constexpr (FAST == 2) {     // modulated layers (G) carry per-(image, channel) scales (x block exponent)
-                        if constexpr (ONE_IMG) v = mul4(v, sa_cv);
-                        else v = mul4(v, *reinterpret_cast<const float4 *>(sA + (cv_n0 + (int)(g_pyx[K] >> 20)) * CV_BM + gc4 * 4));
-                    } else v = scale4(v, xsa);   // block exponent from an SGPR
-                    split4<SPLIT>(v, hi, lo);
+                        if constexpr (ONE_IMG) split4v<SPLIT>(v, sa_cv, hi, lo);
+                        else split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sA + (cv_n0 + (int)(g_pyx[K] >> 20)) * CV_BM + gc4 * 4), hi, lo);
+                    } else split4s<SPLIT>(v, xsa, hi, lo);   // block exponent from an SGPR
                     *reinterpret_cast<uint2 *>(buf + g_lds[K]) = hi;
                     *reinterpret_cast<uint2 *>(buf + WG_GY_BYTES + g_lds[K]) = lo;
                 } else {
-                    float4 v = pq[K - 8];
+                    const float4 v = pq[K - 8];
                     if constexpr (FAST == 2) {     // (an out-of-range item read the zero page: 0 * scale stays 0)
-                        if constexpr (ONE_IMG) v = mul4(v, sb_cv);
-                        else v = mul4(v, *reinterpret_cast<const float4 *>(sB + (cv_n0 + (int)((p_pyx[K - 8] >> 20) & 15)) * CV_CK + pc4 * 4));
-                    } else v = scale4(v, xsb);
-                    split4<SPLIT>(v, hi, lo);
+                        if constexpr (ONE_IMG) split4v<SPLIT>(v, sb_cv, hi, lo);
+                        else split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sB + (cv_n0 + (int)((p_pyx[K - 8] >> 20) & 15)) * CV_CK + pc4 * 4), hi, lo);
+                    } else split4s<SPLIT>(v, xsb, hi, lo);
                     *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + p_lds[K - 8]) = hi;
                     *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + (t.NPP + 1) * 64 + p_lds[K - 8]) = lo;
                 }
             } else if constexpr (K < 8) {
                 float4 v = gq[K];
-                if constexpr (ONE_IMG) v = mul4(v, sa_cv);
-                else v = mul4(v, *reinterpret_cast<const float4 *>(sA + (ok ? (cv_n0 + (int)(g_pyx[K] >> 20)) * CV_BM : 0) + gc4 * 4));
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 hi, lo;
-                split4<SPLIT>(v, hi, lo);
+                if constexpr (ONE_IMG) split4v<SPLIT>(v, sa_cv, hi, lo);
+                else split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sA + (ok ? (cv_n0 + (int)(g_pyx[K] >> 20)) * CV_BM : 0) + gc4 * 4), hi, lo);
                 *reinterpret_cast<uint2 *>(buf + g_lds[K]) = hi;
                 if (SPLIT == 2) *reinterpret_cast<uint2 *>(buf + WG_GY_BYTES + g_lds[K]) = lo;
             } else {
                 constexpr int P = K - 8;
                 float4 v = pq[P];
-                if constexpr (ONE_IMG) v = mul4(v, sb_cv);
-                else v = mul4(v, *reinterpret_cast<const float4 *>(sB + (ok ? (cv_n0 + (int)(p_pyx[P] >> 20)) * CV_CK : 0) + pc4 * 4));
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 hi, lo;
-                split4<SPLIT>(v, hi, lo);
+                if constexpr (ONE_IMG) split4v<SPLIT>(v, sb_cv, hi, lo);
+                else split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sB + (ok ? (cv_n0 + (int)(p_pyx[P] >> 20)) * CV_CK : 0) + pc4 * 4), hi, lo);
                 *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + p_lds[P]) = hi;
                 if (SPLIT == 2) *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + (t.NPP + 1) * 64 + p_lds[P]) = lo;
             }

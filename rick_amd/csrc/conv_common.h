@@ -78,20 +78,44 @@ __device__ __forceinline__ float block_amax(float v, float *red) {
     return m;
 }
 
-// v (already multiplied by 2^e) -> fp16 hi / lo pairs.  SPLIT == 1 (plain fp16, speed option): hi only.
-// 10 VALU per 4 elements: 2 v_cvt_pk_f16_f32, 4 v_cvt_f32_f16, 2 v_pk_add_f32, 2 v_cvt_pk_f16_f32.
+// (v * s) -> fp16 hi / lo pairs in 8 VALU per 4 elements, the scale included: v_fma_mixlo/mixhi_f16 evaluate an fp32 fma
+// and round the result ONCE to fp16 into one half of the destination register, with each source read as fp32 or as one
+// half of an fp16 pair:   hi = f16(v * s + 0),   lo = f16(v * s - hi)   (the fma is exact before the rounding, so lo is
+// the correctly rounded residual).  The cvt-based form costs 12 (2 v_pk_mul, 2 v_cvt_pk, 4 v_cvt_f32_f16, 2 v_pk_add, 2
+// v_cvt_pk) and the kernels are bound by the issue of exactly these instructions.  SPLIT == 1 (plain fp16): hi only.
+// `s` per element (input-scale table x block exponent) ...
 template <int SPLIT>
-__device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
-    const f16x2 h0 = __builtin_convertvector((f32x2_t){v.x, v.y}, f16x2);
-    const f16x2 h1 = __builtin_convertvector((f32x2_t){v.z, v.w}, f16x2);
-    hi.x = *reinterpret_cast<const unsigned *>(&h0);
-    hi.y = *reinterpret_cast<const unsigned *>(&h1);
-    if (SPLIT == 1) {
-        lo.x = lo.y = 0;
-        return;
+__device__ __forceinline__ void split4v(const float4 v, const float4 s, uint2 &hi, uint2 &lo) {
+    unsigned h0, h1, l0 = 0, l1 = 0;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(v.x), "v"(s.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(v.y), "v"(s.y));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1) : "v"(v.z), "v"(s.z));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(v.w), "v"(s.w));
+    if (SPLIT == 2) {
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(v.x), "v"(s.x), "v"(h0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(v.y), "v"(s.y), "v"(h0));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(v.z), "v"(s.z), "v"(h1));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(v.w), "v"(s.w), "v"(h1));
     }
-    lo.x = pack_f16_rne(v.x - (float)h0[0], v.y - (float)h0[1]);
-    lo.y = pack_f16_rne(v.z - (float)h1[0], v.w - (float)h1[1]);
+    hi = make_uint2(h0, h1);
+    lo = make_uint2(l0, l1);
+}
+// ... or one block-uniform scale (the exponent alone) from an SGPR.
+template <int SPLIT>
+__device__ __forceinline__ void split4s(const float4 v, const float s, uint2 &hi, uint2 &lo) {
+    unsigned h0, h1, l0 = 0, l1 = 0;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(v.x), "s"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(v.y), "s"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1) : "v"(v.z), "s"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(v.w), "s"(s));
+    if (SPLIT == 2) {
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(v.x), "s"(s), "v"(h0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(v.y), "s"(s), "v"(h0));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(v.z), "s"(s), "v"(h1));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(v.w), "s"(s), "v"(h1));
+    }
+    hi = make_uint2(h0, h1);
+    lo = make_uint2(l0, l1);
 }
 
 __device__ __forceinline__ void split1(float v, unsigned short &hi, unsigned short &lo, int split) {

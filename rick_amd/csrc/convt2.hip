@@ -101,36 +101,14 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
             }
         }
     }
-    // ---- operand exponent of this block (conv_common.h): amax of iscale * x over 8 sampled items per thread
-    // (its patch pixels x channel chunks spread over the block's range: 16384 values) -> x * 2^e
-    float unscale, xscale;
-    {
-        const int ncl = c_end - c_begin;
-        float m = 0.f;
-#pragma unroll
-        for (int sidx = 0; sidx < 8; sidx++) {
-            const int k = sidx % CT_PITEMS;
-            const int chunk = c_begin + (sidx * ncl) / 8;
-            const int ci = chunk * CV_CK + c4 * 4;
-            const bool ok = ((p_ok >> k) & 1u) && ci < P.Ci;
-            float4 v = *reinterpret_cast<const float4 *>(ok ? xt + p_rel[k] + chunk * CV_CK : g_ct2_zero_page);
-            if (iscale)
-                v = mul4(v, *reinterpret_cast<const float4 *>(ok ? iscale + (int64_t)(n0 + ((p_nbi >> (8 * k)) & 255u)) * P.Ci + ci
-                                                                 : g_ct2_zero_page));
-            m = amax4(m, v);
-        }
-        m = block_amax(m, reinterpret_cast<float *>(smem));
-        float xunscale;
-        cv_pow2_scale(m, xscale, xunscale);
-        xscale = cv_uniform(xscale);
-        // packed-weight exponent (trailer of the packed image)
-        unscale = cv_uniform(xunscale * *reinterpret_cast<const float *>(wpk + (int64_t)P.ncot * P.nchunks * 9 * CV_WSTEP_BYTES));
-        __syncthreads();                                      // every thread has read the reduction scratch
+    // per-(image, input channel) scales of the block's images and channel range; multiplied by the block exponent below
+    if (iscale) {
         for (int i = threadIdx.x; i < P.NB * cspan; i += CT_THREADS) {
             const int nbi = i / cspan, c = c_begin * CV_CK + (i - nbi * cspan);
-            sct[i] = !iscale ? xscale : (n0 + nbi < P.N && c < P.Ci) ? iscale[(int64_t)(n0 + nbi) * P.Ci + c] * xscale : 0.f;
+            sct[i] = (n0 + nbi < P.N && c < P.Ci) ? iscale[(int64_t)(n0 + nbi) * P.Ci + c] : 0.f;
         }
     }
+    float unscale = 1.f, xscale = 1.f;                        // set by block_exponent() once the first chunk is in registers
     float4 pq[CT_PITEMS];
     unsigned cur_ok = 0;
     auto issue_patch = [&](int chunk) {
@@ -148,11 +126,10 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
         auto items = [&](auto ISC) {   // one block-uniform branch around the item loop: input scale x 2^e from the table, or 2^e from an SGPR
 #pragma unroll
             for (int k = 0; k < CT_PITEMS; k++) {
-                float4 v = pq[k];       // (an out-of-range item has read the zero page)
-                if constexpr (decltype(ISC)::value) v = mul4(v, *reinterpret_cast<const float4 *>(sc + ((p_nbi >> (8 * k)) & 255u) * cspan));
-                else v = scale4(v, xscale);
+                const float4 v = pq[k];       // (an out-of-range item has read the zero page)
                 uint2 hi, lo;
-                split4<SPLIT>(v, hi, lo);
+                if constexpr (decltype(ISC)::value) split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sc + ((p_nbi >> (8 * k)) & 255u) * cspan), hi, lo);
+                else split4s<SPLIT>(v, xscale, hi, lo);
                 if (pix0 + (CT_THREADS / 8) * k < P.NPP) {        // (a branch around an LDS store is harmless; loads stay unconditional)
                     *reinterpret_cast<uint2 *>(ph + p_lds0 + k * 4096) = hi;
                     if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds0 + k * 4096) = lo;
@@ -161,6 +138,45 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
         };
         if (iscale) items(std::true_type{});
         else items(std::false_type{});
+    };
+
+    // ---- operand exponent of this block (conv_common.h): amax of |input scale * x| over the first channel chunk's patch
+    // (already in registers: 32 channels x the whole window), reduced over the block -> x * 2^e.  An all-zero first chunk
+    // falls back to explicit samples over all of the block's chunks.
+    auto block_exponent = [&]() {
+        float *red = reinterpret_cast<float *>(smem + 2 * pbuf);   // second patch buffer: not written before the chunk loop
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < CT_PITEMS; k++) {
+            float4 v = pq[k];
+            if (iscale) v = mul4(v, *reinterpret_cast<const float4 *>(sct + ((p_nbi >> (8 * k)) & 255u) * cspan + c4 * 4));
+            m = amax4(m, v);
+        }
+        m = block_amax(m, red);
+        if (m == 0.f) {                                       // block-uniform
+            const int ncl = c_end - c_begin;
+#pragma unroll 1
+            for (int sidx = 0; sidx < 8; sidx++) {
+                const int k = sidx % CT_PITEMS;
+                const int chunk = c_begin + (sidx * ncl) / 8;
+                const int ci = chunk * CV_CK + c4 * 4;
+                const bool ok = ((p_ok >> k) & 1u) && ci < P.Ci;
+                float4 v = *reinterpret_cast<const float4 *>(ok ? xt + p_rel[k] + chunk * CV_CK : g_ct2_zero_page);
+                if (iscale) v = mul4(v, *reinterpret_cast<const float4 *>(sct + ((p_nbi >> (8 * k)) & 255u) * cspan + (chunk - c_begin) * CV_CK + c4 * 4));
+                m = amax4(m, v);
+            }
+            __syncthreads();                                  // every thread has read `red`
+            m = block_amax(m, red);
+        }
+        float xs, xu;
+        cv_pow2_scale(m, xs, xu);
+        xscale = cv_uniform(xs);
+        // packed-weight exponent (trailer of the packed image)
+        unscale = cv_uniform(xu * *reinterpret_cast<const float *>(wpk + (int64_t)P.ncot * P.nchunks * 9 * CV_WSTEP_BYTES));
+        if (iscale) {                                         // fold 2^e into the scale table
+            for (int i = threadIdx.x; i < P.NB * cspan; i += CT_THREADS) sct[i] *= xscale;
+            __syncthreads();
+        }
     };
 
     // ---- B operand (patch) read offsets: position j*16 + l15 of the tile -> patch pixel (ty + 1, tx + 1)
@@ -239,7 +255,8 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
         const unsigned char *wt = wbase + ((int64_t)c_begin * 9 + tap_slice(0)) * CV_WSTEP_BYTES;
         static_for<0, 4>([&](auto IC) { load_a(IC, wt); });
     }
-    __syncthreads();                                          // scale table and position table complete
+    __syncthreads();                                          // scale table complete
+    block_exponent();
     commit_patch(c_begin, smem);
     __syncthreads();
 

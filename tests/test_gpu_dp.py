@@ -17,6 +17,9 @@ pytestmark = pytest.mark.gpu
 class _BlockingDP:
     """Reference exchange: no hooks, no buckets — average the whole gradient buffer after backward."""
 
+    hooks_enabled = True     # like the bucketed exchange in eager mode: the trainer then routes parameter gradients through
+                             # autograd (no gradient sink), so both runs execute the same arithmetic up to the exchange
+
     def __init__(self):
         self.world = torch.distributed.get_world_size()
 

@@ -703,3 +703,48 @@ def test_group_pack_equals_single_pack(O, I, k):
         multi = cv._pack(view, 0.37, (lin.w, tag)).clone()
         single = cv._pack(view, 0.37, None)
         assert torch.equal(multi, single) and not torch.equal(multi, first)
+
+
+@pytest.mark.parametrize('case', ['tiny', 'huge', 'zero_first_chunk', 'pruned_and_tiny', 'range'])
+def test_conv_operand_exponent_edge_cases(case):
+    """The fp16 hi/lo split multiplies each operand by a power of two taken from a sample of the block's own data
+    (conv_common.h).  Results must stay fp32-grade when the data sit far from 1 (gradients: 1e-8; large activations),
+    when the sampled first channel chunk is entirely zero (pruned filters: the fallback sample over all chunks) and
+    when most values are 2^-10 of the maximum (lo parts are fp16 subnormals)."""
+    from rick_amd import op
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 96, 16, 16, generator=g)
+    w = torch.randn(128, 96, 3, 3, generator=g)
+    tol = 2e-6
+    if case == 'tiny':
+        x, w = x * 1e-8, w * 1e-5
+    elif case == 'huge':
+        x = x * 3e4
+    elif case == 'zero_first_chunk':
+        x[:, :32] = 0
+    elif case == 'pruned_and_tiny':
+        x = x * 1e-9
+        x[:, :32] = 0
+        w[5] = 0
+        w[:, 40] = 0
+    elif case == 'range':
+        x = x * 2.0 ** -10
+        x[:, 0] = torch.randn(2, 16, 16, generator=g)
+        w[:, 0] = 0
+        tol = 2e-5          # lo parts of the small values are fp16 subnormals: absolute error 2^-27 of the block maximum
+    wscale = 1 / math.sqrt(96 * 9)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr * wscale, padding=1)
+    gy = torch.randn(yr.shape, generator=g) * float(yr.abs().max())
+    gxr, gwr = torch.autograd.grad(yr, (xr, wr), gy.double())
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = op.conv2d(xd, wd, 1, 1, wscale=wscale)
+    gx, gw = torch.autograd.grad(y, (xd, wd), gy.to(DEV))
+    assert torch.isfinite(y).all()
+    assert rel_err(y, yr) < tol, rel_err(y, yr)
+    assert rel_err(gx, gxr) < 2e-6, rel_err(gx, gxr)
+    assert rel_err(gw, gwr) < 2e-6, rel_err(gw, gwr)
+    # transposed stride-2 form (its own kernel)
+    yt = op.conv_transpose2d(xd, wd[:64], 2, 0, wscale=wscale)                 # weight given as [O, I, kh, kw]
+    ytr = F.conv_transpose2d(xr, (wr[:64] * wscale).transpose(0, 1), stride=2)  # torch wants [I, O, kh, kw]
+    assert rel_err(yt, ytr) < tol, rel_err(yt, ytr)
