@@ -437,7 +437,8 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 float4 v = load4<VEC>(ok ? x + (((int64_t)n * g.IH + iy) * g.IW + ix) * g.Ci + ci : x, ok, ci, g.Ci);
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 hi, lo;
-                split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sct + (int)(e >> 20) * cspan + (chunk - c_begin) * CV_CK + c4 * 4), hi, lo);
+                if (iscale) split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sct + (int)(e >> 20) * cspan + (chunk - c_begin) * CV_CK + c4 * 4), hi, lo);
+                else split4s<SPLIT>(v, xscale, hi, lo);      // (the scale table only exists with an input scale)
                 const int off = pix * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
                 *reinterpret_cast<uint2 *>(ph + off) = hi;
                 if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + off) = lo;

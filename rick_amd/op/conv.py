@@ -23,7 +23,6 @@ import threading
 import numpy as np
 import torch
 from torch.autograd import Function
-from torch.autograd.function import once_differentiable
 
 from .._lib import MAX_TAPS, ConvEpilogue, ConvGeom, check, lib, ptr, require_cuda_f32, stream_ptr
 
@@ -578,8 +577,8 @@ class _WGrad(Function):
 class _ConvBiasAct(Function):
     """EqualConv2d followed by FusedLeakyReLU (every ConvLayer of D, model_probe_tune.py:595-641) with the bias +
     LeakyReLU tail applied in the convolution's epilogue: the separate activation pass (one read + one write of the
-    feature map) disappears from the forward; values are bit-identical to conv -> fused_leaky_relu.  First order only
-    (under op.second_order() the layers run the composed, twice-differentiable ops)."""
+    feature map) disappears from the forward; values are bit-identical to conv -> fused_leaky_relu.  The hand-written
+    backward is first order; under create_graph=True the backward differentiates the composed form (op/_twice.py)."""
 
     @staticmethod
     def forward(ctx, x, w, bias, s, p, wscale, key, slope, gain):
@@ -587,6 +586,7 @@ class _ConvBiasAct(Function):
         if x.shape[1] != I:
             raise RuntimeError(f'conv: input has {x.shape[1]} channels, weight expects {I}')
         ctx.bias = bias                             # the Parameter itself (gradient sink target)
+        ctx.plike = (False, param_like(w), param_like(bias))
         bias = bias.contiguous()
         y = _conv_launch(x, _pack(w, wscale, key and (key[0], key[1] + '/conv')), O, kh, kw, s, p,
                          epi=_epilogue(bias, None, None, slope, gain))
@@ -596,12 +596,18 @@ class _ConvBiasAct(Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, g):
-        from .fused_act import _ActAdjoint, param_sink
+        from .fused_act import _ActAdjoint, fused_leaky_relu, param_sink
         x, w, y = ctx.saved_tensors
         s, p, wscale, key, slope, gain = ctx.cfg
         O, I, kh, kw = w.shape
+        if torch.is_grad_enabled():     # create_graph=True (R1): differentiate the composed, twice-differentiable form
+            from ._twice import second_order_backward
+            bias = ctx.bias
+            gx, gw, gb = second_order_backward(
+                lambda: fused_leaky_relu(_Conv.apply(x, w, s, p, wscale, key), bias, slope, gain),
+                (x, w, bias), ctx.needs_input_grad[:3], g, ctx.plike)
+            return gx, gw, gb, None, None, None, None, None, None
         want_b = ctx.needs_input_grad[2]
         gz, gb, _ = _ActAdjoint.apply(g, y, None, slope, gain, want_b, False, param_sink(ctx.bias, O, ctx.sink and want_b))
         gx = gw = None

@@ -10,7 +10,6 @@ into autograd as a family closed under differentiation (needed by R1 / path-leng
 """
 import torch
 from torch.autograd import Function
-from torch.autograd.function import once_differentiable
 
 from .._lib import check, lib, ptr, require_cuda_f32, stream_ptr
 
@@ -222,12 +221,24 @@ class _ToRGB(Function):
               'rick_torgb_fwd_f32')
         ctx.save_for_backward(x, w, s)
         ctx.wscale, ctx.bias_shape = wscale, (bias.shape if bias is not None else None)
+        ctx.bias_add = (bias, add)      # (only used by the create_graph route; bias is a Parameter, add the upsampled skip)
         return t
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, g):
         x, w, s = ctx.saved_tensors
+        if torch.is_grad_enabled():     # create_graph=True: per-sample weights + the thin product (closed under differentiation)
+            from ._twice import second_order_backward
+            bias, add = ctx.bias_add
+            J, c = w.shape
+
+            def compose():
+                out = _ThinFwd.apply(x, (ctx.wscale * w.view(1, J, c)) * s.unsqueeze(1))
+                if bias is not None:
+                    out = out + bias.view(1, J, 1, 1)
+                return out if add is None else out + add
+            res = second_order_backward(compose, (x, w, s, bias, add), ctx.needs_input_grad[:5], g)
+            return (*res, None)
         g = g.contiguous()
         n, J, h, wd = g.shape
         c = w.shape[1]
@@ -265,28 +276,36 @@ def thin_bwdx(t, W):
 
 # ------------------------------------------------------------------- minibatch stddev
 class _MbStd(Function):
-    """First-order HIP path.  Second-order callers use the composite below."""
+    """HIP path with a hand-written first-order backward; under create_graph=True the backward differentiates the
+    composite below (op/_twice.py)."""
 
     @staticmethod
-    def forward(ctx, x, groups):
-        x = _nhwc(x)
+    def forward(ctx, x_in, groups, stddev=(25, 1)):
+        x = _nhwc(x_in)
         b, c, h, w = x.shape
         out = torch.empty((b, c + 1, h, w), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
         stat = torch.empty(groups, device=x.device, dtype=x.dtype)
         check(lib.rick_mbstd_fwd_f32(ptr(x), ptr(out), ptr(stat), b, h * w, c, groups, stream_ptr()), 'rick_mbstd_fwd_f32')
-        ctx.save_for_backward(x)
-        ctx.groups = groups
+        ctx.save_for_backward(x if x is x_in else x_in)
+        ctx.groups, ctx.stddev = groups, stddev
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
+        if torch.is_grad_enabled():     # create_graph=True (R1): the formula composed from tensor ops, per concatenated call
+            from ._twice import second_order_backward
+            calls, sg, sf = ctx.groups, ctx.stddev
+            (gx,) = second_order_backward(
+                lambda: (_mbstd_composite(x, sg, sf) if calls == 1
+                         else torch.cat([_mbstd_composite(xc, sg, sf) for xc in x.chunk(calls)], 0)), (x,), (True,), g)
+            return gx, None, None
         g = _nhwc(g)
+        x = _nhwc(x)
         b, c, h, w = x.shape
         gx = torch.empty_like(x)
         check(lib.rick_mbstd_bwd_f32(ptr(x), ptr(g), ptr(gx), b, h * w, c, ctx.groups, stream_ptr()), 'rick_mbstd_bwd_f32')
-        return gx, None
+        return gx, None, None
 
 
 def _mbstd_composite(x, stddev_group, stddev_feat):
@@ -311,7 +330,7 @@ def minibatch_stddev(x, stddev_group=25, stddev_feat=1, second_order=False, call
         raise RuntimeError('minibatch_stddev: batch not divisible by the number of concatenated calls')
     per = b // calls
     if per <= stddev_group and stddev_feat == 1 and not second_order:
-        return _MbStd.apply(x, calls)
+        return _MbStd.apply(x, calls, (stddev_group, stddev_feat))
     if calls == 1:
         return _mbstd_composite(x, stddev_group, stddev_feat)
     return torch.cat([_mbstd_composite(xc, stddev_group, stddev_feat) for xc in x.chunk(calls)], 0)

@@ -8,7 +8,8 @@ convolution over the whole batch (GEMM M = B*H*W) with the modulation folded int
 load (iscale) and the demodulation into the epilogue (oscale) of the MFMA kernel.
 
 Two implementations with identical values:
-  * `modulated_conv_fused`   one kernel per direction, first-order backward only
+  * `modulated_conv_fused`   one kernel per direction; hand-written first-order backward, and under create_graph=True a
+                              backward that differentiates the composed form below (op/_twice.py)
   * `modulated_conv_composed` chan_scale -> conv -> chan_scale from the closed primitive
                               family, differentiable to any order (used under op.second_order()).
 """
@@ -17,11 +18,10 @@ import ctypes
 import numpy as np
 import torch
 from torch.autograd import Function
-from torch.autograd.function import once_differentiable
 
 from .._lib import check, lib, ptr, require_cuda_f32, stream_ptr
 from .conv import (_conv_launch, _convT_launch, _epilogue, _pack, _sink_target, _wgrad_launch, conv2d, conv_transpose2d,
-                   grad_sink_enabled)
+                   grad_sink_enabled, param_like)
 from .misc import _chan_scale_raw, _hw_dot_raw, chan_scale
 
 
@@ -42,13 +42,14 @@ def modulated_conv_composed(x, w, s, d, wscale, upsample, key=None):
 
 
 class _DemodFused(Function):
-    """demod_coeff as two launches forward (wsq, d) and two backward (gs; gw), first order only — the tensor-algebra
+    """demod_coeff as two launches forward (wsq, d) and two backward (gs; gw) — the tensor-algebra
     form above costs ~8 launches forward and ~16 backward per layer, which is what this latency-bound corner of
     the network is made of.  Under op.second_order() the composed form is used instead."""
 
     @staticmethod
     def forward(ctx, w, s, wscale, eps, key=None):
         O, I, kh, kw = w.shape
+        w_in, s_in = w, s
         w = w.contiguous()
         s = s.contiguous()
         B = s.shape[0]
@@ -56,17 +57,22 @@ class _DemodFused(Function):
         d = torch.empty((B, O), device=w.device, dtype=w.dtype)
         check(lib.rick_wsq_f32(ptr(w), ptr(wsq), O, I, kh * kw, float(wscale), stream_ptr()), 'rick_wsq_f32')
         check(lib.rick_demod_f32(ptr(s), ptr(wsq), ptr(d), B, I, O, float(eps), stream_ptr()), 'rick_demod_f32')
-        ctx.save_for_backward(w, s, wsq, d)
-        ctx.wscale = float(wscale)
+        ctx.save_for_backward(w, s, wsq, d, w_in, s_in)      # (the inputs themselves: .contiguous() may have copied them)
+        ctx.wscale, ctx.eps = float(wscale), float(eps)
+        ctx.w_param = param_like(w)
         ctx.key, ctx.sink = key, grad_sink_enabled()
         return d
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gd):
-        w, s, wsq, d = ctx.saved_tensors
+        w, s, wsq, d, w_in, s_in = ctx.saved_tensors
         O, I, kh, kw = w.shape
         B = s.shape[0]
+        if torch.is_grad_enabled():     # create_graph=True: the tensor-algebra form, differentiable to any order
+            from ._twice import second_order_backward
+            gw, gs = second_order_backward(lambda: demod_coeff(w_in, s_in, ctx.wscale, ctx.eps), (w_in, s_in),
+                                           ctx.needs_input_grad[:2], gd, (ctx.w_param, False))
+            return gw, gs, None, None, None
         gd = gd.contiguous()
         gw = gs = None
         if ctx.needs_input_grad[1]:
@@ -99,10 +105,12 @@ class _ModConvFused(Function):
     @staticmethod
     def forward(ctx, x, w, s, d, wscale, upsample, key, bias, noise, nw, slope, gain):
         O, I, kh, kw = w.shape
+        s_in, d_in = s, d
         s = s.contiguous()
         d = d.contiguous() if d is not None else None
         tail = bias is not None
         tail_params = (bias, nw)                  # the Parameters themselves (gradient sink targets)
+        ctx.plike = (param_like(w), param_like(bias), param_like(nw))
         wp = _pack(w, wscale, key and (key[0], key[1] + ('/convT' if upsample else '/conv')))
         if upsample:
             if tail:
@@ -115,17 +123,32 @@ class _ModConvFused(Function):
         else:
             y = _conv_launch(x, wp, O, kh, kw, 1, kh // 2, iscale=s, oscale=d)
         ctx.save_for_backward(x, w, s, d, y, *((bias, noise, nw) if tail else ()))
+        ctx.sd_in = None if (s is s_in and d is d_in) else (s_in, d_in)     # only when .contiguous() copied (never in the networks)
         ctx.tail_params = tail_params
         ctx.cfg = (wscale, upsample, key, tail, slope, gain)
         ctx.sink = grad_sink_enabled()
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, g):
         x, w, s, d, y = ctx.saved_tensors[:5]
         wscale, upsample, key, tail, slope, gain = ctx.cfg
         O, I, kh, kw = w.shape
+        if torch.is_grad_enabled():     # create_graph=True (path length): differentiate the composed form
+            from ._twice import second_order_backward
+            from .fused_act import fused_noise_bias_act
+            bias, nw = ctx.tail_params
+            noise = ctx.saved_tensors[6] if tail else None
+            if ctx.sd_in is not None:
+                s, d = ctx.sd_in
+
+            def compose():
+                yc = modulated_conv_composed(x, w, s, d, wscale, upsample, key)
+                return fused_noise_bias_act(yc, bias, noise, nw, slope, gain) if tail else yc
+            gx, gw, gs, gd, gb, gnw = second_order_backward(
+                compose, (x, w, s, d, bias, nw), [ctx.needs_input_grad[i] for i in (0, 1, 2, 3, 7, 9)], g,
+                (False, ctx.plike[0], False, False, ctx.plike[1], ctx.plike[2]))
+            return (gx, gw, gs, gd, None, None, None, gb, None, gnw, None, None)
         g = g.contiguous(memory_format=torch.channels_last)
         gx = gs = gw = gd = gb = gnw = None
         if tail:
@@ -316,11 +339,19 @@ class _ModBank(Function):
         return tuple(res)
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, *gs):
         (latent,) = ctx.saved_tensors
         bank = ctx.bank
         B, n_latent, K = latent.shape
+        if torch.is_grad_enabled():     # create_graph=True: per-layer linears (plain tensor algebra)
+            from ._twice import second_order_backward
+            params = bank.params()
+
+            def compose():
+                return tuple(torch.addmm(params[2 * i + 1], latent[:, bank.lat_idx[i]], params[2 * i].t(), alpha=bank.scale)
+                             for i in range(len(bank.C)))
+            res = second_order_backward(compose, [latent, None] + params, ctx.needs_input_grad, gs)
+            return tuple(res)
         if ctx.needs_input_grad[0]:
             raise RuntimeError('ModulationBank produces no latent gradient; use the per-layer path when the latent requires grad')
         need = ctx.needs_input_grad[2:]

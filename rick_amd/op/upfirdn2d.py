@@ -15,7 +15,6 @@ import torch
 import ctypes
 
 from torch.autograd import Function
-from torch.autograd.function import once_differentiable
 
 from .._lib import check, lib, ptr, require_cuda_f32, stream_ptr
 
@@ -93,7 +92,8 @@ class _FirAct(Function):
     """upfirdn2d (4x4 taps, up = down = 1, channels-last) followed by NoiseInjection + bias + LeakyReLU in the SAME
     launch (rick_upfirdn2d_act_f32): the blur after an upsampling StyledConv and its activation tail
     (model_probe_tune.py:263-268, 343-346) without the intermediate feature map round trip.  Bit-identical to
-    upfirdn2d -> fused_noise_bias_act.  First order only."""
+    upfirdn2d -> fused_noise_bias_act.  Hand-written first-order backward; under create_graph=True the backward
+    differentiates that two-op form (op/_twice.py)."""
 
     @staticmethod
     def forward(ctx, x, taps, pad4, bias, noise, nw, slope, gain):
@@ -102,6 +102,7 @@ class _FirAct(Function):
         n, c, h, w = x.shape
         kh, kw = taps.shape
         oh, ow = h + pad4[2] + pad4[3] - kh + 1, w + pad4[0] + pad4[1] - kw + 1
+        x_in = x
         x = x.contiguous(memory_format=torch.channels_last)
         bias = bias.contiguous()
         noise = noise.contiguous()
@@ -110,19 +111,26 @@ class _FirAct(Function):
         tail = _epilogue(bias, noise, nw, slope, gain)
         check(lib.rick_upfirdn2d_act_f32(ptr(x), ptr(taps), ptr(y), n, h, w, c, kh, kw, 1, 1, 1, 1, pad4[0], pad4[1],
                                          pad4[2], pad4[3], ctypes.byref(tail), stream_ptr()), 'rick_upfirdn2d_act_f32')
-        ctx.save_for_backward(y, noise)
+        ctx.save_for_backward(y, noise, x_in, taps)       # (x only for the create_graph route; no copy: it is the op's input)
+        ctx.pad4 = pad4
         ctx.flipped = _flipped(taps)
         ctx.cfg = (slope, gain, (kw - pad4[0] - 1, w - ow + pad4[0], kh - pad4[2] - 1, h - oh + pad4[2]))
         return y
 
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, g):
-        from .fused_act import _ActAdjoint, param_sink
-        y, noise = ctx.saved_tensors
+        from .fused_act import _ActAdjoint, fused_noise_bias_act, param_sink
+        y, noise, x_in, taps = ctx.saved_tensors
         slope, gain, adj = ctx.cfg
         bias, nw, sink = ctx.params
+        if torch.is_grad_enabled():     # create_graph=True: blur -> activation from the twice-differentiable ops
+            from ._twice import second_order_backward
+            pad4 = ctx.pad4
+            gx, gb, gw = second_order_backward(
+                lambda: fused_noise_bias_act(_UpFirDn.apply(x_in, taps, (1, 1), (1, 1), pad4), bias, noise, nw, slope, gain),
+                (x_in, bias, nw), [ctx.needs_input_grad[i] for i in (0, 3, 5)], g)
+            return (gx, None, None, gb, None, gw, None, None)
         want_b, want_w = ctx.needs_input_grad[3], ctx.needs_input_grad[5]
         gz, gb, gw = _ActAdjoint.apply(g, y, noise, slope, gain, want_b, want_w,
                                        param_sink(bias, y.shape[1], sink and want_b), param_sink(nw, 1, sink and want_w))
@@ -132,7 +140,7 @@ class _FirAct(Function):
 
 def upfirdn2d_noise_bias_act(input, kernel, pad, bias, noise, noise_weight, negative_slope=0.2, gain=2 ** 0.5):
     """gain * lrelu(upfirdn2d(input, kernel, pad=pad) + bias + noise_weight * noise) — one launch when the fused
-    path applies (4x4 taps, C % 64 == 0), the two separate ops otherwise.  First-order autograd."""
+    path applies (4x4 taps, C % 64 == 0), the two separate ops otherwise."""
     require_cuda_f32(input, kernel, bias, noise, noise_weight)
     if kernel.shape == (4, 4) and input.shape[1] % 64 == 0 and input.shape[0] <= 65535:
         return _FirAct.apply(input, kernel.contiguous(), (pad[0], pad[1], pad[0], pad[1]), bias, noise, noise_weight,

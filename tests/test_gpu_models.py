@@ -37,17 +37,20 @@ def grad2(named, grads):
     return {k: (float((g.double() ** 2).sum()) if g is not None else 0.0) for (k, _), g in zip(named, grads)}
 
 
-def check_grad2(got, gold, prefix, tol, key_tol=2e-2):
+def check_grad2(got, gold, prefix, tol, key_tol=2e-4, noise_tol=3e-2):
     """Per-key sum(g^2) vs golden.  The networks are piecewise linear (LeakyReLU): two arithmetics can
     disagree on the sign of a pre-activation that is ~0, which perturbs a few gradient entries by O(1) of
-    their own size.  How much that is worth is MEASURED, not assumed: the reference's own fp32 and fp64 runs
-    differ by <= 2e-5 per key (noise strengths: <= 9e-3) — tests/test_oracle_vs_golden.py::
-    test_reference_fp32_vs_fp64_spread on tests/golden/spread256.npz — and the bf16x3 path (2^-16 per
-    product instead of 2^-24) sits 2.4e-4 (median) / 3.5e-4 (max) from either on D and 5.4e-4 / 1.1e-3 on G
-    at 256 px, noise strengths up to 2.2e-2 (tools/diag_grad2_spread.py on MI355X).  Bounds: MEDIAN relative
-    error over keys < tol, each key within key_tol (first order: 5e-3 = 5x the measured worst key; the
-    second-order R1 / path-length gradients keep 2e-2), noise strengths 1e-1, and keys whose gradient norm
-    is < 0.3 % of the largest one only within 1e-5 of the largest sum."""
+    their own size.  How much that is worth is MEASURED, not assumed (tools/diag_grad2_spread.py on MI355X, 256 px,
+    against the reference's fp64 run; the reference's OWN fp32-vs-fp64 spread in brackets, pinned by
+    tests/test_oracle_vs_golden.py::test_reference_fp32_vs_fp64_spread on tests/golden/spread256.npz):
+        first order   D: median 2.8e-6, max 3.9e-5 [1.2e-6, 2.2e-5]     G: median 8.3e-6, p90 7.2e-5 [3.3e-6, 2.1e-5],
+                      noise strengths 6.4e-3 [9.0e-3]
+        R1            median 2.9e-5, max 8.6e-4 [1.3e-6, 3.0e-4]
+        path length   median 1.2e-4, p90 4.8e-4, noise strengths 2.2e-2 [2.0e-4, 1.1e-3, 1.0e-2]
+    (fp16 hi/lo split MFMA: 2^-22 per operand; the bf16 split of rounds 1-2 sat at 2.4e-4 ... 3e-2 on the same rows).
+    Bounds: MEDIAN relative error over keys < tol, each key within key_tol, noise strengths (scalar sums over a whole
+    feature map with heavy cancellation) within noise_tol, and keys whose gradient norm is < 0.3 % of the largest one
+    only within 1e-5 of the largest sum."""
     top = max(float(gold[f'{prefix}/{k}']) for k in got)
     rels = []
     for k, v in got.items():
@@ -56,9 +59,7 @@ def check_grad2(got, gold, prefix, tol, key_tol=2e-2):
             assert v <= 1e-12 * top, (k, v)
             continue
         rels.append(abs(v - ref) / ref)
-        # scalar parameters (noise strengths) are sums over a whole feature map with heavy cancellation:
-        # one flipped LeakyReLU moves them by percents (the fp32 CPU reference run shows the same spread)
-        lim = 1e-1 if k.endswith('noise.weight') else key_tol
+        lim = noise_tol if k.endswith('noise.weight') else key_tol
         assert abs(v - ref) < lim * ref + 1e-5 * top, f'{prefix}/{k}: {v} vs {ref} (rel {rels[-1]:.2e})'
     med = float(np.median(rels))
     assert med < tol, f'{prefix}: median relative error {med:.2e} >= {tol:.1e}'
@@ -97,40 +98,56 @@ def model_case(gold, tag, size, B, tol, latents=None):
     assert rel(g_loss, gold[f'{tag}/g_loss']) < tol
     gd = torch.autograd.grad(d_loss, [p for _, p in dp], retain_graph=True, allow_unused=True)
     gg = torch.autograd.grad(g_loss, [p for _, p in gp], retain_graph=True, allow_unused=True)
-    check_grad2(grad2(dp, gd), gold, f'{tag}/d_grad2', 20 * tol, key_tol=5e-3)
-    check_grad2(grad2(gp, gg), gold, f'{tag}/g_grad2', 20 * tol, key_tol=5e-3)
+    check_grad2(grad2(dp, gd), gold, f'{tag}/d_grad2', 5 * tol)
+    check_grad2(grad2(gp, gg), gold, f'{tag}/g_grad2', 5 * tol, key_tol=3e-4)
 
+    # second order WITHOUT op.second_order(): the ops choose the twice-differentiable route themselves when a backward pass
+    # runs under create_graph=True, like the reference's (op/fused_act.py:19-48, op/upfirdn2d.py:19-85)
+    real_r = real.clone().requires_grad_(True)
+    rp, _ = d(real_r)
+    r1 = d_r1_loss(rp, real_r)
+    assert rel(r1, gold[f'{tag}/r1']) < 5 * tol, rel(r1, gold[f'{tag}/r1'])          # north-star bar: 1e-3
+    gr1 = torch.autograd.grad(10 / 2 * r1 * 16 + 0 * rp[0].sum(), [p for _, p in dp], allow_unused=True)
+    check_grad2(grad2(dp, gr1), gold, f'{tag}/r1_grad2', 10 * tol, key_tol=3e-3)       # 10x the reference's own spread
+
+    pb = max(1, B // 2)
+    img, lat = g([z[:pb]], return_latents=True, randomize_noise=False)
+    pl_noise = synth_tensor(f'plnoise/{size}', img.shape).to(DEV)
+    pen, _, lens = g_path_regularize(img, lat, 0, noise=pl_noise)
+    assert rel(lens, gold[f'{tag}/pl_lengths']) < 20 * tol, rel(lens, gold[f'{tag}/pl_lengths'])
+    assert rel(pen, gold[f'{tag}/pl_loss']) < 20 * tol, rel(pen, gold[f'{tag}/pl_loss'])
+    gpl = torch.autograd.grad(8 * pen + 0 * img[0, 0, 0, 0], [p for _, p in gp], allow_unused=True)
+    check_grad2(grad2(gp, gpl), gold, f'{tag}/pl_grad2', 50 * tol, key_tol=1e-2, noise_tol=6e-2)
+
+    # ... and with the caller-side hint (the trainer's route): same values
     with op.second_order():
         real_r = real.clone().requires_grad_(True)
         rp, _ = d(real_r)
-        r1 = d_r1_loss(rp, real_r)
-        assert rel(r1, gold[f'{tag}/r1']) < 20 * tol
-        gr1 = torch.autograd.grad(10 / 2 * r1 * 16 + 0 * rp[0].sum(), [p for _, p in dp], allow_unused=True)
-        check_grad2(grad2(dp, gr1), gold, f'{tag}/r1_grad2', 50 * tol)
-
-        pb = max(1, B // 2)
+        r1h = d_r1_loss(rp, real_r)
+        assert rel(r1h, gold[f'{tag}/r1']) < 5 * tol
+        gr1 = torch.autograd.grad(10 / 2 * r1h * 16 + 0 * rp[0].sum(), [p for _, p in dp], allow_unused=True)
+        check_grad2(grad2(dp, gr1), gold, f'{tag}/r1_grad2', 10 * tol, key_tol=3e-3)
         img, lat = g([z[:pb]], return_latents=True, randomize_noise=False)
-        pl_noise = synth_tensor(f'plnoise/{size}', img.shape).to(DEV)
         pen, _, lens = g_path_regularize(img, lat, 0, noise=pl_noise)
         assert rel(lens, gold[f'{tag}/pl_lengths']) < 20 * tol
         assert rel(pen, gold[f'{tag}/pl_loss']) < 20 * tol
         gpl = torch.autograd.grad(8 * pen + 0 * img[0, 0, 0, 0], [p for _, p in gp], allow_unused=True)
-        check_grad2(grad2(gp, gpl), gold, f'{tag}/pl_grad2', 50 * tol)
+        check_grad2(grad2(gp, gpl), gold, f'{tag}/pl_grad2', 50 * tol, key_tol=1e-2, noise_tol=6e-2)
     return g, d
 
 
 def test_small_models_vs_reference_golden(golden):
     """32 px / 16 px networks (512 channels) against fp64 outputs of the reference modules;
-    1e-3 relative is the north-star bar, the bf16x3 MFMA path is held to 1e-4 here."""
-    model_case(golden('small'), 's32_f64', 32, 2, 1e-4)
-    model_case(golden('small'), 's16_f64', 16, 4, 1e-4)
+    1e-3 relative is the north-star bar, the fp16 hi/lo split MFMA path is held to 2e-5 here."""
+    model_case(golden('small'), 's32_f64', 32, 2, 2e-5)
+    model_case(golden('small'), 's16_f64', 16, 4, 2e-5)
 
 
 def test_full_256_vs_reference_golden(golden):
     """BASELINE config shape (256 px) on the shipped _noise/0000-0001 latents, reference fp32 CPU run."""
     gold = golden('full256')
     lat = torch.from_numpy(np.concatenate([golden('noise_latents')[f'noise_{j:04d}'] for j in range(2)], 0))
-    g, d = model_case(gold, 'f256', 256, 2, 5e-4, latents=lat)   # north-star bar: 1e-3 relative fp32
+    g, d = model_case(gold, 'f256', 256, 2, 2e-5, latents=lat)   # north-star bar: 1e-3 relative fp32
 
     # Fisher sample j = 0 (batch 1, fixed noise buffers) -> per-filter FIM vectors
     from rick_amd.train import (d_filter_fim, d_logistic_loss, g_filter_fim, g_nonsaturating_loss)
@@ -140,18 +157,18 @@ def test_full_256_vs_reference_golden(golden):
     rp, _ = d(real[0:1])
     g_loss = g_nonsaturating_loss(fp)
     d_loss = d_logistic_loss(rp, fp)
-    assert rel(g_loss, gold['fisher/g_loss']) < 5e-4
-    assert rel(d_loss, gold['fisher/d_loss']) < 5e-4
+    assert rel(g_loss, gold['fisher/g_loss']) < 5e-5
+    assert rel(d_loss, gold['fisher/d_loss']) < 5e-5
     _, fg = g.estimate_fisher(g_loss)
     _, fd = d.estimate_fisher(d_loss)
-    check_grad2({k: float(v.double().sum()) for k, v in fg.items()}, gold, 'fisher/g_sum', 2e-3)
-    check_grad2({k: float(v.double().sum()) for k, v in fd.items()}, gold, 'fisher/d_sum', 2e-3)
+    check_grad2({k: float(v.double().sum()) for k, v in fg.items()}, gold, 'fisher/g_sum', 2e-4, key_tol=2e-3)
+    check_grad2({k: float(v.double().sum()) for k, v in fd.items()}, gold, 'fisher/d_sum', 2e-4, key_tol=2e-3)
     conv, fc = g_filter_fim(fg)
     for k in range(12):
-        assert l2rel(conv[f'convs.{k}.conv.weight'], gold[f'fisher/g_conv/{k}']) < 5e-3
-        assert l2rel(fc[f'convs.{k}.conv.modulation.weight'], gold[f'fisher/g_fc/{k}']) < 5e-3
+        assert l2rel(conv[f'convs.{k}.conv.weight'], gold[f'fisher/g_conv/{k}']) < 1e-3
+        assert l2rel(fc[f'convs.{k}.conv.modulation.weight'], gold[f'fisher/g_fc/{k}']) < 1e-3
     for k, v in d_filter_fim(fd).items():
-        assert l2rel(v, gold[f'fisher/d/{k}']) < 5e-3, k
+        assert l2rel(v, gold[f'fisher/d/{k}']) < 1e-3, k
 
 
 def test_trainer_steps_match_oracle():
@@ -200,7 +217,7 @@ def test_trainer_steps_match_oracle():
             lo, hi = flat.segment(k)
             p0, g_ref = masked(before[k], ref_grads[k], k, freeze, zero)
             g_dev = flat.grad[lo:hi].view(p0.shape).double().cpu()
-            assert l2rel(g_dev, g_ref) < (4e-3 if g_ref.numel() >= 16 else 3e-2), ('grad', k)   # scalars: cancellation
+            assert l2rel(g_dev, g_ref) < (2e-4 if g_ref.numel() >= 16 else 1e-2), ('grad', k, l2rel(g_dev, g_ref))   # scalars: cancellation
             exp, _, _ = adam_step_ref(p0, g_dev, torch.zeros_like(p0), torch.zeros_like(p0), 1, lr, 0.0, b2)
             assert rel(named_after[k], exp) < 2e-6, ('adam', k)
 
@@ -216,7 +233,7 @@ def test_trainer_steps_match_oracle():
     gd = dict(zip(dkeys, torch.autograd.grad(dl, [sd[k] for k in dkeys])))
     before = {k: sd[k].detach().clone() for k in dkeys}
     d_loss = tr.d_step(real.to(DEV), [z.to(DEV)], g_noise=dev_noises)
-    assert rel(d_loss, dl.detach()) < 1e-4
+    assert rel(d_loss, dl.detach()) < 1e-5
     got = dict(d.named_parameters())
     check_step(tr.d_flat, before, gd, dkeys, cfg.lr * 16 / 17, 0.99 ** (16 / 17), freeze_d, zero_d, got)
     assert float(got['convs.2.skip.1.weight'][[0, 3]].abs().max()) == 0.0
@@ -232,7 +249,7 @@ def test_trainer_steps_match_oracle():
     gg = dict(zip(gkeys, torch.autograd.grad(gl, [sg[k] for k in gkeys])))
     before = {k: sg[k].detach().clone() for k in gkeys}
     g_loss = tr.g_step([z.to(DEV)], g_noise=dev_noises)
-    assert rel(g_loss, gl.detach()) < 1e-4
+    assert rel(g_loss, gl.detach()) < 1e-5
     got = dict(g.named_parameters())
     check_step(tr.g_flat, before, gg, gkeys, cfg.lr * 4 / 5, 0.99 ** (4 / 5), freeze_g, zero_g, got)
 
@@ -242,15 +259,15 @@ def test_trainer_steps_match_oracle():
     rp, _ = discriminator_ref(sd3, rr, size=size)
     r1_ref = d_r1_loss_ref(rp, rr)
     r1 = tr.r1_step(real.to(DEV))
-    assert rel(r1, r1_ref.detach()) < 1e-3
+    assert rel(r1, r1_ref.detach()) < 1e-4
     sg3 = {k: v.detach().double().cpu().requires_grad_(True) for k, v in g.state_dict().items()}
     pl_noise = synth_tensor('plnoise/trainer', (1, 3, size, size))
     img, lat = generator_ref(sg3, [z[:1].double()], size=size, return_latents=True,
                              noise=[sg3[f'noises.noise_{i}'] for i in range(g.num_layers)])
     pen_ref, mean_ref, _ = g_path_regularize_ref(img, lat, 0, pl_noise.double())
     pen = tr.plr_step([z[:1].to(DEV)], pl_noise=pl_noise.to(DEV), g_noise=dev_noises)
-    assert rel(pen, pen_ref.detach()) < 2e-3
-    assert rel(tr.mean_path_length, mean_ref) < 1e-3
+    assert rel(pen, pen_ref.detach()) < 2e-4
+    assert rel(tr.mean_path_length, mean_ref) < 1e-4
     tr.ema_step()
 
 
@@ -336,16 +353,17 @@ def test_rick_loop_body_256_batch4_vs_reference(golden):
         return out
 
     d_loss = tr.d_step(real, [z['d']], g_noise=noises)
-    assert rel(d_loss, gold['step/d_loss']) < 5e-4
-    assert abs(float(tr.losses['real_score']) - float(gold['step/real_pred'].mean())) < 2e-3 * max(1.0, abs(float(gold['step/real_pred'].mean())))
-    assert abs(float(tr.losses['fake_score']) - float(gold['step/fake_pred'].mean())) < 2e-3 * max(1.0, abs(float(gold['step/fake_pred'].mean())))
-    _check_summaries(gold, 'step/d_grad', flat_grads(tr.d_flat, dp), 'D grad', 0.0, 3e-3, 2e-3)
+    assert rel(d_loss, gold['step/d_loss']) < 5e-5
+    assert abs(float(tr.losses['real_score']) - float(gold['step/real_pred'].mean())) < 2e-4 * max(1.0, abs(float(gold['step/real_pred'].mean())))
+    assert abs(float(tr.losses['fake_score']) - float(gold['step/fake_pred'].mean())) < 2e-4 * max(1.0, abs(float(gold['step/fake_pred'].mean())))
+    _check_summaries(gold, 'step/d_grad', flat_grads(tr.d_flat, dp), 'D grad', 0.0, 3e-4, 1e-4)
     _check_summaries(gold, 'step/d_param', dp, 'D param after Adam', 2e-5, 1e-5, 1e-4)
 
     r1 = tr.r1_step(real)
-    # R1 is a second-order quantity (|dD/dx|^2 ~ 5e-5 here): the pre-step 256-px case above already needs 1e-2
-    assert rel(r1, gold['step/r1_loss']) < 1.5e-2
-    _check_summaries(gold, 'step/r1_grad', flat_grads(tr.d_flat, dp), 'R1 grad', 0.0, 3e-2, 2.5e-2)
+    # R1 is a second-order quantity (|dD/dx|^2 ~ 5e-5 here) evaluated on a discriminator that has already taken one
+    # sign-like Adam step on either side; north-star bar 1e-3
+    assert rel(r1, gold['step/r1_loss']) < 1e-3, rel(r1, gold['step/r1_loss'])
+    _check_summaries(gold, 'step/r1_grad', flat_grads(tr.d_flat, dp), 'R1 grad', 0.0, 5e-3, 3e-3)
     _check_summaries(gold, 'step/r1_param', dp, 'D param after R1 Adam', 4e-4, 1e-5, 3e-4)
 
     g_loss = tr.g_step([z['g']], g_noise=noises)
@@ -356,10 +374,10 @@ def test_rick_loop_body_256_batch4_vs_reference(golden):
     _check_summaries(gold, 'step/g_param', gp, 'G param after Adam', 2e-5, 1e-5, 1e-4)
 
     pen = tr.plr_step([z['plr']], pl_noise=pl_noise, g_noise=noises)
-    assert rel(pen, gold['step/path_loss']) < 5e-3
-    assert rel(tr.losses['path_length'], gold['step/path_lengths'].mean()) < 2e-3
-    assert rel(tr.mean_path_length, gold['step/mean_path_length']) < 2e-3
-    _check_summaries(gold, 'step/pl_grad', flat_grads(tr.g_flat, gp), 'path-length grad', 0.0, 3e-2, 2.5e-2)
+    assert rel(pen, gold['step/path_loss']) < 1e-3, rel(pen, gold['step/path_loss'])
+    assert rel(tr.losses['path_length'], gold['step/path_lengths'].mean()) < 1e-3
+    assert rel(tr.mean_path_length, gold['step/mean_path_length']) < 1e-3
+    _check_summaries(gold, 'step/pl_grad', flat_grads(tr.g_flat, gp), 'path-length grad', 0.0, 2e-2, 1e-2)
     # second Adam step on a gradient that itself carries ~2 % noise: update error ~ lr * 2 % = 4e-5 typical, tails 4e-4
     _check_summaries(gold, 'step/pl_param', gp, 'G param after path-length Adam', 4e-4, 1e-5, 3e-4)
 
