@@ -15,20 +15,27 @@ from .conv import skip_param_grad
 
 
 def second_order_backward(compose, inputs, needs, grad_outputs, param_like=None):
-    """Gradients of ``compose()`` (a tensor or tuple rebuilt from `inputs` by twice-differentiable ops) w.r.t. the
-    inputs flagged in `needs`, with the graph kept.  `param_like[i]`: input i is a leaf parameter whose gradient an
-    enclosing ``op.no_param_grads()`` block does not want."""
+    """LOCAL gradients of ``compose(*aliases)`` (a tensor or tuple rebuilt from the op's inputs by twice-differentiable
+    ops) w.r.t. the inputs flagged in `needs`, with the graph kept.
+
+    The inputs may depend on each other upstream (the demodulation coefficients d are a function of the style scales s):
+    differentiating a graph built on the input tensors themselves would let the gradient w.r.t. s leak through d's
+    history and count that path twice.  The graph is therefore built on ALIASES (``t.view_as(t)``): a partial derivative
+    w.r.t. an alias follows only the op's own use of that input, while the result stays a differentiable function of the
+    original tensors (the alias is a view of them) — which is what the outer, second differentiation needs.
+    `param_like[i]`: input i is a leaf parameter whose gradient an enclosing ``op.no_param_grads()`` block does not want."""
     with torch.enable_grad():
-        out = compose()
+        alias = [t.view_as(t) if (torch.is_tensor(t) and t.requires_grad) else t for t in inputs]
+        out = compose(*alias)
         outs = list(out) if isinstance(out, (tuple, list)) else [out]
         gouts = list(grad_outputs) if isinstance(grad_outputs, (tuple, list)) else [grad_outputs]
         pairs = [(o, g) for o, g in zip(outs, gouts) if g is not None and o.requires_grad]
         want = [i for i, (t, n) in enumerate(zip(inputs, needs))
-                if n and t is not None and torch.is_tensor(t) and t.requires_grad
+                if n and torch.is_tensor(t) and t.requires_grad
                 and not (param_like is not None and skip_param_grad(param_like[i]))]
         res = [None] * len(inputs)
         if pairs and want:
-            grads = torch.autograd.grad([o for o, _ in pairs], [inputs[i] for i in want], [g for _, g in pairs],
+            grads = torch.autograd.grad([o for o, _ in pairs], [alias[i] for i in want], [g for _, g in pairs],
                                         create_graph=True, allow_unused=True)
             for i, g in zip(want, grads):
                 res[i] = g

@@ -605,7 +605,7 @@ class _ConvBiasAct(Function):
             from ._twice import second_order_backward
             bias = ctx.bias
             gx, gw, gb = second_order_backward(
-                lambda: fused_leaky_relu(_Conv.apply(x, w, s, p, wscale, key), bias, slope, gain),
+                lambda x_, w_, b_: fused_leaky_relu(_Conv.apply(x_, w_, s, p, wscale, key), b_, slope, gain),
                 (x, w, bias), ctx.needs_input_grad[:3], g, ctx.plike)
             return gx, gw, gb, None, None, None, None, None, None
         want_b = ctx.needs_input_grad[2]

@@ -232,11 +232,11 @@ class _ToRGB(Function):
             bias, add = ctx.bias_add
             J, c = w.shape
 
-            def compose():
-                out = _ThinFwd.apply(x, (ctx.wscale * w.view(1, J, c)) * s.unsqueeze(1))
-                if bias is not None:
-                    out = out + bias.view(1, J, 1, 1)
-                return out if add is None else out + add
+            def compose(x_, w_, s_, b_, add_):
+                out = _ThinFwd.apply(x_, (ctx.wscale * w_.view(1, J, c)) * s_.unsqueeze(1))
+                if b_ is not None:
+                    out = out + b_.view(1, J, 1, 1)
+                return out if add_ is None else out + add_
             res = second_order_backward(compose, (x, w, s, bias, add), ctx.needs_input_grad[:5], g)
             return (*res, None)
         g = g.contiguous()
@@ -295,10 +295,10 @@ class _MbStd(Function):
         (x,) = ctx.saved_tensors
         if torch.is_grad_enabled():     # create_graph=True (R1): the formula composed from tensor ops, per concatenated call
             from ._twice import second_order_backward
-            calls, sg, sf = ctx.groups, ctx.stddev
+            calls, (sg, sf) = ctx.groups, ctx.stddev
             (gx,) = second_order_backward(
-                lambda: (_mbstd_composite(x, sg, sf) if calls == 1
-                         else torch.cat([_mbstd_composite(xc, sg, sf) for xc in x.chunk(calls)], 0)), (x,), (True,), g)
+                lambda x_: (_mbstd_composite(x_, sg, sf) if calls == 1
+                            else torch.cat([_mbstd_composite(xc, sg, sf) for xc in x_.chunk(calls)], 0)), (x,), (True,), g)
             return gx, None, None
         g = _nhwc(g)
         x = _nhwc(x)

@@ -70,7 +70,7 @@ class _DemodFused(Function):
         B = s.shape[0]
         if torch.is_grad_enabled():     # create_graph=True: the tensor-algebra form, differentiable to any order
             from ._twice import second_order_backward
-            gw, gs = second_order_backward(lambda: demod_coeff(w_in, s_in, ctx.wscale, ctx.eps), (w_in, s_in),
+            gw, gs = second_order_backward(lambda w_, s_: demod_coeff(w_, s_, ctx.wscale, ctx.eps), (w_in, s_in),
                                            ctx.needs_input_grad[:2], gd, (ctx.w_param, False))
             return gw, gs, None, None, None
         gd = gd.contiguous()
@@ -142,9 +142,9 @@ class _ModConvFused(Function):
             if ctx.sd_in is not None:
                 s, d = ctx.sd_in
 
-            def compose():
-                yc = modulated_conv_composed(x, w, s, d, wscale, upsample, key)
-                return fused_noise_bias_act(yc, bias, noise, nw, slope, gain) if tail else yc
+            def compose(x_, w_, s_, d_, b_, nw_):
+                yc = modulated_conv_composed(x_, w_, s_, d_, wscale, upsample, key)
+                return fused_noise_bias_act(yc, b_, noise, nw_, slope, gain) if tail else yc
             gx, gw, gs, gd, gb, gnw = second_order_backward(
                 compose, (x, w, s, d, bias, nw), [ctx.needs_input_grad[i] for i in (0, 1, 2, 3, 7, 9)], g,
                 (False, ctx.plike[0], False, False, ctx.plike[1], ctx.plike[2]))
@@ -347,8 +347,8 @@ class _ModBank(Function):
             from ._twice import second_order_backward
             params = bank.params()
 
-            def compose():
-                return tuple(torch.addmm(params[2 * i + 1], latent[:, bank.lat_idx[i]], params[2 * i].t(), alpha=bank.scale)
+            def compose(lat_, _bank, *ps):
+                return tuple(torch.addmm(ps[2 * i + 1], lat_[:, bank.lat_idx[i]], ps[2 * i].t(), alpha=bank.scale)
                              for i in range(len(bank.C)))
             res = second_order_backward(compose, [latent, None] + params, ctx.needs_input_grad, gs)
             return tuple(res)

@@ -128,7 +128,7 @@ class _FirAct(Function):
             from ._twice import second_order_backward
             pad4 = ctx.pad4
             gx, gb, gw = second_order_backward(
-                lambda: fused_noise_bias_act(_UpFirDn.apply(x_in, taps, (1, 1), (1, 1), pad4), bias, noise, nw, slope, gain),
+                lambda x_, b_, nw_: fused_noise_bias_act(_UpFirDn.apply(x_, taps, (1, 1), (1, 1), pad4), b_, noise, nw_, slope, gain),
                 (x_in, bias, nw), [ctx.needs_input_grad[i] for i in (0, 3, 5)], g)
             return (gx, None, None, gb, None, gw, None, None)
         want_b, want_w = ctx.needs_input_grad[3], ctx.needs_input_grad[5]
