@@ -180,6 +180,9 @@ int rick_convt2_f32(const float *x, const void *packed_w, float *out, const floa
                     void *workspace, void *stream);
 /* The tile / split plan the launch above will use: out6 = {TW, TH, NB, blocks before the split, nsplit, chunks per split}. */
 int rick_convt2_plan(int N, int IH, int IW, int Ci, int Co, int OH, int OW, int *out6);
+/* The plan's lane-slot -> tile-position table (128 entries, bit 7 = unused slot) and its patch-window pitch in pixels:
+ * the permutation that makes the kernel's LDS reads bank-conflict-free (tools/lds_sim.py checks it). */
+int rick_convt2_posmap(int N, int IH, int IW, int Ci, int Co, int OH, int OW, unsigned char *out128, int *pitch);
 
 /* Weight gradient for the same geometry:
  *   gw[(co, ci, t)] = alpha * sum_{n, pos} (ascale[n,co] * gy[n, outpix(pos), co]) *

@@ -58,6 +58,7 @@ SIGNATURES = {
     'rick_conv_igemm_multi_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(ConvGeom), c_int, c_fp, c_fp]),
     'rick_convt2_workspace_bytes': (c_i64, [c_int] * 7),
     'rick_convt2_plan': (c_int, [c_int] * 7 + [ctypes.POINTER(c_int)]),
+    'rick_convt2_posmap': (c_int, [c_int] * 7 + [ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(c_int)]),
     'rick_convt2_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp] + [c_int] * 8 + [c_f, c_fp, c_fp]),
     'rick_conv_wgrad_workspace_bytes': (c_i64, [ctypes.POINTER(ConvGeom)]),
     'rick_conv_wgrad_f32': (c_int, [c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_fp, c_fp,

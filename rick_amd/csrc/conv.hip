@@ -173,6 +173,7 @@ struct ConvTiling {
     int nchunks, ncot;
     int nbe;                    // images per tile actually used (min(nb, N)); patch holds nbe images
     int nsplit, cps;            // igemm split-K over channel chunks: splits, chunks per split
+    int pkb;                    // wgrad: bit of the patch pixel index that keys the slot swizzle
     int debug;                  // ablation switches for tools/bench_conv.py (RICK_CONV_DEBUG); 0 in production
 };
 
@@ -230,6 +231,7 @@ static int make_tiling(const rick_conv_geom *g, int tile_positions, ConvTiling *
     t->ncot = cdiv(g->Co, CV_BM);
     t->nsplit = 1;
     t->cps = t->nchunks;
+    t->pkb = (g->is == 1 && tw == 4) ? 3 : 2;
     t->debug = ablation_env("RICK_CONV_DEBUG", 0);
     return 0;
 }
@@ -1143,7 +1145,11 @@ extern "C" int rick_conv_igemm_multi_f32(const float *x, const void *packed_w, f
 // [position][channel] and consumed through ds_read_b64_tr_b16 transposing reads.
 //   gy image : [64 pos][128 co] fp16, 256 B rows, 32-byte granules XOR-swizzled with
 //              key(r) = ((r>>3)&1)*4 + (r&3)  (conflict-free for the 8 rows a half-wave reads)
-//   x  patch : same image as the igemm kernel ([pixel][32 ci], cv_swz slots)
+//   x  patch : [pixel][32 ci] like the igemm kernel's, 16-byte slots XOR-swizzled with bit `pkb` of the pixel index:
+//              a transposing read takes 32 B of 8 patch rows per 32-lane group — rows p..p+3 and p+8..p+11 of a
+//              16-wide position tile — so the two runs must differ in their slot key: bit 3 (pkb = 3, conflict-free;
+//              the igemm's bit 2 makes every such read 2-way: 31 % of the LDS cycles were conflicts in round 2);
+//              narrower tiles and stride-2 geometries keep bit 2 (tools/lds_sim.py)
 #define WG_TILE 64
 #define WG_GY_BYTES (WG_TILE * CV_BM * 2)   // 16 KB (one of hi / lo)
 
@@ -1159,6 +1165,7 @@ __device__ __forceinline__ f16x8 tr_read2(const unsigned char *base, int off0, i
 }
 
 __device__ __forceinline__ int wg_key(int r) { return (((r >> 3) & 1) << 2) + (r & 3); }
+__device__ __forceinline__ int wg_pswz(int kg, int pix, int kb) { return kg ^ (((pix >> kb) & 1) << 1); }
 
 // FAST (pipelined form; the host selects it for layers whose position grid is an exact multiple of the tile and whose
 // channel counts fill the 128 x 32 block — every 3x3 / 1x1 convolution of both networks at >= 8x8): staging is stripped to
@@ -1261,7 +1268,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         const int pix = (threadIdx.x >> 3) + 32 * k;
         p_rel[k] = 0;
         p_pyx[k] = 0xffffffffu;
-        p_lds[k] = (pix < t.NPP ? pix : t.NPP) * 64 + cv_swz(pc4 >> 1, pix) * 16 + (pc4 & 1) * 8;
+        p_lds[k] = (pix < t.NPP ? pix : t.NPP) * 64 + wg_pswz(pc4 >> 1, pix, t.pkb) * 16 + (pc4 & 1) * 8;
         if (pix < t.NPP) {
             const unsigned e = ptab[pix];
             p_rel[k] = (((int)(e >> 20) * g.IH + (int)((e >> 10) & 1023)) * g.IW + (int)(e & 1023)) * g.Ci;
@@ -1409,8 +1416,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                     if (tt < g.ntaps) {
                         const int toff = (g.dy[tt] - t.dymin) * t.PW + (g.dx[tt] - t.dxmin);
                         const int pp0 = pbase[kk][0] + toff, pp1 = pbase[kk][1] + toff;
-                        const int o0 = pp0 * 64 + cv_swz(b_kg, pp0) * 16 + b_sub;
-                        const int o1 = pp1 * 64 + cv_swz(b_kg, pp1) * 16 + b_sub;
+                        const int o0 = pp0 * 64 + wg_pswz(b_kg, pp0, t.pkb) * 16 + b_sub;
+                        const int o1 = pp1 * 64 + wg_pswz(b_kg, pp1, t.pkb) * 16 + b_sub;
                         const f16x8 bhi = tr_read2(ph, o0, o1);
                         f16x8 blo;
                         if (SPLIT == 2) blo = tr_read2(pl, o0, o1);
@@ -1590,8 +1597,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                         const int ts = tt < g.ntaps ? tt : 0;
                         const int toff = (g.dy[ts] - t.dymin) * t.PW + (g.dx[ts] - t.dxmin);
                         const int pp0 = pbase[kk][0] + toff, pp1 = pbase[kk][1] + toff;
-                        const int o0 = pp0 * 64 + cv_swz(b_kg, pp0) * 16 + b_sub;
-                        const int o1 = pp1 * 64 + cv_swz(b_kg, pp1) * 16 + b_sub;
+                        const int o0 = pp0 * 64 + wg_pswz(b_kg, pp0, t.pkb) * 16 + b_sub;
+                        const int o1 = pp1 * 64 + wg_pswz(b_kg, pp1, t.pkb) * 16 + b_sub;
                         const f16x8 bhi = tr_read2(bph, o0, o1);
                         f16x8 blo;
                         if (SPLIT == 2) blo = tr_read2(bpl, o0, o1);

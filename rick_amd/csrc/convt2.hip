@@ -38,6 +38,9 @@ struct Ct2Plan {
     int PH, PW, NPP;                // patch = (TH+1) x (TW+1) input pixels per image, NB images
     int nchunks, ncot, nsplit, cps;
     float alpha;
+    // lane slot (j * 16 + l15) -> tile position (bit 7: slot unused), 4 slots per word; a permutation that makes every
+    // ds_read_b128 of the patch conflict-free (ct2_position_map)
+    unsigned posw[32];
 };
 
 template <int SPLIT>
@@ -49,6 +52,13 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int pbuf = P.NPP * 64;                              // one of hi / lo of one patch buffer
     float *sct = reinterpret_cast<float *>(smem + 4 * pbuf);  // [NB][cps * 32] input scales
+    unsigned char *spos = reinterpret_cast<unsigned char *>(sct + P.NB * P.cps * CV_CK);   // [128] lane slot -> tile position
+    if (threadIdx.x < 32) {     // (a select chain over the kernel argument: a dynamic index would send the struct to scratch)
+        unsigned w = 0;
+#pragma unroll
+        for (int i = 0; i < 32; i++) w = (int)threadIdx.x == i ? P.posw[i] : w;
+        reinterpret_cast<unsigned *>(spos)[threadIdx.x] = w;
+    }
 
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int npos_tiles = P.ntx * P.nty * P.ntn;
@@ -179,12 +189,16 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
         }
     };
 
-    // ---- B operand (patch) read offsets: position j*16 + l15 of the tile -> patch pixel (ty + 1, tx + 1)
+    // ---- B operand (patch) read offsets: lane slot j*16 + l15 -> tile position (position map) -> patch pixel (ty + 1, tx + 1)
+    __syncthreads();                                          // position map in LDS
     const int tpos = P.TW * P.TH;
     int pb[8];
+    unsigned slotpos[2] = {0, 0};                             // this lane's 8 table entries (positions of slots j * 16 + l15)
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const int pos = j * 16 + l15;
+        const unsigned ent = spos[j * 16 + l15];
+        slotpos[j >> 2] |= ent << (8 * (j & 3));
+        const int pos = (int)(ent & 127u);
         int nbi = pos / tpos;
         const int rem = pos - nbi * tpos;
         const int ty = rem / P.TW, tx = rem - ty * P.TW;
@@ -282,12 +296,13 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     const float oalpha = P.alpha * unscale;                   // exact: the exponents are powers of two
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const int pos = j * 16 + l15;
+        const unsigned ent = (slotpos[j >> 2] >> (8 * (j & 3))) & 255u;
+        const int pos = (int)(ent & 127u);
         const int nbi = pos / tpos, rem = pos - nbi * tpos;
         const int ty = rem / P.TW, tx = rem - ty * P.TW;
         const int n = n0 + nbi, gy = gy0 + ty, gx = gx0 + tx;
         const int oy = 2 * gy + py, ox = 2 * gx + px;
-        if (nbi >= P.NB || n >= P.N || gy >= GHc || gx >= GWc || oy >= P.OH || ox >= P.OW) continue;
+        if ((ent & 128u) || nbi >= P.NB || n >= P.N || gy >= GHc || gx >= GWc || oy >= P.OH || ox >= P.OW) continue;
         const int64_t opix = ((int64_t)n * P.OH + oy) * P.OW + ox;
         if (P.nsplit > 1) {     // raw partial sums in output layout; scaled by the reduce kernel
             float *wrow = ws + (int64_t)split * osz + opix * P.Co;
@@ -344,6 +359,55 @@ __global__ __launch_bounds__(256) void convt2_reduce_kernel(const float *__restr
     }
 }
 
+static size_t ct2_lds_bytes(const Ct2Plan &p) { return 4 * (size_t)p.NPP * 64 + (size_t)p.NB * p.cps * CV_CK * 4 + 128; }
+
+// Which tile position each lane slot (j, l15) of a B-operand read serves.  ds_read_b128 is serviced in four fixed groups
+// of 16 lanes (MI355X_MICROARCH.md, LDS): {l15 in A = 0-3, 12-15 with k-group 2h; l15 in B = 4-11 with k-group 2h + 1} and
+// the mirror image.  With 64-byte pixel rows and the slot key on bit 2 of the pixel index, a group is conflict-free iff
+// its 8 A-lanes read pixels that are distinct mod 8, and its 8 B-lanes likewise.  16 consecutive pixels satisfy that;
+// the (TW + 1)-pitched windows of this kernel's odd-sized tiles (6 x 5 x 4, 10 x 3 x 4, 11 x 11 ...) do not — every read
+// was 2-way (46 % of the LDS cycles in round 2).  The tap offsets are constant shifts of the pixel index, which keep
+// "distinct mod 8", so ONE assignment serves all taps: sort the tile's positions by (pixel index mod 8) and give the
+// s-th position of every residue class to set s (16 sets of 8 = 8 j's x {A, B}).  Needs <= 16 positions per residue:
+// the window pitch is padded by 0-3 unused columns until that holds (else the identity map: correct, with conflicts).
+static void ct2_position_map(Ct2Plan *p) {
+    static const int laneA[8] = {0, 1, 2, 3, 12, 13, 14, 15}, laneB[8] = {4, 5, 6, 7, 8, 9, 10, 11};
+    const int npos = p->TW * p->TH * p->NB, tpos = p->TW * p->TH;
+    unsigned char map[128];
+    for (int i = 0; i < 128; i++) map[i] = (unsigned char)(i < npos ? i : 128 | (npos - 1));
+    const int base_pw = p->TW + 1;
+    for (int pad = 0; pad <= 3; pad++) {
+        const int PW = base_pw + pad, npp = p->NB * p->PH * PW;
+        Ct2Plan q = *p;
+        q.PW = PW;
+        q.NPP = npp;
+        if (npp > CT_MAX_NPP || ct2_lds_bytes(q) > 160 * 1024) break;
+        int cls[8][128], cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int pos = 0; pos < npos; pos++) {
+            const int nbi = pos / tpos, rem = pos % tpos, ty = rem / p->TW, tx = rem % p->TW;
+            const int r = ((nbi * p->PH + ty + 1) * PW + tx + 1) & 7;
+            cls[r][cnt[r]++] = pos;
+        }
+        int mx = 0;
+        for (int r = 0; r < 8; r++) mx = cnt[r] > mx ? cnt[r] : mx;
+        if (mx > 16) continue;
+        for (int s = 0; s < 16; s++) {
+            const int j = s >> 1;
+            const int *lanes = (s & 1) ? laneB : laneA;
+            int any = -1;
+            for (int r = 0; r < 8 && any < 0; r++)
+                if (s < cnt[r]) any = cls[r][s];
+            for (int r = 0; r < 8; r++)     // a missing residue re-reads a pixel of its own set (same address: broadcast)
+                map[j * 16 + lanes[r]] = (unsigned char)(s < cnt[r] ? cls[r][s] : 128 | (any >= 0 ? any : 0));
+        }
+        p->PW = PW;
+        p->NPP = npp;
+        break;
+    }
+    for (int i = 0; i < 32; i++)
+        p->posw[i] = map[4 * i] | (map[4 * i + 1] << 8) | (map[4 * i + 2] << 16) | ((unsigned)map[4 * i + 3] << 24);
+}
+
 // Tile and split-K plan.  One 512-thread block (256 registers per thread) is resident per CU, so the grid runs in
 // waves of 256 blocks: minimise  waves x (chunks per block x 9 taps + fixed cost)  over the position-tile shape
 // (any TW x TH x NB with <= 128 positions: the class grids are (2^k + 1)-sized, powers of two would waste up to
@@ -397,10 +461,9 @@ static int ct2_plan(int N, int IH, int IW, int Ci, int Co, int OH, int OW, float
     p->PH = p->TH + 1;
     p->PW = p->TW + 1;
     p->NPP = p->NB * p->PH * p->PW;
+    ct2_position_map(p);
     return 0;
 }
-
-static size_t ct2_lds_bytes(const Ct2Plan &p) { return 4 * (size_t)p.NPP * 64 + (size_t)p.NB * p.cps * CV_CK * 4; }
 
 extern "C" int64_t rick_convt2_workspace_bytes(int N, int IH, int IW, int Ci, int Co, int OH, int OW) {
     Ct2Plan p;
@@ -447,5 +510,15 @@ extern "C" int rick_convt2_plan(int N, int IH, int IW, int Ci, int Co, int OH, i
     const int rc = ct2_plan(N, IH, IW, Ci, Co, OH, OW, 1.f, &p);
     if (rc || !out6) return RICK_EINVAL;
     out6[0] = p.TW; out6[1] = p.TH; out6[2] = p.NB; out6[3] = p.ntx * p.nty * p.ntn * p.ncot; out6[4] = p.nsplit; out6[5] = p.cps;
+    return 0;
+}
+
+// The lane-slot -> position table of the plan and its (padded) window pitch, for tools/lds_sim.py and the tests.
+extern "C" int rick_convt2_posmap(int N, int IH, int IW, int Ci, int Co, int OH, int OW, unsigned char *out128, int *pitch) {
+    Ct2Plan p;
+    const int rc = ct2_plan(N, IH, IW, Ci, Co, OH, OW, 1.f, &p);
+    if (rc || !out128 || !pitch) return RICK_EINVAL;
+    for (int i = 0; i < 128; i++) out128[i] = (unsigned char)((p.posw[i >> 2] >> (8 * (i & 3))) & 255u);
+    *pitch = p.PW;
     return 0;
 }
