@@ -1,0 +1,663 @@
+// Weight gradients of the convolution family on gfx950 MFMA (v_mfma_f32_16x16x32_f16); see conv.hip for the forward /
+// data-gradient kernels and conv_common.h for the fp16 hi/lo split.
+#include "conv_tiling.h"
+
+// ==========================================================================================
+// Weight gradient.  GEMM view per block: D[128 co][NT taps x 32 ci] += GY^T[128 co][K] * X[K][..],
+// K = positions (64 per tile, two 32-deep MFMA k-steps), split-K over position tiles.
+// Both operands are k-strided in NHWC memory (k = position), so they are staged row-major
+// [position][channel] and consumed through ds_read_b64_tr_b16 transposing reads.
+//   gy image : [64 pos][128 co] fp16, 256 B rows, 32-byte granules XOR-swizzled with
+//              key(r) = ((r>>3)&1)*4 + (r&3)  (conflict-free for the 8 rows a half-wave reads)
+//   x  patch : [pixel][32 ci] like the igemm kernel's, 16-byte slots XOR-swizzled with bit `pkb` of the pixel index:
+//              a transposing read takes 32 B of 8 patch rows per 32-lane group — rows p..p+3 and p+8..p+11 of a
+//              16-wide position tile — so the two runs must differ in their slot key: bit 3 (pkb = 3, conflict-free;
+//              the igemm's bit 2 makes every such read 2-way: 31 % of the LDS cycles were conflicts in round 2);
+//              narrower tiles and stride-2 geometries keep bit 2 (tools/lds_sim.py)
+#define WG_TILE 64
+#define WG_GY_BYTES (WG_TILE * CV_BM * 2)   // 16 KB (one of hi / lo)
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+__device__ __forceinline__ f16x8 tr_read2(const unsigned char *base, int off0, int off1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + off0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + off1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 r = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(f16x8, r);
+}
+
+typedef unsigned int wg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {   // buffer_load_dwordx4 ... offen
+    const wg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+__device__ __forceinline__ int wg_key(int r) { return (((r >> 3) & 1) << 2) + (r & 3); }
+__device__ __forceinline__ int wg_pswz(int kg, int pix, int kb) { return kg ^ (((pix >> kb) & 1) << 1); }
+
+// FAST (pipelined form; the host selects it for layers whose position grid is an exact multiple of the tile and whose
+// channel counts fill the 128 x 32 block — every 3x3 / 1x1 convolution of both networks at >= 8x8): staging is stripped to
+// what such a layer needs.  gy items are always valid (one unconditional load, no mask bookkeeping); x items test two
+// unsigned compares (halo of the padding) and read the zero page when outside; conversion is the fp16 split plus, for
+// the modulated layers only, the scale multiply — no zero-select.  ~15 / ~22 instructions per item instead of ~30.  The
+// kernel is bound by the ISSUE of exactly these instructions (one wave per SIMD, 2-3 of them per MFMA, and an MFMA
+// leaves room for ~2), not by the matrix pipe: measured +20...27 % (280 -> 330-345 TFLOP/s on the 64^2...256^2 layers).
+template <int NT, int SPLIT, bool VEC, int PMAX, bool PIPE, int FAST = 0>   // FAST: 1 = no per-channel scales, 2 = with
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                         float *__restrict__ ws, const float *__restrict__ ascale,
+                                                         const float *__restrict__ bscale, const rick_conv_geom g,
+                                                         const ConvTiling t, int nsplit, int tiles_per_split) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // one operand buffer = [gy hi 16 KB][gy lo 16 KB][patch hi (NPP+1) x 64 B][patch lo]; PIPE keeps two of them
+    // (+1 patch row: spare row for out-of-patch items)
+    const int bufsz = 2 * WG_GY_BYTES + 2 * (t.NPP + 1) * 64;
+    unsigned char *gh = smem;                          // gy hi
+    unsigned char *gl = smem + WG_GY_BYTES;            // gy lo
+    unsigned char *ph = smem + 2 * WG_GY_BYTES;
+    unsigned char *pl = ph + (t.NPP + 1) * 64;
+    unsigned *ptab = reinterpret_cast<unsigned *>(smem + (PIPE ? 2 : 1) * bufsz);
+    float *sA = reinterpret_cast<float *>(ptab + ((t.NPP + 3) & ~3));   // [N][128 co] scales of gy (1 if none)
+    float *sB = sA + g.N * CV_BM;                                        // [N][32 ci]  scales of x
+    build_patch_table(ptab, t);
+
+    // XCD-aware mapping: blocks with equal blockIdx % 8 share an XCD (and its L2).  Every XCD owns its own
+    // slices of the position range; all (co-tile, chunk) blocks of a slice run there, so a gy tile is fetched
+    // into ONE L2 and re-used by the nchunks blocks that need it.  (Placement only affects speed.)
+    int split, cc;
+    if ((nsplit & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, spx = nsplit >> 3;
+        split = xcd + 8 * (j % spx);
+        cc = j / spx;
+    } else {
+        split = blockIdx.x / (t.nchunks * t.ncot);
+        cc = blockIdx.x % (t.nchunks * t.ncot);
+    }
+    const int chunk = cc % t.nchunks;
+    const int cot = cc / t.nchunks;
+    const int ntiles = t.ntx * t.nty * t.ntn;
+    const int tile_begin = split * tiles_per_split;
+    const int tile_end = tile_begin + tiles_per_split < ntiles ? tile_begin + tiles_per_split : ntiles;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int tw_mask = (1 << t.tw_log2) - 1, th_mask = (1 << t.th_log2) - 1;
+
+    int a_row[2][2], a_key[2][2], pbase[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int r = kk * 32 + G * 8 + h * 4 + q;
+            a_row[kk][h] = r * 256;
+            a_key[kk][h] = wg_key(r) * 32;
+            const int px = r & tw_mask, py = (r >> t.tw_log2) & th_mask;
+            int nbi = r >> (t.tw_log2 + t.th_log2);
+            nbi = nbi < t.nbe ? nbi : t.nbe - 1;   // masked rows (zero gy) still read finite patch data
+            pbase[kk][h] = (nbi * t.PH + py * g.is) * t.PW + px * g.is;
+        }
+    const int b_kg = wn * 2 + (p >> 1), b_sub = (p & 1) * 8;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int tt = 0; tt < NT; tt++) acc[i][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- staging state (tile-invariant parts computed once per thread)
+    float4 gq[8];
+    float4 pq[PMAX];
+    int g_rel[8], g_lds[8], p_rel[PMAX], p_lds[PMAX];
+    unsigned g_pyx[8], p_pyx[PMAX];
+    const int gc4 = threadIdx.x & 31, pc4 = threadIdx.x & 7;
+    const int co_base = cot * CV_BM, ci_base = chunk * CV_CK;
+    const int gco = co_base + gc4 * 4, pci = ci_base + pc4 * 4;
+    // per-(image, channel) scales of this block's channel ranges -> LDS once (applied in store_tile without
+    // a global-load round trip per item)
+    for (int i = threadIdx.x; i < g.N * CV_BM; i += 256) {
+        const int n = i >> 7, co = co_base + (i & 127);
+        sA[i] = !ascale ? 1.f : co < g.Co ? ascale[(int64_t)n * g.Co + co] : 0.f;
+    }
+    for (int i = threadIdx.x; i < g.N * CV_CK; i += 256) {
+        const int n = i >> 5, ci = ci_base + (i & 31);
+        sB[i] = !bscale ? 1.f : ci < g.Ci ? bscale[(int64_t)n * g.Ci + ci] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int r = (threadIdx.x >> 5) + 8 * k;
+        const int px = r & tw_mask, py = (r >> t.tw_log2) & th_mask, nbi = r >> (t.tw_log2 + t.th_log2);
+        g_rel[k] = ((nbi * g.OH + py * g.os) * g.OW + px * g.os) * g.Co;
+        g_pyx[k] = (gco < g.Co && nbi < t.nbe) ? (((unsigned)nbi << 20) | ((unsigned)py << 10) | (unsigned)px) : 0xffffffffu;
+        g_lds[k] = r * 256 + ((gc4 * 8) ^ (wg_key(r) * 32));
+    }
+#pragma unroll
+    for (int k = 0; k < PMAX; k++) {
+        const int pix = (threadIdx.x >> 3) + 32 * k;
+        p_rel[k] = 0;
+        p_pyx[k] = 0xffffffffu;
+        p_lds[k] = (pix < t.NPP ? pix : t.NPP) * 64 + wg_pswz(pc4 >> 1, pix, t.pkb) * 16 + (pc4 & 1) * 8;
+        if (pix < t.NPP) {
+            const unsigned e = ptab[pix];
+            p_rel[k] = (((int)(e >> 20) * g.IH + (int)((e >> 10) & 1023)) * g.IW + (int)(e & 1023)) * g.Ci;
+            if (pci < g.Ci) p_pyx[k] = e;
+        }
+    }
+
+    // ---- operand exponents of this block (conv_common.h): amax of gy * ascale and of x * bscale over 4 of the block's
+    // position tiles x 2 staging items each (4096 values per operand), then 2^e is folded into the LDS scale tables.
+    float punscale;   // 2^-(e_gy + e_x): applied to the partial tile on its way to the workspace
+    float xsa, xsb;   // 2^e_gy, 2^e_x (SGPRs: the multiplier of layers without per-channel scales)
+    {
+        float ma = 0.f, mb = 0.f;
+        const int nt = tile_end - tile_begin;
+#pragma unroll
+        for (int sidx = 0; sidx < 4; sidx++) {
+            int pt = tile_begin + (sidx * nt) / 4;
+            const int tx_i = pt % t.ntx;
+            pt /= t.ntx;
+            const int ty_i = pt % t.nty;
+            const int tn_i = pt / t.nty;
+            const int gx0 = tx_i << t.tw_log2, gy0 = ty_i << t.th_log2, n0 = tn_i * t.nbe;
+            const int iy0 = gy0 * g.is + t.dymin, ix0 = gx0 * g.is + t.dxmin;
+            const float *gbase = gy + (((int64_t)n0 * g.OH + gy0 * g.os + g.oy0) * g.OW + gx0 * g.os + g.ox0) * g.Co + gco;
+            const float *xbase = x + (((int64_t)n0 * g.IH + iy0) * g.IW + ix0) * g.Ci + pci;
+            const int nrem = g.N - n0, yrem = g.GH - gy0, xrem = g.GW - gx0;
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                {
+                    const int k = (2 * sidx + 5 * kk + 1) & 7;
+                    const unsigned e = g_pyx[k];
+                    const int nbi = (int)(e >> 20), py = (int)((e >> 10) & 1023), px = (int)(e & 1023);
+                    const bool ok = nt > 0 && e != 0xffffffffu && nbi < nrem && py < yrem && px < xrem;
+                    float4 v = load4<VEC>(ok ? gbase + g_rel[k] : (VEC ? g_zero_page : gy), ok, gco, g.Co);
+                    v = mul4(v, *reinterpret_cast<const float4 *>(sA + (ok ? (n0 + nbi) * CV_BM : 0) + gc4 * 4));
+                    if (ok) ma = amax4(ma, v);
+                }
+                {
+                    const int k = (3 * sidx + 7 * kk + 2) % PMAX;
+                    const unsigned e = p_pyx[k];
+                    const int nbi = (int)(e >> 20), iy = iy0 + (int)((e >> 10) & 1023), ix = ix0 + (int)(e & 1023);
+                    const bool ok = nt > 0 && e != 0xffffffffu && nbi < nrem && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+                    float4 v = load4<VEC>(ok ? xbase + p_rel[k] : (VEC ? g_zero_page : x), ok, pci, g.Ci);
+                    v = mul4(v, *reinterpret_cast<const float4 *>(sB + (ok ? (n0 + nbi) * CV_CK : 0) + pc4 * 4));
+                    if (ok) mb = amax4(mb, v);
+                }
+            }
+        }
+        float *red = reinterpret_cast<float *>(smem);      // (operand buffers are not in use yet)
+        ma = block_amax(ma, red);
+        mb = block_amax(mb, red + 8);
+        float sa, ua, sb, ub;
+        cv_pow2_scale(ma, sa, ua);
+        cv_pow2_scale(mb, sb, ub);
+        punscale = cv_uniform(ua * ub);
+        xsa = cv_uniform(sa);
+        xsb = cv_uniform(sb);
+        __syncthreads();                                    // every thread has read `red`
+        for (int i = threadIdx.x; i < g.N * CV_BM; i += 256) sA[i] *= sa;
+        for (int i = threadIdx.x; i < g.N * CV_CK; i += 256) sB[i] *= sb;
+        __syncthreads();
+    }
+
+    // load_tile only ISSUES raw 16-byte loads (safe address for out-of-range items) and records a validity
+    // bitmask; every consumer of the loaded registers (scale, zero-select, fp16 split) lives in store_tile,
+    // which runs after the MFMA phase of the previous tile — so the loads stay in flight behind the MFMAs.
+    unsigned okmask = 0;
+    int st_n0 = 0;
+    auto load_tile = [&](int tile) {
+        int pt = tile;
+        const int tx_i = pt % t.ntx;
+        pt /= t.ntx;
+        const int ty_i = pt % t.nty;
+        const int tn_i = pt / t.nty;
+        const int gx0 = tx_i << t.tw_log2, gy0 = ty_i << t.th_log2, n0 = tn_i * t.nbe;
+        const int iy0 = gy0 * g.is + t.dymin, ix0 = gx0 * g.is + t.dxmin;
+        const float *gbase = gy + (((int64_t)n0 * g.OH + gy0 * g.os + g.oy0) * g.OW + gx0 * g.os + g.ox0) * g.Co + gco;
+        const float *xbase = x + (((int64_t)n0 * g.IH + iy0) * g.IW + ix0) * g.Ci + pci;
+        const int nrem = g.N - n0, yrem = g.GH - gy0, xrem = g.GW - gx0;
+        unsigned m = 0;
+        st_n0 = n0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned e = g_pyx[k];
+            const int nbi = (int)(e >> 20), py = (int)((e >> 10) & 1023), px = (int)(e & 1023);
+            const bool ok = e != 0xffffffffu && nbi < nrem && py < yrem && px < xrem;
+            m |= (ok ? 1u : 0u) << k;
+            gq[k] = load4<VEC>(ok ? gbase + g_rel[k] : gy, ok, gco, g.Co);
+        }
+#pragma unroll
+        for (int k = 0; k < PMAX; k++) {
+            const unsigned e = p_pyx[k];
+            const int nbi = (int)(e >> 20), iy = iy0 + (int)((e >> 10) & 1023), ix = ix0 + (int)(e & 1023);
+            const bool ok = e != 0xffffffffu && nbi < nrem && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+            m |= (ok ? 1u : 0u) << (8 + k);
+            pq[k] = load4<VEC>(ok ? xbase + p_rel[k] : x, ok, pci, g.Ci);
+        }
+        okmask = m;
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool ok = (okmask >> k) & 1u;
+            float4 v = gq[k];
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 hi, lo;
+            split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sA + (ok ? (st_n0 + (int)(g_pyx[k] >> 20)) * CV_BM : 0) + gc4 * 4), hi, lo);
+            *reinterpret_cast<uint2 *>(gh + g_lds[k]) = hi;
+            if (SPLIT == 2) *reinterpret_cast<uint2 *>(gl + g_lds[k]) = lo;
+        }
+#pragma unroll
+        for (int k = 0; k < PMAX; k++) {
+            const bool ok = (okmask >> (8 + k)) & 1u;
+            float4 v = pq[k];
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 hi, lo;
+            split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sB + (ok ? (st_n0 + (int)(p_pyx[k] >> 20)) * CV_CK : 0) + pc4 * 4), hi, lo);
+            *reinterpret_cast<uint2 *>(ph + p_lds[k]) = hi;
+            if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds[k]) = lo;
+        }
+    };
+
+    if (!PIPE) {
+        if (tile_begin < tile_end) load_tile(tile_begin);
+        for (int tile = tile_begin; tile < tile_end; tile++) {
+            __syncthreads();   // previous tile fully consumed
+            if (!(t.debug & 6) || tile == tile_begin) store_tile();
+            __syncthreads();
+            if (tile + 1 < tile_end && !(t.debug & 10)) load_tile(tile + 1);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads ahead of the MFMA phase
+            if (t.debug & 1) continue;
+    #pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                f16x8 ahi[4], alo[4];
+    #pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int cb = (wm * 64 + i * 16 + p * 4) * 2;
+                    const int o0 = a_row[kk][0] + (cb ^ a_key[kk][0]);
+                    const int o1 = a_row[kk][1] + (cb ^ a_key[kk][1]);
+                    ahi[i] = tr_read2(gh, o0, o1);
+                    if (SPLIT == 2) alo[i] = tr_read2(gl, o0, o1);
+                }
+    #pragma unroll
+                for (int tt = 0; tt < NT; tt++) {
+                    if (tt < g.ntaps) {
+                        const int toff = (g.dy[tt] - t.dymin) * t.PW + (g.dx[tt] - t.dxmin);
+                        const int pp0 = pbase[kk][0] + toff, pp1 = pbase[kk][1] + toff;
+                        const int o0 = pp0 * 64 + wg_pswz(b_kg, pp0, t.pkb) * 16 + b_sub;
+                        const int o1 = pp1 * 64 + wg_pswz(b_kg, pp1, t.pkb) * 16 + b_sub;
+                        const f16x8 bhi = tr_read2(ph, o0, o1);
+                        f16x8 blo;
+                        if (SPLIT == 2) blo = tr_read2(pl, o0, o1);
+    #pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            if (SPLIT == 2) {
+                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[i], bhi, acc[i][tt], 0, 0, 0);
+                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], blo, acc[i][tt], 0, 0, 0);
+                            }
+                            acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], bhi, acc[i][tt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        // ---- software-pipelined form (two operand buffers in LDS).  While the MFMAs of tile t run from buffer
+        // t&1, the same wave converts the raw registers of tile t+1 into buffer (t+1)&1 — one staging item per
+        // (k-half, tap) slot, placed in program order between the MFMA groups so its VALU / LDS-write work issues
+        // in the shadow of the matrix pipe — and re-issues each register's global load for tile t+2 as soon as
+        // the register is free.  One barrier per tile; a load has a whole tile period to land.
+        constexpr int NITEM = 8 + PMAX, NSLOT = 2 * NT, IPS = (NITEM + NSLOT - 1) / NSLOT;
+        // the zero page's address as an opaque register value: left visible, hipcc sinks its materialisation (s_getpc + add)
+        // into a per-item branch (s_and_saveexec / s_cbranch_execz), which cuts the tile's code into basic blocks and keeps the
+        // scheduler from spreading the staging work under the MFMAs
+        const float *zero_page = g_zero_page;
+        asm volatile("" : "+s"(zero_page));
+        (void)zero_page;
+        // FAST: buffer descriptors over the whole tensors (the host only selects FAST below 4 GB per tensor)
+        const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(gy), 0, FAST ? (unsigned)((int64_t)g.N * g.OH * g.OW * g.Co * 4) : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(x), 0, FAST ? (unsigned)((int64_t)g.N * g.IH * g.IW * g.Ci * 4) : 0u, 0x00020000);
+        int g_toff = 0, x_toff = 0;              // byte offset of the loading tile's origin (+ this thread's channel quad)
+        const float *gbase = gy, *xbase = x;     // bases of the tile being LOADED
+        int l_n0 = 0, l_nrem = 0, l_yrem = 0, l_xrem = 0, l_iy0 = 0, l_ix0 = 0;
+        unsigned mask_ld = 0, mask_cv = 0;       // validity of the registers being loaded / converted
+        int cv_n0 = 0;
+        // a tile inside ONE image (every layer >= 8x8) has one gy / x scale vector per thread: kept in registers,
+        // fetched from the LDS table once per tile instead of once per staged item
+        const bool one_img = t.nbe == 1;
+        float4 sa_cv = make_float4(1.f, 1.f, 1.f, 1.f), sb_cv = sa_cv;
+        auto set_tile = [&](int tile) {
+            int pt = tile;
+            const int tx_i = pt % t.ntx;
+            pt /= t.ntx;
+            const int ty_i = pt % t.nty;
+            const int tn_i = pt / t.nty;
+            const int gx0 = tx_i << t.tw_log2, gy0 = ty_i << t.th_log2;
+            l_n0 = tn_i * t.nbe;
+            l_iy0 = gy0 * g.is + t.dymin;
+            l_ix0 = gx0 * g.is + t.dxmin;
+            gbase = gy + (((int64_t)l_n0 * g.OH + gy0 * g.os + g.oy0) * g.OW + gx0 * g.os + g.ox0) * g.Co + gco;
+            xbase = x + (((int64_t)l_n0 * g.IH + l_iy0) * g.IW + l_ix0) * g.Ci + pci;
+            if constexpr (FAST != 0) {           // (32-bit: FAST tensors are < 4 GB; the x origin may lie before the tensor — halo)
+                g_toff = ((((l_n0 * g.OH + gy0 * g.os + g.oy0) * g.OW + gx0 * g.os + g.ox0) * g.Co) + gco) * 4;
+                x_toff = ((((l_n0 * g.IH + l_iy0) * g.IW + l_ix0) * g.Ci) + pci) * 4;
+            }
+            l_nrem = g.N - l_n0;
+            l_yrem = g.GH - gy0;
+            l_xrem = g.GW - gx0;
+            mask_ld = 0;
+        };
+        auto issue_item = [&](auto KC) {         // raw load of staging item K of the tile selected by set_tile
+            constexpr int K = decltype(KC)::value;
+            if constexpr (FAST && K < 8) {
+                // buffer loads: one descriptor per tensor, the tile's origin and the item in a 32-bit byte offset
+                if constexpr (PMAX <= 4) gq[K] = buf_load4(g_rsrc, (unsigned)(g_toff + g_rel[K] * 4));
+                else gq[K] = *reinterpret_cast<const float4 *>(gbase + g_rel[K]);
+            } else if constexpr (FAST) {
+                constexpr int P = K - 8;
+                const unsigned e = p_pyx[P];
+                const unsigned iy = (unsigned)(l_iy0 + (int)((e >> 10) & 1023)), ix = (unsigned)(l_ix0 + (int)(e & 1023));
+                const bool ok = (e != 0xffffffffu) & (iy < (unsigned)g.IH) & (ix < (unsigned)g.IW);
+                // an item outside the image (zero padding) gets an offset beyond the descriptor's range: the hardware's range
+                // check returns zeros.  One v_cndmask on a 32-bit offset — the pointer select this replaces was compiled into a
+                // branch per item (s_and_saveexec / s_cbranch_execz around the 64-bit address arithmetic), which cut the tile's code
+                // into basic blocks and kept the scheduler from spreading the staging work under the MFMAs.
+                // (PMAX = 12, the stride-2 patches: one basic block per tile needs more registers than the 512 there are — 54-89
+                // spilled in the loop, measured 227 -> 204 TF — so those keep the pointer select and its per-item branch)
+                if constexpr (PMAX <= 4) pq[P] = buf_load4(x_rsrc, ok ? (unsigned)(x_toff + p_rel[P] * 4) : 0xFFFFFFF0u);
+                else pq[P] = *reinterpret_cast<const float4 *>(ok ? xbase + p_rel[P] : g_zero_page);
+            } else if constexpr (K < 8) {
+                const unsigned e = g_pyx[K];
+                const int nbi = (int)(e >> 20), py = (int)((e >> 10) & 1023), px = (int)(e & 1023);
+                const bool ok = e != 0xffffffffu && nbi < l_nrem && py < l_yrem && px < l_xrem;
+                mask_ld |= (ok ? 1u : 0u) << K;
+                gq[K] = load4<VEC>(ok ? gbase + g_rel[K] : gy, ok, gco, g.Co);
+            } else {
+                constexpr int P = K - 8;
+                const unsigned e = p_pyx[P];
+                const int nbi = (int)(e >> 20), iy = l_iy0 + (int)((e >> 10) & 1023), ix = l_ix0 + (int)(e & 1023);
+                const bool ok = e != 0xffffffffu && nbi < l_nrem && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+                mask_ld |= (ok ? 1u : 0u) << K;
+                pq[P] = load4<VEC>(ok ? xbase + p_rel[P] : x, ok, pci, g.Ci);
+            }
+        };
+        auto convert_item = [&](auto KC, unsigned char *buf, auto ONE) {   // raw register K -> scaled fp16 hi/lo in `buf`
+            constexpr int K = decltype(KC)::value;
+            constexpr bool ONE_IMG = decltype(ONE)::value;
+            const bool ok = (mask_cv >> K) & 1u;
+            if constexpr (FAST) {
+                uint2 hi, lo;
+                if constexpr (K < 8) {
+                    const float4 v = gq[K];
+                    if constexpr (FAST == 2) {     // modulated layers (G) carry per-(image, channel) scales (x block exponent)
+                        if constexpr (ONE_IMG) split4v<SPLIT>(v, sa_cv, hi, lo);
+                        else split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sA + (cv_n0 + (int)(g_pyx[K] >> 20)) * CV_BM + gc4 * 4), hi, lo);
+                    } else split4s<SPLIT>(v, xsa, hi, lo);   // block exponent from an SGPR
+                    *reinterpret_cast<uint2 *>(buf + g_lds[K]) = hi;
+                    *reinterpret_cast<uint2 *>(buf + WG_GY_BYTES + g_lds[K]) = lo;
+                } else {
+                    const float4 v = pq[K - 8];
+                    if constexpr (FAST == 2) {     // (an out-of-range item read the zero page: 0 * scale stays 0)
+                        if constexpr (ONE_IMG) split4v<SPLIT>(v, sb_cv, hi, lo);
+                        else split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sB + (cv_n0 + (int)((p_pyx[K - 8] >> 20) & 15)) * CV_CK + pc4 * 4), hi, lo);
+                    } else split4s<SPLIT>(v, xsb, hi, lo);
+                    *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + p_lds[K - 8]) = hi;
+                    *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + (t.NPP + 1) * 64 + p_lds[K - 8]) = lo;
+                }
+            } else if constexpr (K < 8) {
+                float4 v = gq[K];
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                uint2 hi, lo;
+                if constexpr (ONE_IMG) split4v<SPLIT>(v, sa_cv, hi, lo);
+                else split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sA + (ok ? (cv_n0 + (int)(g_pyx[K] >> 20)) * CV_BM : 0) + gc4 * 4), hi, lo);
+                *reinterpret_cast<uint2 *>(buf + g_lds[K]) = hi;
+                if (SPLIT == 2) *reinterpret_cast<uint2 *>(buf + WG_GY_BYTES + g_lds[K]) = lo;
+            } else {
+                constexpr int P = K - 8;
+                float4 v = pq[P];
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                uint2 hi, lo;
+                if constexpr (ONE_IMG) split4v<SPLIT>(v, sb_cv, hi, lo);
+                else split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sB + (ok ? (cv_n0 + (int)(p_pyx[P] >> 20)) * CV_CK : 0) + pc4 * 4), hi, lo);
+                *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + p_lds[P]) = hi;
+                if (SPLIT == 2) *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + (t.NPP + 1) * 64 + p_lds[P]) = lo;
+            }
+        };
+        auto for_items = [&](auto LO, auto fn) {  // fn(K) for the IPS items of one slot, K static
+            constexpr int L = decltype(LO)::value;
+            if constexpr (L < NITEM) fn(std::integral_constant<int, L>{});
+            if constexpr (IPS > 1 && L + 1 < NITEM) fn(std::integral_constant<int, L + 1>{});
+            if constexpr (IPS > 2 && L + 2 < NITEM) fn(std::integral_constant<int, L + 2>{});
+            if constexpr (IPS > 3 && L + 3 < NITEM) fn(std::integral_constant<int, L + 3>{});
+            if constexpr (IPS > 4 && L + 4 < NITEM) fn(std::integral_constant<int, L + 4>{});
+            if constexpr (IPS > 5 && L + 5 < NITEM) fn(std::integral_constant<int, L + 5>{});
+            if constexpr (IPS > 6 && L + 6 < NITEM) fn(std::integral_constant<int, L + 6>{});
+            if constexpr (IPS > 7 && L + 7 < NITEM) fn(std::integral_constant<int, L + 7>{});
+            if constexpr (IPS > 8 && L + 8 < NITEM) fn(std::integral_constant<int, L + 8>{});
+            if constexpr (IPS > 9 && L + 9 < NITEM) fn(std::integral_constant<int, L + 9>{});
+            static_assert(IPS <= 10, "items per slot");
+        };
+        auto for_slots = [&](auto fn) { static_for<0, NSLOT>(fn); };   // fn(slot), slot static
+        // prologue: tile_begin -> buffer 0, raw registers <- tile_begin + 1
+        if (tile_begin < tile_end) {
+            set_tile(tile_begin);
+            for_slots([&](auto S) { for_items(std::integral_constant<int, decltype(S)::value * IPS>{}, [&](auto K) { issue_item(K); }); });
+            mask_cv = mask_ld;
+            cv_n0 = l_n0;
+            sa_cv = *reinterpret_cast<const float4 *>(sA + (cv_n0 < g.N ? cv_n0 : 0) * CV_BM + gc4 * 4);
+            sb_cv = *reinterpret_cast<const float4 *>(sB + (cv_n0 < g.N ? cv_n0 : 0) * CV_CK + pc4 * 4);
+            for_slots([&](auto S) {
+                for_items(std::integral_constant<int, decltype(S)::value * IPS>{}, [&](auto K) { convert_item(K, smem, std::false_type{}); });
+            });
+            set_tile(tile_begin + 1 < tile_end ? tile_begin + 1 : tile_end - 1);
+            for_slots([&](auto S) { for_items(std::integral_constant<int, decltype(S)::value * IPS>{}, [&](auto K) { issue_item(K); }); });
+        }
+        __syncthreads();
+        // two copies of the tile loop (tile within one image / spanning images): a run-time select per item would
+        // put a branch between the loads and cost the exact vmcnt counts
+        auto run = [&](auto ONE) {
+            for (int tile = tile_begin; tile < tile_end; tile++) {
+                const int cur = (tile - tile_begin) & 1;
+                const unsigned char *bgh = smem + cur * bufsz, *bgl = bgh + WG_GY_BYTES;
+                const unsigned char *bph = bgh + 2 * WG_GY_BYTES, *bpl = bph + (t.NPP + 1) * 64;
+                unsigned char *nbuf = smem + (cur ^ 1) * bufsz;
+                mask_cv = mask_ld;                   // the registers hold tile + 1
+                cv_n0 = l_n0;
+                sa_cv = *reinterpret_cast<const float4 *>(sA + (cv_n0 < g.N ? cv_n0 : 0) * CV_BM + gc4 * 4);
+                sb_cv = *reinterpret_cast<const float4 *>(sB + (cv_n0 < g.N ? cv_n0 : 0) * CV_CK + pc4 * 4);
+                // No branch around the staging work: past the end of the range the last tile is simply staged again
+                // (never consumed).  With straight-line VMEM traffic hipcc's waitcnt pass keeps exact counts
+                // (vmcnt(NITEM-1) per converted register); any branch here makes it fall back to vmcnt(0) per slot.
+                set_tile(tile + 2 < tile_end ? tile + 2 : tile_end - 1);
+                f16x8 ahi[4], alo[4];
+                // ONEBB (FAST, small patches): the tile is straight-line code — no branch per slot or item (compile-time tap count,
+                // buffer loads with range-checked offsets) — so hipcc's scheduler spreads the staging work of a slot (fp16 split,
+                // LDS stores, the next global load) and the LDS reads under the MFMAs of its neighbours: 276 -> 300-308 TF at
+                // N = 4, 315-329 -> 338-351 TF at N = 8.  Measured and rejected on top of it: B fragments software-pipelined by
+                // hand one slot ahead with sched_barrier(0) between slots (-3 %), and a sched_group_barrier template for the
+                // whole tile (1 MFMA : 2 VALU with the LDS / VMEM instructions pinned: the scheduler then front-loads ~170
+                // SALU / VALU instructions and emits 11 % more code).
+                constexpr bool ONEBB = FAST != 0 && PMAX <= 4;
+                for_slots([&](auto SC) {
+                    constexpr int S = decltype(SC)::value, kk = S / NT, tt = S % NT;
+                    if constexpr (tt == 0) {
+    #pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int cb = (wm * 64 + i * 16 + p * 4) * 2;
+                            const int o0 = a_row[kk][0] + (cb ^ a_key[kk][0]);
+                            const int o1 = a_row[kk][1] + (cb ^ a_key[kk][1]);
+                            ahi[i] = tr_read2(bgh, o0, o1);
+                            if (SPLIT == 2) alo[i] = tr_read2(bgl, o0, o1);
+                        }
+                    }
+                    for_items(std::integral_constant<int, S * IPS>{}, [&](auto K) { convert_item(K, nbuf, ONE); });
+                    for_items(std::integral_constant<int, S * IPS>{}, [&](auto K) { issue_item(K); });
+                    if (ONEBB || tt < g.ntaps) {     // (ONEBB: the host guarantees ntaps == NT)
+                        const int ts = (ONEBB || tt < g.ntaps) ? tt : 0;
+                        const int toff = (g.dy[ts] - t.dymin) * t.PW + (g.dx[ts] - t.dxmin);
+                        const int pp0 = pbase[kk][0] + toff, pp1 = pbase[kk][1] + toff;
+                        const int o0 = pp0 * 64 + wg_pswz(b_kg, pp0, t.pkb) * 16 + b_sub;
+                        const int o1 = pp1 * 64 + wg_pswz(b_kg, pp1, t.pkb) * 16 + b_sub;
+                        const f16x8 bhi = tr_read2(bph, o0, o1);
+                        f16x8 blo;
+                        if (SPLIT == 2) blo = tr_read2(bpl, o0, o1);
+    #pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            if (SPLIT == 2) {
+                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[i], bhi, acc[i][tt], 0, 0, 0);
+                                acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], blo, acc[i][tt], 0, 0, 0);
+                            }
+                            acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], bhi, acc[i][tt], 0, 0, 0);
+                        }
+                    }
+                });
+                __syncthreads();   // buffer `cur` fully consumed, buffer cur^1 fully written
+            }
+        };
+        if (one_img) run(std::true_type{});
+        else run(std::false_type{});
+    }
+
+    // ---- partial tile -> workspace [split][cot][chunk][tap][32 ci][128 co]: a lane's 4 accumulator
+    // registers are 4 consecutive co of one ci, so the [ci][co] order makes every store a float4
+    float *wsb = ws + (((int64_t)split * t.ncot + cot) * t.nchunks + chunk) * g.ntaps * (CV_BM * CV_CK);
+#pragma unroll
+    for (int tt = 0; tt < NT; tt++) {
+        if (tt < g.ntaps) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int co = wm * 64 + i * 16 + G * 4;
+                const int ci = wn * 16 + (lane & 15);
+                *reinterpret_cast<float4 *>(wsb + (tt * CV_CK + ci) * CV_BM + co) =
+                    make_float4(acc[i][tt][0] * punscale, acc[i][tt][1] * punscale, acc[i][tt][2] * punscale, acc[i][tt][3] * punscale);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ gw,
+                                                           int64_t s_co, int64_t s_ci, int64_t s_t, int Co, int Ci,
+                                                           int ncot, int nchunks, int ntaps, int nsplit, float alpha,
+                                                           int accumulate, rick_conv_geom g) {
+    const int64_t per_split = (int64_t)ncot * nchunks * ntaps * CV_BM * CV_CK;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_split; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i & 127);              // co within tile (fastest in the partial layout)
+        const int k = (int)((i >> 7) & 31);        // ci within chunk
+        int64_t blk = i >> 12;
+        const int tt = (int)(blk % ntaps);
+        blk /= ntaps;
+        const int chunk = (int)(blk % nchunks);
+        const int cot = (int)(blk / nchunks);
+        const int co = cot * CV_BM + r, ci = chunk * CV_CK + k;
+        if (co >= Co || ci >= Ci) continue;
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; sp++) s += ws[sp * per_split + i];
+        float *dst = gw + co * s_co + ci * s_ci + g.wt[tt] * s_t;
+        const float v = s * alpha;
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+
+// Split-K plan of the weight gradient: blocks = co-tiles x chunks x splits, one 400-register block per CU, so the grid
+// runs in waves of 256 blocks.  Minimise  waves x (tiles per block + fixed block cost)  plus a small charge per split
+// for the partial tiles the second stage has to read (measured: 512x512 @64^2, batch 4 runs best as 4 splits of 64
+// tiles = one wave, not 8 x 32).  Multiples of 8 splits get the XCD-aware block mapping and win ties.
+static void wgrad_plan(const rick_conv_geom *g, ConvTiling *t, int *nsplit, int *tps) {
+    make_tiling(g, WG_TILE, t);
+    const int ntiles = t->ntx * t->nty * t->ntn;
+    const int cc = t->ncot * t->nchunks;
+    int best_tps = ntiles, best_cost = 1 << 30;
+    const int smax = ntiles < 64 ? ntiles : 64;
+    for (int s = 1; s <= smax; s++) {
+        const int tp = cdiv(ntiles, s), se = cdiv(ntiles, tp);
+        const int waves = cdiv(cc * se, 256);
+        const int cost = 2 * waves * (tp + 8) + se - ((se & 7) == 0 ? 1 : 0);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best_tps = tp;
+        }
+    }
+    *tps = best_tps;
+    *nsplit = cdiv(ntiles, best_tps);
+}
+
+extern "C" int64_t rick_conv_wgrad_workspace_bytes(const rick_conv_geom *g) {
+    if (check_geom(g)) return -1;
+    ConvTiling t;
+    int nsplit, tps;
+    wgrad_plan(g, &t, &nsplit, &tps);
+    return (int64_t)nsplit * t.ncot * t.nchunks * g->ntaps * CV_BM * CV_CK * 4;
+}
+
+template <int NT, int SPLIT, bool VEC, int PMAX, bool PIPE, int FAST = 0>
+static void launch_wgrad_k(const float *x, const float *gy, float *ws, const float *ascale, const float *bscale,
+                           const rick_conv_geom *g, const ConvTiling &t, int nsplit, int tps, size_t lds, hipStream_t st) {
+    const unsigned nwg = (unsigned)(nsplit * t.ncot * t.nchunks);
+    (void)hipFuncSetAttribute((const void *)conv_wgrad_kernel<NT, SPLIT, VEC, PMAX, PIPE, FAST>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv_wgrad_kernel<NT, SPLIT, VEC, PMAX, PIPE, FAST>), dim3(nwg), dim3(256), lds, st, x, gy, ws, ascale,
+                       bscale, *g, t, nsplit, tps);
+}
+
+static size_t wgrad_lds_bytes(const rick_conv_geom *g, const ConvTiling &t, bool pipe) {
+    const size_t buf = 2 * WG_GY_BYTES + 2 * (size_t)(t.NPP + 1) * 64;
+    return (pipe ? 2 : 1) * buf + (size_t)((t.NPP + 3) & ~3) * 4 + (size_t)g->N * (CV_BM + CV_CK) * 4;
+}
+// The software-pipelined form needs two operand buffers in LDS; production path only (fp16x3, vector loads).
+static bool wgrad_use_pipe(const rick_conv_geom *g, const ConvTiling &t) {
+    static const int off = ablation_env("RICK_WGRAD_NOPIPE", 0);
+    return !off && g->split == 2 && ((g->Ci | g->Co) & 3) == 0 && wgrad_lds_bytes(g, t, true) <= 160 * 1024;
+}
+
+template <int NT>
+static void launch_wgrad(const float *x, const float *gy, float *ws, const float *ascale, const float *bscale,
+                         const rick_conv_geom *g, const ConvTiling &t, int nsplit, int tps, hipStream_t st) {
+    const bool vec = ((g->Ci | g->Co) & 3) == 0;
+    const bool small = t.NPP <= 4 * 32;
+    const bool pipe = wgrad_use_pipe(g, t);
+    const size_t lds = wgrad_lds_bytes(g, t, pipe);
+    // FAST: position grid an exact multiple of the tile, full 128 x 32 channel blocks
+    const bool fast = pipe && g->ntaps == NT && (int64_t)g->N * g->IH * g->IW * g->Ci < (1LL << 29) &&
+                      (int64_t)g->N * g->OH * g->OW * g->Co < (1LL << 29) &&     // (32-bit byte offsets of the buffer loads) !(g->Co % CV_BM) && !(g->Ci % CV_CK) && !(g->GH & ((1 << t.th_log2) - 1)) &&
+                      !(g->GW & ((1 << t.tw_log2) - 1)) && !(g->N % t.nbe) && (t.nb == t.nbe);
+    const bool scaled = ascale != nullptr || bscale != nullptr;
+    // ONE chain: exactly one kernel per call
+    if (g->split == 1 && vec) launch_wgrad_k<NT, 1, true, 12, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (!vec) launch_wgrad_k<NT, 2, false, 12, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (fast && small && scaled) launch_wgrad_k<NT, 2, true, 4, true, 2>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (fast && small) launch_wgrad_k<NT, 2, true, 4, true, 1>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (fast && scaled) launch_wgrad_k<NT, 2, true, 12, true, 2>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (fast) launch_wgrad_k<NT, 2, true, 12, true, 1>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (small && pipe) launch_wgrad_k<NT, 2, true, 4, true>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (small) launch_wgrad_k<NT, 2, true, 4, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else if (pipe) launch_wgrad_k<NT, 2, true, 12, true>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    else launch_wgrad_k<NT, 2, true, 12, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+}
+
+extern "C" int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw, int64_t s_co, int64_t s_ci, int64_t s_t,
+                                   const float *ascale, const float *bscale, const rick_conv_geom *g, int accumulate,
+                                   void *workspace, void *stream) {
+    if (!x || !gy || !gw || !workspace || check_geom(g)) return RICK_EINVAL;
+    if (g->ntaps > 9) return RICK_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)gy | (uintptr_t)(ascale ? ascale : x) | (uintptr_t)(bscale ? bscale : x)) % 16) return RICK_EINVAL;
+    ConvTiling t;
+    int nsplit, tps;
+    wgrad_plan(g, &t, &nsplit, &tps);
+    if (wgrad_lds_bytes(g, t, false) > 160 * 1024 || t.NPP > 12 * 32 || t.PH > 1023 || t.PW > 1023) return RICK_EINVAL;
+    if (g->split == 1 && (((g->Ci | g->Co) & 3) != 0)) return RICK_EINVAL;   // plain-fp16 option: vector path only
+    hipStream_t st = (hipStream_t)stream;
+    float *ws = (float *)workspace;
+    if (g->ntaps == 1) launch_wgrad<1>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
+    else if (g->ntaps <= 4) launch_wgrad<4>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
+    else launch_wgrad<9>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
+    const int64_t per_split = (int64_t)t.ncot * t.nchunks * g->ntaps * CV_BM * CV_CK;
+    int64_t nb = cdiv64(per_split, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, ws, gw, s_co, s_ci, s_t, g->Co, g->Ci,
+                       t.ncot, t.nchunks, g->ntaps, nsplit, g->alpha, accumulate, *g);
+    RICK_LAUNCH_STATUS();
+}
