@@ -58,6 +58,7 @@ def load_adam_state_dict(optim, sd):
 
 def state_dict(trainer):
     """The reference's checkpoint dict (:647-659) for a RickTrainer."""
+    getattr(trainer, '_finish_pending', lambda: None)()      # a deferred optimiser step (data-parallel pipelining) lands first
     return {'g_ema': trainer.g_ema.state_dict(), 'g': trainer.g.state_dict(), 'd': trainer.d.state_dict(),
             'g_optim': adam_state_dict(trainer.g_optim), 'd_optim': adam_state_dict(trainer.d_optim)}
 

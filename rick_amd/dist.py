@@ -12,8 +12,13 @@ the only data-path exchange is the gradient average before each optimiser step:
     its ``all_reduce`` is issued asynchronously (torch.distributed 'nccl' == RCCL on ROCm; it
     runs on the backend's own stream), so communication overlaps the rest of backward;
   * ``all_reduce(flat)`` (called right before the optimiser step) issues whatever is left and
-    waits.  Semantics: mean over ranks == the reference's loss ``.mean()`` over the global batch;
-    minibatch-stddev stays per rank, as under DataParallel's per-device chunks.
+    waits.  Semantics: mean over ranks == the reference's loss ``.mean()`` over the global batch
+    (RCCL's ncclAvg: no separate scaling pass); minibatch-stddev stays per rank, as under
+    DataParallel's per-device chunks;
+  * graph mode (RickTrainer.enable_graphs): ``launch(flat)`` issues every bucket right behind the
+    replayed forward/backward graph and returns; the optimiser graph of that step is DEFERRED
+    (``wait(flat)`` + replay) until the next piece of work that needs the updated parameters —
+    the generator forward of the following G step runs while the D gradients are on the wire.
 
 Fisher sweep: samples are sharded over ranks, grad^2 is reduced per filter locally (linear), and
 only the per-filter vectors (~20 KB) are summed across ranks (``all_reduce_vectors``).
@@ -42,9 +47,11 @@ def init_from_env(backend=None):
 
 
 class DataParallelGrads:
-    def __init__(self, bucket_bytes=32 << 20, group=None):
+    def __init__(self, bucket_bytes=32 << 20, group=None, force=False):
+        """force: run the collectives even with a single rank (the RCCL code path on a one-GPU box: tests)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.bucket_elems = max(1, bucket_bytes // 4)
         self._state = {}       # id(flat) -> dict(buckets, pending, works, hooks)
         self.hooks_enabled = True   # False: no launches from autograd hooks (backward replayed from a hipGraph)
@@ -71,7 +78,7 @@ class DataParallelGrads:
                     st['owner'][i] = b
             self._state[id(flat)] = st
             self._arm(st)
-            if self.world > 1:
+            if self.active:
                 for i in st['owner']:
                     flat.params[i].register_post_accumulate_grad_hook(self._make_hook(st, i))
 
@@ -88,9 +95,12 @@ class DataParallelGrads:
             host = view.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             view.copy_(host)
-            st['works'].append((None, view))
+            st['works'].append((None, view, 1.0 / self.world))
+        elif dist.get_backend(self.group) == 'nccl':
+            # RCCL: the mean itself (ncclAvg), asynchronous on the backend's stream behind the current stream's work
+            st['works'].append((dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True), view, None))
         else:
-            st['works'].append((dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True), view))
+            st['works'].append((dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True), view, 1.0 / self.world))
         st['launched'][b] = True
 
     def _make_hook(self, st, i):
@@ -108,27 +118,38 @@ class DataParallelGrads:
         """Re-count the gradients each bucket waits for from the parameters' CURRENT requires_grad
         flags.  Call after changing flags (warm-up gating, frozen D in the G step) and before
         backward: a bucket armed with stale flags could leave before all of its gradients exist."""
-        if self.world > 1:
+        if self.active:
             self._arm(self._state[id(flat)])
 
-    def all_reduce(self, flat):
-        """Average flat.grad over ranks (finishes the buckets the hooks already started)."""
-        if self.world == 1:
+    def launch(self, flat):
+        """Issue the all-reduce of every bucket that has not left yet and return without waiting."""
+        if not self.active:
             return
         st = self._state[id(flat)]
         for b in range(len(st['buckets'])):
             if not st['launched'][b]:
                 self._launch(st, b)
-        inv = 1.0 / self.world
-        for work, view in st['works']:
+
+    def wait(self, flat):
+        """Make the current stream wait for the launched buckets (and scale where the backend summed)."""
+        if not self.active:
+            return
+        st = self._state[id(flat)]
+        for work, view, scale in st['works']:
             if work is not None:
                 work.wait()
-            view.mul_(inv)
+            if scale is not None:
+                view.mul_(scale)
         self._arm(st)
+
+    def all_reduce(self, flat):
+        """Average flat.grad over ranks (finishes the buckets the hooks already started)."""
+        self.launch(flat)
+        self.wait(flat)
 
     def all_reduce_vectors(self, vectors):
         """Sum small vectors (per-filter Fisher) over ranks in one collective."""
-        if self.world == 1:
+        if not self.active:
             return
         flat = torch.cat([v.reshape(-1) for v in vectors])
         if flat.is_cuda and dist.get_backend(self.group) == 'gloo':
@@ -145,7 +166,7 @@ class DataParallelGrads:
 
     def broadcast_params(self, modules, src=0):
         """Make replicas identical at start-up (one-off)."""
-        if self.world == 1:
+        if not self.active:
             return
         for m in modules:
             for t in list(m.parameters()) + list(m.buffers()):

@@ -185,10 +185,15 @@ class PackGroup:
             self._repack()
         return req['buf']
 
-    def refresh(self):
+    def refresh(self, skip=None):
         """Repack now if any registered request is stale (one launch).  RickTrainer calls this on the host before it
         captures or replays a step graph, so the graphs themselves contain no pack launches and a network is repacked
-        once per update of its weights instead of once per step graph that uses it."""
+        once per update of its weights instead of once per step graph that uses it.  `skip`: a FlatParams whose
+        optimiser step is still pending (data-parallel pipelining) — a group that holds its parameters is left alone."""
+        if skip is not None and self.reqs:
+            first = next(iter(self.reqs.values()))['param']
+            if any(first is p for p in skip.params):
+                return False
         for r in self.reqs.values():
             if r['stamp'] != (r['param']._version, _weights_epoch, self.epoch, _SPLIT):
                 self._repack()

@@ -392,6 +392,7 @@ class RickTrainer:
         self.step_events = None     # list of (step name, event) while bench.py times step types
         self._gs, self._inject, self._layer_idx, self._real = {}, {}, None, None
         self._fisher_state = None   # persistent accumulators / static inputs / captured per-sample graph of the Fisher sweep
+        self._pending = None        # (graph state, flat, optimiser, optimiser graph) of a step whose gradient exchange is in flight
         if dp is not None:
             dp.attach(self.g_flat, self.d_flat)
 
@@ -425,7 +426,7 @@ class RickTrainer:
         parameters' post-accumulate-grad hooks while backward is still running: a sunk gradient fires no hook, so every
         bucket with a conv weight would only leave at the end of backward and nothing would overlap."""
         import contextlib
-        if self.dp is not None and getattr(self.dp, 'hooks_enabled', False) and getattr(self.dp, 'world', 1) > 1:
+        if self.dp is not None and getattr(self.dp, 'hooks_enabled', False) and getattr(self.dp, 'active', getattr(self.dp, 'world', 1) > 1):
             return contextlib.nullcontext()
         return op.grad_sink()
 
@@ -484,8 +485,15 @@ class RickTrainer:
         w = self.g.style(z).view(2, batch, 1, -1)
         return torch.where(self._layer_idx < self._inject[key], w[0], w[1])
 
-    def _run(self, key, fb, flat, optim, pre=None):
-        """fb(): forward + backward into flat.grad;  then gradient exchange and optimiser step."""
+    def _run(self, key, fb, flat, optim, pre=None, fb_head=None):
+        """fb(): forward + backward into flat.grad;  then gradient exchange and optimiser step.
+
+        fb_head(): an optional first part of the step that does not read the parameters the PREVIOUS step is still
+        updating (the generator forward of the G step does not touch D).  Under data parallelism with step graphs the
+        optimiser part of a step is deferred (`_pending`): its gradient buckets are launched right behind the replayed
+        forward/backward graph and the step returns; the next step replays its head, THEN waits for the exchange, replays the
+        pending optimiser graph and continues — the all-reduce of the D gradients travels while the generator forward
+        runs (north star: "overlapped with the next micro-batch forward")."""
         if pre is not None:
             pre()
         st = None
@@ -495,44 +503,87 @@ class RickTrainer:
                 # optimiser state / stage changed under the capture: drop it AND run the two eager warm-up steps again —
                 # a new requires_grad pattern needs new descriptor tables (PackGroup, ModulationBank), which must not be
                 # built inside a capture
+                self._finish_pending()
                 del st['graphs']
                 st['n'] = 0
             st['n'] += 1
         if st is None or st['n'] <= 2:                        # eager (also the warm-up of a graph: caches, allocator)
+            self._finish_pending()
+            if fb_head is not None:
+                fb_head()
             fb()
             self._reduce(flat)
             optim.step()
             return
-        # packed weights are refreshed HERE, on the host side of the graph: a network is repacked once per update of its
-        # weights (the D step's graph used to repack G again although the G step's graph had just done so, and vice versa)
-        for grp in self._pack_groups:
-            grp.refresh()
+        split = self.dp is not None and getattr(self.dp, 'active', True)
         if 'graphs' not in st:
+            self._finish_pending()
+            # packed weights are refreshed on the HOST side of the graphs: a network is repacked once per update of its
+            # weights (the D step's graph used to repack G again although the G step's graph had just done so, and vice versa)
+            for grp in self._pack_groups:
+                grp.refresh()
             torch.cuda.synchronize()
             before = list(optim.steps)
             seen = dict(self.losses)
-            if self.dp is None:
+            if not split:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
+                    if fb_head is not None:
+                        fb_head()
                     fb()
                     optim.step()
-                st['graphs'] = (g,)
+                st['graphs'] = (None, g, None)
             else:
+                # head | forward/backward | optimiser as separate graphs from ONE memory pool: the autograd graph the head
+                # builds (saved activations in pool memory) is consumed by the backward captured in the second graph
+                gh = torch.cuda.CUDAGraph() if fb_head is not None else None
                 g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
+                pool = None
+                if gh is not None:
+                    with torch.cuda.graph(gh):
+                        fb_head()
+                    pool = gh.pool()
+                with torch.cuda.graph(g1, pool=pool):
                     fb()
-                with torch.cuda.graph(g2):
+                with torch.cuda.graph(g2, pool=g1.pool()):
                     optim.step()
-                st['graphs'] = (g1, g2)
+                st['graphs'] = (gh, g1, g2)
             st['runs'] = list(optim.last_runs)
             st['losses'] = {k: v for k, v in self.losses.items() if seen.get(k) is not v}   # this graph's output tensors
             optim.steps[:] = before                           # capture executes nothing: the replay below is this step
             st['sig'] = self._graph_signature(optim)
-        gs = st['graphs']
-        gs[0].replay()
-        if len(gs) == 2:
-            self.dp.all_reduce(flat)
-            gs[1].replay()
+        gh, g1, g2 = st['graphs']
+        if not split:
+            for grp in self._pack_groups:
+                grp.refresh()
+            g1.replay()
+            self._after_optimizer(st, flat, optim)
+            return
+        if gh is not None:
+            for grp in self._pack_groups:                     # (the head only reads networks no pending step is updating)
+                grp.refresh(skip=self._pending_params())
+            gh.replay()                                       # ... while the previous step's buckets are on the wire
+        self._finish_pending()
+        for grp in self._pack_groups:
+            grp.refresh()
+        g1.replay()
+        self.dp.launch(flat)
+        self._pending = (st, flat, optim, g2)
+
+    def _pending_params(self):
+        return None if self._pending is None else self._pending[1]
+
+    def _finish_pending(self):
+        """Complete a step whose optimiser part was deferred: wait for its gradient exchange, replay its optimiser graph."""
+        if self._pending is None:
+            return
+        st, flat, optim, g2 = self._pending
+        self._pending = None
+        self.dp.wait(flat)
+        g2.replay()
+        self._after_optimizer(st, flat, optim)
+
+    def _after_optimizer(self, st, flat, optim):
         optim.last_runs = st['runs']
         optim.note_replayed_step()
         # the replay updated the parameters through raw pointers: packed weights are stale (a host-side counter; the next
@@ -552,6 +603,7 @@ class RickTrainer:
 
     def invalidate_graphs(self):
         """Drop every captured step (after loading a checkpoint or changing optimiser hyper-parameters)."""
+        self._finish_pending()
         for st in self._gs.values():
             st.pop('graphs', None)
             st['n'] = 0                                       # two eager warm-up steps before the next capture
@@ -600,19 +652,23 @@ class RickTrainer:
     def g_step(self, noise, g_noise=None, graph=False):
         key = 'g' if graph else None
         batch = self.cfg.batch
+        box = {}
+
+        def head():                              # generator forward: reads G only (D's update may still be in flight)
+            with self._sink():
+                if graph:
+                    box['fake'], _ = self.g([self._graph_latents(key, batch)], input_is_latent=True, noise=g_noise)
+                else:
+                    box['fake'], _ = self.g(noise, noise=g_noise)
 
         def fb():
             with self._sink(), self._d_frozen():
-                if graph:
-                    fake_img, _ = self.g([self._graph_latents(key, batch)], input_is_latent=True, noise=g_noise)
-                else:
-                    fake_img, _ = self.g(noise, noise=g_noise)
-                fake_pred, _ = self.d(fake_img)
+                fake_pred, _ = self.d(box.pop('fake'))
                 g_loss = g_nonsaturating_loss(fake_pred)
                 self._zero_grad(self.g_flat)
                 g_loss.backward()
             self.losses['g'] = g_loss.detach()
-        self._run(key, fb, self.g_flat, self.g_optim, pre=(lambda: self._draw_inject(key)) if graph else None)
+        self._run(key, fb, self.g_flat, self.g_optim, pre=(lambda: self._draw_inject(key)) if graph else None, fb_head=head)
         return self.losses['g']
 
     def _mixed_latents(self, noise):
@@ -659,6 +715,7 @@ class RickTrainer:
 
     def ema_step(self):
         """accumulate(g_ema, g), accumulate(d_ema, d) (:697-698) over ALL named parameters."""
+        self._finish_pending()
         ema_flat(self.g_ema_flat, self.g_flat, self.cfg.ema_decay)
         ema_flat(self.d_ema_flat, self.d_flat, self.cfg.ema_decay)
 
@@ -685,6 +742,7 @@ class RickTrainer:
         Returns the two PERSISTENT accumulators (scaled grad^2 per parameter): the next sweep zeroes and refills them in
         place — clone what must outlive it."""
         cfg = self.cfg
+        self._finish_pending()
         requires_grad(self.g_ema, True)
         requires_grad(self.d_ema, True)
         g_named, d_named = list(self.g_ema.named_parameters()), list(self.d_ema.named_parameters())

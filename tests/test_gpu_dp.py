@@ -253,3 +253,73 @@ def test_bench_self_launch_two_ranks_one_gpu():
     assert out['n_gpus'] == 2 and out['value'] > 0 and out['config']['global_batch'] == 4
     assert out['ranks']['world_size'] == 2 and len(out['ranks']['ms_per_step_per_rank']) == 2
     assert out['ranks']['backend'] == 'gloo' and out['ranks']['rccl_ranks'] == 0
+
+
+def _nccl_worker(q):
+    """Single rank, backend 'nccl' (= RCCL): the data-parallel code path — bucket launches with ncclAvg, work.wait() stream
+    semantics around replayed step graphs, the deferred optimiser graph with the generator forward running while the D
+    gradients are "on the wire" — on the one GPU this box has.  With one rank the exchange is the identity, so the result
+    must equal the plain trainer's bit for bit."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(q[1]), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    from rick_amd.dist import DataParallelGrads
+    from rick_amd.models import Discriminator, Generator
+    from rick_amd.synth import synth_reals, synth_state_dict
+    from rick_amd.train import RickTrainer, TrainConfig
+    from tests.shapes import discriminator_shapes, generator_shapes
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    size, B, dev = 32, 2, 'cuda:0'
+
+    def build():
+        g = Generator(size, 512, 8, channel_multiplier=2)
+        d = Discriminator(size, channel_multiplier=2)
+        g.load_state_dict(synth_state_dict(generator_shapes(size)), strict=False)
+        d.load_state_dict(synth_state_dict(discriminator_shapes(size)), strict=False)
+        return g.to(dev), d.to(dev)
+
+    out = {}
+    for mode in ('plain', 'rccl'):
+        import random
+        random.seed(3)
+        torch.manual_seed(3)
+        g, d = build()
+        g_ema, d_ema = build()
+        dp = DataParallelGrads(bucket_bytes=256 * 1024, force=True) if mode == 'rccl' else None
+        tr = RickTrainer(TrainConfig(size=size, batch=B, warmup_iter=0), g, d, g_ema, d_ema, dp=dp)
+        if dp is not None:
+            assert dp.active and dist.get_backend() == 'nccl' and len(dp._state[id(tr.d_flat)]['buckets']) >= 3
+        tr.enable_graphs(True)
+        reals = [synth_reals(B, size=size, seed=40 + k).to(dev) for k in range(3)]
+        for i in range(16, 16 + 9):                      # i = 16: R1 + path length; captures happen on each step type's 3rd call
+            tr.iteration(i, reals[i % 3])
+        if dp is not None:
+            assert tr._gs['g']['graphs'][0] is not None and tr._gs['g']['graphs'][2] is not None    # head | fwd/bwd | optimiser
+            assert tr._pending is None                   # ema_step completed the deferred optimiser step
+        torch.cuda.synchronize()
+        out[mode] = [t.detach().cpu().numpy() for t in (tr.g_flat.flat, tr.d_flat.flat, tr.g_ema_flat.flat, tr.d_ema_flat.flat)]
+        out[mode].append(float(tr.losses['g']))
+    dist.destroy_process_group()
+    q[0].put(out)
+
+
+def test_rccl_code_path_single_rank_pipelined_graphs():
+    """RCCL ('nccl' backend) has never seen two devices on this pool, but its code path can run with ONE rank: nine RICK
+    iterations with step graphs through DataParallelGrads(force=True) — AVG all-reduces launched behind the replayed
+    forward/backward graph, the optimiser graph deferred behind the next step's head — leave exactly the parameters, EMA
+    weights and losses of the plain single-process trainer."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    p = ctx.Process(target=_nccl_worker, args=((q, port),))
+    p.start()
+    out = q.get(timeout=900)
+    p.join(60)
+    assert p.exitcode == 0
+    for a, b in zip(out['plain'][:4], out['rccl'][:4]):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+    assert out['plain'][4] == out['rccl'][4]

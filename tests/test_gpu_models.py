@@ -596,3 +596,93 @@ def test_fisher_sweep_graph_replay_equals_eager():
         for k in da:
             assert torch.equal(da[k], db[k]), k
         assert torch.equal(mga, mgb) and torch.equal(mda, mdb)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs 4 and 5 at their own sizes
+def test_eval_sampling_256_batch25_vs_reference(golden):
+    """BASELINE config 4: the evaluator's g_ema sampling loop (gan_training/eval.py:34-41) with n_sample_store = 25 at
+    256 px — 50 images = two generator calls at batch 25 (N = 25 exercises the partial image-group tiles no training
+    batch touches) on the first 50 rows of the shipped noise.pt, against the reference modules' own fp32 outputs
+    (tests/golden/eval256.npz: channel means / stds of all 50 images, 4096 sampled pixels of six of them)."""
+    from rick_amd.evaluate import sample_images
+    gold = golden('eval256')
+    g, _ = build(256)
+    z = torch.from_numpy(golden('noise_latents')['sample_z'][:50])
+    fwd = g.forward
+    g.forward = lambda styles, **kw: fwd(styles, randomize_noise=False, **kw)      # registered noise buffers, like the golden
+    imgs, feats = sample_images(g, 50, n_sample_store=25, latents=z, feature_fn=lambda im: im.mean(dim=(2, 3)))
+    assert imgs.shape == (50, 3, 256, 256) and feats.shape == (50, 3)
+    assert torch.isfinite(imgs).all()
+    assert rel(imgs.mean(dim=(2, 3)), gold['e256/img_mean']) < 2e-4       # means: cancellation over 65 536 pixels
+    assert rel(feats, gold['e256/img_mean']) < 2e-4
+    assert rel(imgs.std(dim=(2, 3)), gold['e256/img_std']) < 2e-5
+    idx = torch.from_numpy(gold['e256/img_idx']).to(DEV)
+    picks = [int(k) for k in gold['e256/picks']]
+    got = torch.stack([imgs[k].reshape(-1)[idx] for k in picks])
+    assert rel(got, gold['e256/img_samples']) < 2e-5                       # north-star bar: 1e-3
+    # the loop's partial last batch: 30 images = 25 + 5
+    imgs30, _ = sample_images(g, 30, n_sample_store=25, latents=z)
+    assert torch.equal(imgs30[:25], imgs[:25])
+    assert rel(imgs30[25:30], imgs[25:30].double().cpu()) < 2e-6           # (batch 25 vs batch 25 again: same tiles)
+
+
+def test_fisher_sweep_256_16_samples(golden):
+    """BASELINE config 5 at 256 px: a 16-sample Fisher sweep (the 10 shipped _noise latents + 6 seeded ones for j >= 10,
+    train_dynamic_update_prune.py:225-269) through the captured per-sample graph.
+      * sample 0 alone reproduces the reference's estimate_fisher goldens (full256.npz: per-key sums, per-filter FIM);
+      * the 16-sample accumulators equal the sum of 16 one-sample sweeps (grad^2 accumulation is linear in the samples);
+      * the freeze / prune index sets equal the oracle's decision code applied to the device FIM, and the masks mark
+        exactly those filters."""
+    from oracle.train_ref import d_decisions_ref, g_decisions_ref
+    from rick_amd.train import RickTrainer, TrainConfig, d_filter_fim, g_filter_fim
+    gold = golden('full256')
+    lat = golden('noise_latents')
+    size, n = 256, 16
+    g, d = build(size)
+    g_ema, d_ema = build(size)
+    cfg = TrainConfig(size=size, batch=4, warmup_iter=0, num_fisher_img=n, fisher_quantile=40.0, prune_quantile=0.1)
+    tr = RickTrainer(cfg, g, d, g_ema, d_ema)
+    zs = [torch.from_numpy(lat[f'noise_{j:04d}']).to(DEV) for j in range(10)] + [synth_latents(1, seed=500 + j).to(DEV) for j in range(10, n)]
+    reals = [synth_reals(2, size=size, seed=256)[0:1].to(DEV)] + [synth_reals(1, size=size, seed=600 + j).to(DEV) for j in range(1, n)]
+    tr.enable_graphs(True)
+
+    # one-sample sweeps (sample 0 doubles as the reference check); scale = 1 / (num_fisher_img * batch)
+    scale = 1.0 / (n * cfg.batch)
+    sum_g, sum_d = None, None
+    for j in range(n):
+        acc_g, acc_d = tr.fisher_sweep([zs[j]], [reals[j]], first=True, fixed_noise=True)
+        if j == 0:
+            check_grad2({k: float(v.double().sum()) / scale for k, v in acc_g.acc.items()}, gold, 'fisher/g_sum', 2e-4, key_tol=2e-3)
+            check_grad2({k: float(v.double().sum()) / scale for k, v in acc_d.acc.items()}, gold, 'fisher/d_sum', 2e-4, key_tol=2e-3)
+            conv, fc = g_filter_fim({k: v / scale for k, v in acc_g.acc.items()})
+            for k in range(12):
+                assert l2rel(conv[f'convs.{k}.conv.weight'], gold[f'fisher/g_conv/{k}']) < 1e-3
+        cg = {k: v.double().clone() for k, v in acc_g.acc.items()}
+        cd = {k: v.double().clone() for k, v in acc_d.acc.items()}
+        sum_g = cg if sum_g is None else {k: sum_g[k] + cg[k] for k in cg}
+        sum_d = cd if sum_d is None else {k: sum_d[k] + cd[k] for k in cd}
+
+    acc_g, acc_d = tr.fisher_sweep(zs, reals, first=True, fixed_noise=True)
+    for k, v in acc_g.acc.items():
+        assert l2rel(v, sum_g[k]) < 2e-6, k                  # fp32 accumulation order only
+    for k, v in acc_d.acc.items():
+        assert l2rel(v, sum_d[k]) < 2e-6, k
+    # decisions: the oracle's restatement of train_dynamic_update_prune.py:279-393 on the DEVICE Fisher tensors
+    fz_g, _, pr_g = g_decisions_ref({k: v.cpu().numpy() for k, v in acc_g.acc.items()}, cfg.fisher_quantile, cfg.prune_quantile,
+                                    n_blocks=len(g.convs))
+    fz_d, _, pr_d = d_decisions_ref({k: v.cpu().numpy() for k, v in acc_d.acc.items()}, cfg.fisher_quantile, cfg.prune_quantile,
+                                    blocks=range(1, len(d.convs)))
+    for got, want in ((tr.idx_freeze_g, fz_g), (tr.zero_idx_g, pr_g), (tr.idx_freeze_d, fz_d), (tr.zero_idx_d, pr_d)):
+        assert set(got) == set(want)
+        for k in want:
+            assert np.array_equal(np.sort(got[k]), np.sort(want[k])), k
+    # README quantiles: 40 % of the filters frozen, 0.1 % pruned (of 4 864 generator conv filters: ~5)
+    n_conv = sum(len(v) for k, v in tr.idx_freeze_g.items() if k.endswith('conv.weight'))
+    assert abs(n_conv / 4864 - 0.60) < 0.01
+    n_pruned = sum(len(v) for k, v in tr.zero_idx_g.items() if k.endswith('conv.weight'))
+    assert 1 <= n_pruned <= 8
+    mask = tr.g_optim.mask.cpu().numpy()
+    lo, hi = tr.g_flat.segment('convs.0.conv.weight')
+    view = mask[lo:hi].reshape(tuple(dict(g.named_parameters())['convs.0.conv.weight'].shape))
+    assert (view[0, tr.idx_freeze_g['convs.0.conv.weight']] & 1).all()

@@ -12,7 +12,7 @@ the reference's own `upfirdn2d_native`, op/upfirdn2d.py:146-149).  Everything el
 Inputs are never stored when they can be regenerated from rick_amd.synth (closed-form,
 seeded by key name); only outputs are.
 
-usage: python tools/make_golden.py [--only ops|layers|small|full|latents|fid|ada|rick|spread]
+usage: python tools/make_golden.py [--only ops|layers|small|full|latents|fid|ada|rick|spread|eval]
 """
 import argparse
 import importlib.util
@@ -587,6 +587,33 @@ def gen_spread(mpt):
     print('spread256.npz', len(out), 'arrays')
 
 
+def gen_eval(mpt):
+    """BASELINE config 4 at its own batch size: the evaluator's sampling loop (gan_training/eval.py:34-41) draws
+    n_sample_store = 25 latents per g_ema call.  Two such calls on the first 50 rows of the shipped noise.pt with the
+    registered noise buffers (randomize_noise=False: the device RNG cannot reproduce the reference's draws), fp32 like the
+    reference: per-image channel means / stds of all 50 images and 4096 sampled pixels of six of them."""
+    out = {}
+    g, _ = build(mpt, 256, torch.float32)
+    z = torch.load(os.path.join(REF, 'noise.pt'))[:50]
+    idx = torch.from_numpy(np.random.RandomState(0).randint(0, 3 * 256 * 256, size=4096))
+    means, stds, picks = [], [], {}
+    with torch.no_grad():
+        for b in range(2):
+            img, _ = g([z[25 * b:25 * (b + 1)]], randomize_noise=False)
+            means.append(img.mean(dim=(2, 3)))
+            stds.append(img.std(dim=(2, 3)))
+            for i in (0, 12, 24):
+                picks[25 * b + i] = img[i].reshape(-1)[idx]
+            print('  eval batch', b, flush=True)
+    out['e256/img_mean'] = np32(torch.cat(means))
+    out['e256/img_std'] = np32(torch.cat(stds))
+    out['e256/img_idx'] = idx.numpy()
+    out['e256/picks'] = np.array(sorted(picks), dtype=np.int64)
+    out['e256/img_samples'] = np32(torch.stack([picks[k] for k in sorted(picks)]))
+    np.savez_compressed(os.path.join(OUT, 'eval256.npz'), **out)
+    print('eval256.npz', len(out), 'arrays')
+
+
 def check_shapes(mpt):
     """tests/shapes.py (the state_dict contract the build's modules are asserted against) == the reference modules'
     state_dict() keys and shapes, at the three sizes the tests use."""
@@ -609,7 +636,7 @@ def main():
         return
     torch.manual_seed(1)
     op, mpt = import_reference()
-    todo = [a.only] if a.only else ['latents', 'ops', 'layers', 'small', 'full', 'ada', 'rick', 'spread']
+    todo = [a.only] if a.only else ['latents', 'ops', 'layers', 'small', 'full', 'ada', 'rick', 'spread', 'eval']
     check_shapes(mpt)
     if 'latents' in todo:
         gen_latents()
@@ -627,6 +654,8 @@ def main():
         gen_rick(mpt)
     if 'spread' in todo:
         gen_spread(mpt)
+    if 'eval' in todo:
+        gen_eval(mpt)
     if not a.only:
         gen_fid()
 
