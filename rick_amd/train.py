@@ -527,7 +527,7 @@ class RickTrainer:
             seen = dict(self.losses)
             if not split:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with self._capture(g):
                     if fb_head is not None:
                         fb_head()
                     fb()
@@ -540,12 +540,12 @@ class RickTrainer:
                 g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 pool = None
                 if gh is not None:
-                    with torch.cuda.graph(gh):
+                    with self._capture(gh):
                         fb_head()
                     pool = gh.pool()
-                with torch.cuda.graph(g1, pool=pool):
+                with self._capture(g1, pool=pool):
                     fb()
-                with torch.cuda.graph(g2, pool=g1.pool()):
+                with self._capture(g2, pool=g1.pool()):
                     optim.step()
                 st['graphs'] = (gh, g1, g2)
             st['runs'] = list(optim.last_runs)
@@ -569,6 +569,15 @@ class RickTrainer:
         g1.replay()
         self.dp.launch(flat)
         self._pending = (st, flat, optim, g2)
+
+    def _capture(self, graph, pool=None):
+        """torch.cuda.graph(...) — with a process group alive, in 'thread_local' capture-error mode: RCCL's watchdog thread
+        polls its events (hipEventQuery) at any time, and under the default 'global' mode such a call from ANOTHER thread
+        while this one is capturing is an error that takes the process down (hipErrorStreamCaptureUnsupported: seen on
+        MI355X with one rank; it is a timing matter, so it would have surfaced on some rank of an 8-GPU run)."""
+        import torch.distributed as dist
+        mode = 'thread_local' if (dist.is_available() and dist.is_initialized()) else 'global'
+        return torch.cuda.graph(graph, pool=pool, capture_error_mode=mode)
 
     def _pending_params(self):
         return None if self._pending is None else self._pending[1]
@@ -768,7 +777,7 @@ class RickTrainer:
                     grp.refresh()
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with self._capture(graph):
                     self._fisher_sample(st['z'], st['real'], acc_g, acc_d, g_params, d_params, fixed_noise)
                 st['graph'] = graph
             if st['graph'] is not None:
