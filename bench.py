@@ -76,15 +76,33 @@ def cpu_baseline(size=256, batch=2, timed=2):
                       f'threads measured 28x slower): ' + ', '.join(f'{t:.1f}' for t in times) + ' s'}
 
 
+def kernel_source_hash():
+    """sha256 over rick_amd/csrc/*.{hip,h} (tools/pmc_traffic.py stores the same digest with the counters)."""
+    import hashlib
+    root = os.path.join(ROOT, 'rick_amd', 'csrc')
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic():
-    """HBM bytes per conv_igemm launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json,
-    produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes over the bench iteration, FETCH_SIZE
-    doubled as the guide prescribes for 16-B/lane reads on gfx950).  None when the file is absent."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f).get('conv_igemm', {}).get('hbm_bytes_per_launch')
+    """(HBM bytes per conv_igemm launch, provenance) from the newest committed rocprofv3 --pmc passes
+    (profiles/rNN_pmc_traffic.json, produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes over the
+    bench iteration, FETCH_SIZE doubled as the guide prescribes for 16-B/lane reads on gfx950).  The provenance says
+    whether the kernel sources are still the ones the counters were collected with.  (None, None) when no file exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    sha = d.get('kernel_source_sha16')
+    return d.get('conv_igemm', {}).get('hbm_bytes_per_launch'), {
+        'file': os.path.relpath(files[-1], ROOT), 'kernel_source_sha16': sha, 'current_kernel_source_sha16': kernel_source_hash(),
+        'counters_describe_current_kernels': sha == kernel_source_hash()}
 
 
 def self_launch(n):
@@ -136,7 +154,8 @@ def main():
     ap.add_argument('--graphs', action='store_true', help='(default) replay captured step graphs; with N > 1 each step is a '
                     'forward/backward graph, the bucketed RCCL all-reduce, and an optimiser graph (--no-graphs: eager issue, '
                     'all-reduce launched from autograd hooks and overlapped with backward, but host-bound)')
-    ap.add_argument('--eval', action='store_true', help='also time G inference (BASELINE config 4: batches of 25)')
+    ap.add_argument('--eval', action='store_true', help='(default on) also time G inference (BASELINE config 4: batches of 25)')
+    ap.add_argument('--no-extras', action='store_true', help='skip the untimed extras: 64-sample Fisher sweep (config 5), G inference (config 4)')
     ap.add_argument('--fisher-img', type=int, default=2, help='samples of the (untimed) Fisher sweep that sets the masks')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -296,12 +315,13 @@ def main():
             torch.cuda.synchronize()
         agg = {}
         by_tag = {}
-        for kind, flops, e0, e1, tag in prof:
+        for kind, flops, e0, e1, tag, abytes in prof:
             dt = e0.elapsed_time(e1) * 1e-3
-            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            a = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += dt
             a[2] += 1
+            a[3] += abytes
             bt = by_tag.setdefault(tag, [0.0, 0.0, 0])
             bt[0] += flops
             bt[1] += dt
@@ -310,26 +330,49 @@ def main():
             for tag, (fl, dt, n) in sorted(by_tag.items(), key=lambda kv: -kv[1][1]):
                 print(f'  {tag:44s} n={n:4d} total {dt*1e3/16:7.3f} ms/step  avg {dt/n*1e6:8.1f} us  {fl/dt/1e12:6.1f} TF',
                       file=sys.stderr)
-        ig = agg.get('igemm', [0.0, 1.0, 1])
+        ig = agg.get('igemm', [0.0, 1.0, 1, 0.0])
+        traffic, traffic_src = load_traffic()
         ach = ig[0] / ig[1] / 1e12
         mult = 3.0 if args.precision == 'fp16x3' else 1.0
         out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel', 'achieved': ach,
                            'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 'traffic': load_traffic(),
+                           'frac': ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                           'algorithmic_bytes_per_launch': ig[3] / max(ig[2], 1),
                            'mfma_issued_frac': mult * ach / MFMA_BF16_DENSE_PEAK_TFLOPS,
                            'launches': ig[2], 'avg_launch_us': 1e6 * ig[1] / max(ig[2], 1),
                            'algorithmic_gflop_per_launch': ig[0] / max(ig[2], 1) / 1e9,
                            'note': 'achieved = algorithmic FLOPs (2*N*OH*OW*Co*Ci*taps) / event-timed duration over '
                                    '16 instrumented iterations (forward, data-gradient and transposed launches of the '
                                    'igemm family incl. their split-K second stage); fp16x3 issues 3 MFMA FLOPs per '
-                                   'algorithmic FLOP; traffic = HBM bytes per launch from profiles/r02_pmc_traffic.json'}
+                                   'algorithmic FLOP; traffic = HBM bytes per launch from the committed counter passes (traffic_source says '
+                                   'whether they were taken with the current kernel sources); algorithmic_bytes_per_launch = fp32 input + '
+                                   'weights + output of each launch, measured in this run'}
         if 'wgrad' in agg:
             wg = agg['wgrad']
             out['roofline']['wgrad_kernel'] = {'achieved': wg[0] / wg[1] / 1e12, 'launches': wg[2],
                                                'avg_launch_us': 1e6 * wg[1] / max(wg[2], 1)}
         conv_s = sum(a[1] for a in agg.values()) / 16
         out['roofline']['conv_family_ms_per_step'] = 1e3 * conv_s
-    if rank == 0 and args.eval:
+    if rank == 0 and not args.no_extras:
+        # BASELINE config 5 at its own size: a 64-sample Fisher sweep (10 shipped-latent stand-ins + 54 seeded), this rank's
+        # share, from the captured per-sample graph
+        from rick_amd.synth import synth_latents as _sl, synth_reals as _sr
+        tr.enable_graphs(use_graphs)
+        n64 = 64
+        cfg64 = cfg.num_fisher_img
+        cfg.num_fisher_img = n64
+        fin = ([_sl(1, seed=500 + j).to(dev) for j in range(n64)], [_sr(1, cfg.size, seed=600 + (j % 8)).to(dev) for j in range(n64)])
+        if world == 1:
+            tr.fisher_sweep(fin[0][:2], fin[1][:2], first=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tr.fisher_sweep(*fin, first=True)
+            torch.cuda.synchronize()
+            out['fisher_sweep_64'] = {'ms': 1e3 * (time.perf_counter() - t0), 'samples': n64,
+                                      'note': 'BASELINE config 5 (num_fisher_img = 64) on one GPU: per-sample graph replay, grad^2 '
+                                              'accumulate, per-filter reduce, decisions, mask upload'}
+        cfg.num_fisher_img = cfg64
+    if rank == 0 and (args.eval or not args.no_extras):
         from rick_amd.evaluate import sample_images
         n = 500
         sample_images(g_ema, 50, 25)

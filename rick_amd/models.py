@@ -159,7 +159,9 @@ class ModulatedConv2d(nn.Module):
         all layers at once."""
         if s is None:
             s = self.modulation(style)                               # [B, Ci]
-        w = self.weight[0]                                           # [Co, Ci, k, k]
+        # [Co, Ci, k, k] as a VIEW (not weight[0]: a select's backward materialises zeros + a copy of the whole weight per use
+        # whenever the gradient travels through autograd — 41 of them in a path-length step)
+        w = self.weight.view(self.out_channel, self.in_channel, self.kernel_size, self.kernel_size)
         if self.kernel_size == 1 and self.out_channel <= 4 and not self.demodulate:
             if rgb_tail is not None and not op.second_order_enabled():
                 # ToRGB: weight modulation, bias and the skip addition inside the one launch (first-order steps)
@@ -347,7 +349,7 @@ class Generator(nn.Module, _FisherMixin):
             if c.demodulate:
                 groups.setdefault(tuple(c.weight.shape), []).append(l)
         for shape, ls in groups.items():
-            Wc = torch.stack([convs[l].weight[0] for l in ls])                          # [L, O, I, k, k]
+            Wc = torch.stack([convs[l].weight.squeeze(0) for l in ls])                  # [L, O, I, k, k]
             wsq = (Wc * convs[ls[0]].scale).pow(2).sum([3, 4])                          # [L, O, I]
             S2 = torch.stack([s_out[l] for l in ls]).pow(2)                             # [L, B, I]
             D = torch.rsqrt(torch.bmm(S2, wsq.transpose(1, 2)) + convs[ls[0]].eps)      # [L, B, O]

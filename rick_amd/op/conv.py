@@ -49,14 +49,14 @@ class launch_profiler:
         _prof = None
 
 
-def _launch(kind, flops, fn, *args, tag=''):
+def _launch(kind, flops, fn, *args, tag='', abytes=0.0):
     if _prof is None:
         return fn(*args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     rc = fn(*args)
     e1.record()
-    _prof.append((kind, flops, e0, e1, tag))
+    _prof.append((kind, flops, e0, e1, tag, abytes))
     return rc
 
 
@@ -309,17 +309,17 @@ def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0, ep
         if nbytes < 0:
             raise RuntimeError('rick_conv_igemm_workspace_bytes: invalid geometry')
         ent = (g, ctypes.byref(g), nbytes, OH, OW, 2.0 * N * OH * OW * O * I * kh * kw,
-               f'conv {I}->{O} k{kh} s{s} N{N} {IH}x{IW}')
+               f'conv {I}->{O} k{kh} s{s} N{N} {IH}x{IW}', 4.0 * (N * IH * IW * I + N * OH * OW * O + O * I * kh * kw))
         _geom_cache[key] = ent
-    g, gref, nbytes, OH, OW, flops, tag = ent
+    g, gref, nbytes, OH, OW, flops, tag, abytes = ent
     y = _empty_nhwc(N, O, OH, OW, x)
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     if epi is not None:
         check(_launch('igemm', flops, lib.rick_conv_igemm_act_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), gref,
-                      ctypes.byref(epi), ptr(ws), stream_ptr(), tag=tag), 'rick_conv_igemm_act_f32')
+                      ctypes.byref(epi), ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_conv_igemm_act_f32')
         return y
     check(_launch('igemm', flops, lib.rick_conv_igemm_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), gref,
-                  ptr(ws), stream_ptr(), tag=tag), 'rick_conv_igemm_f32')
+                  ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_conv_igemm_f32')
     return y
 
 
@@ -340,15 +340,16 @@ def _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha):
         # algorithmic FLOPs: every (input pixel, tap) pair whose output pixel exists
         ny = [sum(1 for iy in range(IH) if 2 * iy + k < OH) for k in range(3)]
         nx = [sum(1 for ix in range(IW) if 2 * ix + k < OW) for k in range(3)]
-        ent = (nbytes, 2.0 * N * O * I * sum(ny) * sum(nx), f'convT {I}->{O} k3 s2 N{N} {IH}x{IW}')
+        ent = (nbytes, 2.0 * N * O * I * sum(ny) * sum(nx), f'convT {I}->{O} k3 s2 N{N} {IH}x{IW}',
+               4.0 * (N * IH * IW * I + N * OH * OW * O + O * I * 9))
         _geom_cache[key] = ent
-    nbytes, flops, tag = ent
+    nbytes, flops, tag, abytes = ent[0], ent[1], ent[2], (ent[3] if len(ent) > 3 else 0.0)
     if nbytes is None:
         return None
     y = _empty_nhwc(N, O, OH, OW, x)
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     check(_launch('igemm', flops, lib.rick_convt2_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), N, IH, IW, I, O,
-                  OH, OW, _SPLIT, alpha, ptr(ws), stream_ptr(), tag=tag), 'rick_convt2_f32')
+                  OH, OW, _SPLIT, alpha, ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_convt2_f32')
     return y
 
 
@@ -401,15 +402,16 @@ def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alph
         nbytes = lib.rick_conv_igemm_multi_workspace_bytes(geoms, len(live))
         if nbytes < 0:
             raise RuntimeError('rick_conv_igemm_multi_workspace_bytes: invalid geometry')
-        ent = (geoms, len(live), nbytes, full, flops, f'convT {I}->{O} k{kh} s{s} N{N} {IH}x{IW}')
+        ent = (geoms, len(live), nbytes, full, flops, f'convT {I}->{O} k{kh} s{s} N{N} {IH}x{IW}',
+               4.0 * (N * IH * IW * I + N * OH * OW * O + O * I * kh * kw))
         _geom_cache[key] = ent
-    geoms, ngeom, nbytes, full, flops, tag = ent
+    geoms, ngeom, nbytes, full, flops, tag, abytes = ent
     y = _empty_nhwc(N, O, OH, OW, x)
     if not full:
         y.zero_()
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     check(_launch('igemm', flops, lib.rick_conv_igemm_multi_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale),
-                  geoms, ngeom, ptr(ws), stream_ptr(), tag=tag), 'rick_conv_igemm_multi_f32')
+                  geoms, ngeom, ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_conv_igemm_multi_f32')
     return y
 
 
@@ -493,19 +495,19 @@ def _wgrad_launch(a, b, kh, kw, s, p, alpha=1.0, ascale=None, bscale=None, out=N
         if nbytes < 0:
             raise RuntimeError('rick_conv_wgrad_workspace_bytes: invalid geometry')
         ent = (g, ctypes.byref(g), max(nbytes, 16), 2.0 * N * AH * AW * O * I * kh * kw,
-               f'wgrad {I}x{O} k{kh} s{s} N{N} a{AH}x{AW} b{BH}x{BW}')
+               f'wgrad {I}x{O} k{kh} s{s} N{N} a{AH}x{AW} b{BH}x{BW}', 4.0 * (N * AH * AW * O + N * BH * BW * I + O * I * kh * kw))
         _geom_cache[key] = ent
-    g, gref, nbytes, flops, tag = ent
+    g, gref, nbytes, flops, tag, abytes = ent
     ws = torch.empty(nbytes, device=a.device, dtype=torch.uint8)
     K = kh * kw
     if out is not None:
         s_co, s_ci = (K, O * K) if transposed else (I * K, K)
         check(_launch('wgrad', flops, lib.rick_conv_wgrad_f32, ptr(b), ptr(a), ptr(out), s_co, s_ci, 1,
-                      ptr(ascale), ptr(bscale), gref, 1, ptr(ws), stream_ptr(), tag=tag), 'rick_conv_wgrad_f32')
+                      ptr(ascale), ptr(bscale), gref, 1, ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_conv_wgrad_f32')
         return None
     gw = torch.empty((O, I, kh, kw), device=a.device, dtype=a.dtype)
     check(_launch('wgrad', flops, lib.rick_conv_wgrad_f32, ptr(b), ptr(a), ptr(gw), I * K, K, 1,
-                  ptr(ascale), ptr(bscale), gref, 0, ptr(ws), stream_ptr(), tag=tag), 'rick_conv_wgrad_f32')
+                  ptr(ascale), ptr(bscale), gref, 0, ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_conv_wgrad_f32')
     return gw
 
 

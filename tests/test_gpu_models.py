@@ -686,3 +686,38 @@ def test_fisher_sweep_256_16_samples(golden):
     lo, hi = tr.g_flat.segment('convs.0.conv.weight')
     view = mask[lo:hi].reshape(tuple(dict(g.named_parameters())['convs.0.conv.weight'].shape))
     assert (view[0, tr.idx_freeze_g['convs.0.conv.weight']] & 1).all()
+
+
+def test_generator_forward_options_vs_oracle():
+    """Generator.forward's remaining arguments (model_probe_tune.py:509-592): two-style mixing at an explicit inject_index,
+    truncation < 1 towards a truncation_latent, return_feats (the 2 * (log2(size) - 2) + 1 StyledConv outputs),
+    input_is_latent with a [B, n_latent, 512] tensor, return_latents — against the oracle at 32 px."""
+    from oracle.model_ref import generator_ref
+    size, B = 32, 3
+    g, _ = build(size)
+    sg = {k: v.double() for k, v in synth_state_dict(generator_shapes(size)).items()}
+    z1, z2 = synth_latents(B, seed=61), synth_latents(B, seed=62)
+    # (a) style mixing at layer 3 + feature list
+    with torch.no_grad():
+        img, feats = g([z1.to(DEV), z2.to(DEV)], inject_index=3, randomize_noise=False, return_feats=True)
+    ref, rfeats = generator_ref(sg, [z1.double(), z2.double()], size=size, inject_index=3, randomize_noise=False, return_feats=True)
+    assert rel(img, ref) < 2e-5
+    assert len(feats) == len(rfeats) == g.num_layers
+    for a, b in zip(feats, rfeats):
+        assert a.shape == b.shape and rel(a, b) < 2e-5
+    # (b) truncation 0.7 towards the mean latent (Generator.mean_latent's formula on fixed z), return_latents
+    zm = synth_latents(64, seed=63)
+    with torch.no_grad():
+        mean_w = g.get_latent(zm.to(DEV)).mean(0, keepdim=True)
+        img, lat = g([z1.to(DEV)], truncation=0.7, truncation_latent=mean_w, randomize_noise=False, return_latents=True)
+    from oracle.model_ref import mapping_ref
+    mean_ref = mapping_ref(sg, zm.double(), 8).mean(0, keepdim=True)
+    assert rel(mean_w, mean_ref) < 2e-5
+    ref, rlat = generator_ref(sg, [z1.double()], size=size, truncation=0.7, truncation_latent=mean_ref, randomize_noise=False,
+                              return_latents=True)
+    assert lat.shape == rlat.shape == (B, g.n_latent, 512) and rel(lat, rlat) < 2e-5
+    assert rel(img, ref) < 2e-5
+    # (c) W+ latents straight in
+    with torch.no_grad():
+        img2, _ = g([lat], input_is_latent=True, randomize_noise=False)
+    assert torch.equal(img2, img)
