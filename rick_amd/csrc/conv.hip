@@ -40,7 +40,7 @@ extern "C" int64_t rick_conv_packed_bytes(int Co, int Ci, int nslices) {
     return packed_tile_bytes(Co, Ci, nslices) + CV_WTRAILER_BYTES;
 }
 
-#define PK_SAMPLES 32    // per thread: up to 8192 strided samples of the tensor
+#define PK_SAMPLES 8     // per thread: up to 2048 strided samples of the tensor (one block: the kernel is latency-bound)
 
 // One block: sampled amax of (w * scale) -> {2^-e, 2^e} into the trailer.
 __device__ __forceinline__ void pack_exponent(const float *__restrict__ w, int64_t s_co, int64_t s_ci, int64_t s_t, int Co,
@@ -167,7 +167,7 @@ extern "C" int rick_conv_pack_weights_multi(const rick_pack_desc *descs_device, 
 static size_t igemm_lds_bytes(const ConvTiling &t, bool has_iscale) {
     (void)has_iscale;   // the scale table is always present (filled with 1 when the conv has no input scale)
     return 2 * CV_WSTEP_BYTES + 2 * (size_t)(t.NPP + 1) * 64 + (size_t)((t.NPP + 3) & ~3) * 4 +
-           (size_t)t.nbe * t.cps * CV_CK * 4;
+           (size_t)t.nbe * t.cps * CV_CK * 4 + 64;      // (+64: the block-exponent reduction scratch)
 }
 
 static int igemm_tile_positions(const rick_conv_geom *g) { return (g->is >= 2 && g->ntaps > 1) ? 64 : CV_BN; }
@@ -367,7 +367,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     // the block -> x * 2^e (conv_common.h).  An all-zero first chunk (padding, pruned channels) falls back to explicit
     // samples over all of the block's chunks.  Called between issue_patch(c_begin) and commit_patch(c_begin).
     auto block_exponent = [&]() {
-        float *red = reinterpret_cast<float *>(pl + t.NPP * 64);      // the spare row: not written before the first commit
+        float *red = sct + t.nbe * cspan;                             // 16 floats behind the scale table, used for nothing else
         float m = 0.f;
 #pragma unroll
         for (int k = 0; k < PSET; k++) {

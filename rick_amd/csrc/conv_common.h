@@ -64,13 +64,12 @@ __device__ __forceinline__ float amax4(float m, const float4 v) {
     return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
 
-// wave64 max, then across the block's waves through `red` (>= blockDim.x / 64 floats of LDS); result in every thread.
-// Contains two barriers.
+// wave64 max, then across the block's waves through `red` (>= blockDim.x / 64 floats of LDS that nobody is reading or
+// writing at the moment of the call); result in every thread.  ONE barrier.
 __device__ __forceinline__ float block_amax(float v, float *red) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     const int nw = (int)blockDim.x >> 6;
-    __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     float m = red[0];
