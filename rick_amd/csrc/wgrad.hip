@@ -15,6 +15,9 @@
 //              the igemm's bit 2 makes every such read 2-way: 31 % of the LDS cycles were conflicts in round 2);
 //              narrower tiles and stride-2 geometries keep bit 2 (tools/lds_sim.py)
 #define WG_TILE 64
+#ifndef WG_BUF12
+#define WG_BUF12 1      // stride-2 patches (PMAX = 12): range-checked buffer loads as well, but one basic block per SLOT
+#endif
 #define WG_GY_BYTES (WG_TILE * CV_BM * 2)   // 16 KB (one of hi / lo)
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             constexpr int K = decltype(KC)::value;
             if constexpr (FAST && K < 8) {
                 // buffer loads: one descriptor per tensor, the tile's origin and the item in a 32-bit byte offset
-                if constexpr (PMAX <= 4) gq[K] = buf_load4(g_rsrc, (unsigned)(g_toff + g_rel[K] * 4));
+                if constexpr (PMAX <= 4 || WG_BUF12) gq[K] = buf_load4(g_rsrc, (unsigned)(g_toff + g_rel[K] * 4));
                 else gq[K] = *reinterpret_cast<const float4 *>(gbase + g_rel[K]);
             } else if constexpr (FAST) {
                 constexpr int P = K - 8;
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                 // into basic blocks and kept the scheduler from spreading the staging work under the MFMAs.
                 // (PMAX = 12, the stride-2 patches: one basic block per tile needs more registers than the 512 there are — 54-89
                 // spilled in the loop, measured 227 -> 204 TF — so those keep the pointer select and its per-item branch)
-                if constexpr (PMAX <= 4) pq[P] = buf_load4(x_rsrc, ok ? (unsigned)(x_toff + p_rel[P] * 4) : 0xFFFFFFF0u);
+                if constexpr (PMAX <= 4 || WG_BUF12) pq[P] = buf_load4(x_rsrc, ok ? (unsigned)(x_toff + p_rel[P] * 4) : 0xFFFFFFF0u);
                 else pq[P] = *reinterpret_cast<const float4 *>(ok ? xbase + p_rel[P] : g_zero_page);
             } else if constexpr (K < 8) {
                 const unsigned e = g_pyx[K];
