@@ -368,6 +368,12 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     // samples over all of the block's chunks.  Called between issue_patch(c_begin) and commit_patch(c_begin).
     auto block_exponent = [&]() {
         float *red = sct + t.nbe * cspan;                             // 16 floats behind the scale table, used for nothing else
+#ifdef RICK_ABLATION
+        if (t.debug & 8) {   // timing-only ablation (RICK_CONV_DEBUG=8): no exponent (values are wrong for data far from 1)
+            unscale = *reinterpret_cast<const float *>(wpk + (int64_t)t.ncot * t.nchunks * g.nslices * CV_WSTEP_BYTES);
+            return;
+        }
+#endif
         float m = 0.f;
 #pragma unroll
         for (int k = 0; k < PSET; k++) {
@@ -894,7 +900,7 @@ static void launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *
     static const int no_unroll = ablation_env("RICK_IGEMM_NOUNROLL", 0);
     static const int u9_minchunks = ablation_env("RICK_U9_MINCHUNKS", 4), u9_s2 = ablation_env("RICK_U9_S2", 1);
     static const int u9_split = ablation_env("RICK_U9_SPLIT", 4);    // split-K launches too when a split keeps >= 4 chunks (+5..13 %)
-    const bool u9 = SPLIT == 2 && VEC && g->ntaps == 9 && !no_unroll && !t.debug && igemm_tile_positions(g) == CV_BN &&
+    const bool u9 = SPLIT == 2 && VEC && g->ntaps == 9 && !no_unroll && !(t.debug & 7) && igemm_tile_positions(g) == CV_BN &&
                     t.NPP <= IG_DEEP_NPP && (t.nsplit == 1 || (u9_split && t.cps >= u9_split)) && t.cps >= u9_minchunks;
     const bool u9s2 = SPLIT == 2 && VEC && g->ntaps == 9 && u9_s2 && igemm_tile_positions(g) == 64 && t.NPP <= 32 * IG_PMAX &&
                       (t.nsplit == 1 || (u9_split && t.cps >= u9_split)) && t.cps >= u9_minchunks;

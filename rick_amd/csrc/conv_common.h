@@ -26,7 +26,8 @@ __host__ __device__ __forceinline__ int cv_swz(int kg, int row) { return kg ^ ((
 // hi*hi + hi*lo + lo*hi accumulate in ONE fp32 accumulator (lo carries no extra factor), the result is multiplied by
 // 2^-e in the epilogue (exact).
 //   * values within 2^(T+3) = 32x of the sampled maximum: |x - hi - lo| <= 2^-22 |x| (fp16 has 11 significant bits,
-//     twice) - fp32-grade, 64x finer than a bf16 hi/lo split (2^-16) at the same three MFMAs; measured on MI355X:
+//     twice) - fp32-grade, 64x finer than a bf16 hi/lo split (2^-16) at the same three MFMAs and the same 12 conversion
+//     instructions per 4 elements; measured on MI355X:
 //     2-4e-7 of the output maximum on every layer shape, the level of an fp32 CPU convolution (tools/diag_precision.py);
 //   * both roundings are to NEAREST on purpose: with hi rounded towards zero (v_cvt_pkrtz_f16_f32, which would saturate
 //     instead of overflowing) lo always has the sign of x, the dropped lo*lo term always has the sign of the product,
@@ -77,44 +78,31 @@ __device__ __forceinline__ float block_amax(float v, float *red) {
     return m;
 }
 
-// (v * s) -> fp16 hi / lo pairs in 8 VALU per 4 elements, the scale included: v_fma_mixlo/mixhi_f16 evaluate an fp32 fma
-// and round the result ONCE to fp16 into one half of the destination register, with each source read as fp32 or as one
-// half of an fp16 pair:   hi = f16(v * s + 0),   lo = f16(v * s - hi)   (the fma is exact before the rounding, so lo is
-// the correctly rounded residual).  The cvt-based form costs 12 (2 v_pk_mul, 2 v_cvt_pk, 4 v_cvt_f32_f16, 2 v_pk_add, 2
-// v_cvt_pk) and the kernels are bound by the issue of exactly these instructions.  SPLIT == 1 (plain fp16): hi only.
+// (v * s) -> fp16 hi / lo pairs: 12 VALU per 4 elements, the scale included — 2 v_pk_mul_f32, 2 v_cvt_pk_f16_f32 (hi),
+// 4 v_cvt_f32_f16, 2 v_pk_fma_f32 (x*s - hi, exact before its rounding), 2 v_cvt_pk_f16_f32 (lo) — all full-rate
+// instructions: 41 issue cycles per split on one SIMD.  The shorter-looking form on v_fma_mixlo/mixhi_f16 (8 instructions:
+// f16(v*s) and f16(v*s - hi) with the fp16 hi read back in place) was built first and is SLOWER: the mix instructions
+// issue at half rate — 57 cycles per split (tools/micro/split_rate.hip on MI355X: 89 / 73 / 74 cycles per round for mix /
+// this form / round 2's bf16 split, each round carrying 8 further VALU).  SPLIT == 1 (plain fp16): hi only.
 // `s` per element (input-scale table x block exponent) ...
 template <int SPLIT>
 __device__ __forceinline__ void split4v(const float4 v, const float4 s, uint2 &hi, uint2 &lo) {
-    unsigned h0, h1, l0 = 0, l1 = 0;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(v.x), "v"(s.x));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(v.y), "v"(s.y));
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1) : "v"(v.z), "v"(s.z));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(v.w), "v"(s.w));
-    if (SPLIT == 2) {
-        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(v.x), "v"(s.x), "v"(h0));
-        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(v.y), "v"(s.y), "v"(h0));
-        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(v.z), "v"(s.z), "v"(h1));
-        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(v.w), "v"(s.w), "v"(h1));
+    const float4 w = make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
+    const f16x2 h0 = __builtin_convertvector((f32x2_t){w.x, w.y}, f16x2);
+    const f16x2 h1 = __builtin_convertvector((f32x2_t){w.z, w.w}, f16x2);
+    hi.x = *reinterpret_cast<const unsigned *>(&h0);
+    hi.y = *reinterpret_cast<const unsigned *>(&h1);
+    if (SPLIT == 1) {
+        lo.x = lo.y = 0;
+        return;
     }
-    hi = make_uint2(h0, h1);
-    lo = make_uint2(l0, l1);
+    lo.x = pack_f16_rne(w.x - (float)h0[0], w.y - (float)h0[1]);
+    lo.y = pack_f16_rne(w.z - (float)h1[0], w.w - (float)h1[1]);
 }
 // ... or one block-uniform scale (the exponent alone) from an SGPR.
 template <int SPLIT>
 __device__ __forceinline__ void split4s(const float4 v, const float s, uint2 &hi, uint2 &lo) {
-    unsigned h0, h1, l0 = 0, l1 = 0;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(v.x), "s"(s));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(v.y), "s"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1) : "v"(v.z), "s"(s));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(v.w), "s"(s));
-    if (SPLIT == 2) {
-        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(v.x), "s"(s), "v"(h0));
-        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(v.y), "s"(s), "v"(h0));
-        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(v.z), "s"(s), "v"(h1));
-        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(v.w), "s"(s), "v"(h1));
-    }
-    hi = make_uint2(h0, h1);
-    lo = make_uint2(l0, l1);
+    split4v<SPLIT>(v, make_float4(s, s, s, s), hi, lo);
 }
 
 __device__ __forceinline__ void split1(float v, unsigned short &hi, unsigned short &lo, int split) {

@@ -3,9 +3,9 @@
 # bench iterations, SQ / LDS counters of the three MFMA kernels, the conv and HBM micro-benchmarks.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 o=gpurun_out/final3; rm -rf $o; mkdir -p $o
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats -o bench -- python3 bench.py --steps 32 --warmup 0 --no-fisher --no-cpu-baseline --no-roofline --no-step-times > $o/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats -o bench -- python3 bench.py --steps 32 --warmup 0 --no-fisher --no-cpu-baseline --no-roofline --no-step-times --no-extras > $o/stats.log 2>&1
 rm -f $o/stats/*/bench_kernel_trace.csv $o/stats/bench_kernel_trace.csv
-A="--no-graphs --no-fisher --no-cpu-baseline --no-roofline --no-step-times --steps 16 --warmup 0"
+A="--no-graphs --no-fisher --no-cpu-baseline --no-roofline --no-step-times --no-extras --steps 16 --warmup 0"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch -o t -- python3 bench.py $A > $o/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -o t -- python3 bench.py $A > $o/pmc_write.log 2>&1
 python3 tools/pmc_traffic.py $o/pmc_fetch $o/pmc_write $o/r03_pmc_traffic.json > $o/pmc_traffic.txt 2>&1
