@@ -397,17 +397,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                 if constexpr (K < 8) {
                     const float4 v = gq[K];
                     if constexpr (FAST == 2) {     // modulated layers (G) carry per-(image, channel) scales (x block exponent)
-                        if constexpr (ONE_IMG) split4v<SPLIT>(v, sa_cv, hi, lo);
-                        else split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sA + (cv_n0 + (int)(g_pyx[K] >> 20)) * CV_BM + gc4 * 4), hi, lo);
-                    } else split4s<SPLIT>(v, xsa, hi, lo);   // block exponent from an SGPR
+                        if constexpr (ONE_IMG) split4v_mix<SPLIT>(v, sa_cv, hi, lo);
+                        else split4v_mix<SPLIT>(v, *reinterpret_cast<const float4 *>(sA + (cv_n0 + (int)(g_pyx[K] >> 20)) * CV_BM + gc4 * 4), hi, lo);
+                    } else split4s_mix<SPLIT>(v, xsa, hi, lo);   // block exponent from an SGPR
                     *reinterpret_cast<uint2 *>(buf + g_lds[K]) = hi;
                     *reinterpret_cast<uint2 *>(buf + WG_GY_BYTES + g_lds[K]) = lo;
                 } else {
                     const float4 v = pq[K - 8];
                     if constexpr (FAST == 2) {     // (an out-of-range item read the zero page: 0 * scale stays 0)
-                        if constexpr (ONE_IMG) split4v<SPLIT>(v, sb_cv, hi, lo);
-                        else split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sB + (cv_n0 + (int)((p_pyx[K - 8] >> 20) & 15)) * CV_CK + pc4 * 4), hi, lo);
-                    } else split4s<SPLIT>(v, xsb, hi, lo);
+                        if constexpr (ONE_IMG) split4v_mix<SPLIT>(v, sb_cv, hi, lo);
+                        else split4v_mix<SPLIT>(v, *reinterpret_cast<const float4 *>(sB + (cv_n0 + (int)((p_pyx[K - 8] >> 20) & 15)) * CV_CK + pc4 * 4), hi, lo);
+                    } else split4s_mix<SPLIT>(v, xsb, hi, lo);
                     *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + p_lds[K - 8]) = hi;
                     *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + (t.NPP + 1) * 64 + p_lds[K - 8]) = lo;
                 }
