@@ -624,8 +624,9 @@ static void launch_wgrad(const float *x, const float *gy, float *ws, const float
     const bool pipe = wgrad_use_pipe(g, t);
     const size_t lds = wgrad_lds_bytes(g, t, pipe);
     // FAST: position grid an exact multiple of the tile, full 128 x 32 channel blocks
-    const bool fast = pipe && g->ntaps == NT && (int64_t)g->N * g->IH * g->IW * g->Ci < (1LL << 29) &&
-                      (int64_t)g->N * g->OH * g->OW * g->Co < (1LL << 29) &&     // (32-bit byte offsets of the buffer loads) !(g->Co % CV_BM) && !(g->Ci % CV_CK) && !(g->GH & ((1 << t.th_log2) - 1)) &&
+    const bool fast = pipe && g->ntaps == NT &&
+                      (int64_t)g->N * g->IH * g->IW * g->Ci < (1LL << 29) && (int64_t)g->N * g->OH * g->OW * g->Co < (1LL << 29) &&   // (32-bit byte offsets of the buffer loads)
+                      !(g->Co % CV_BM) && !(g->Ci % CV_CK) && !(g->GH & ((1 << t.th_log2) - 1)) &&
                       !(g->GW & ((1 << t.tw_log2) - 1)) && !(g->N % t.nbe) && (t.nb == t.nbe);
     const bool scaled = ascale != nullptr || bscale != nullptr;
     // ONE chain: exactly one kernel per call

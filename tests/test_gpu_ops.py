@@ -132,6 +132,9 @@ CONV_CASES = [
     ('k1_s2', 2, 64, 32, 15, 15, 1, 2, 0),
     ('k1_s1', 2, 32, 64, 8, 8, 1, 1, 0),
     ('co256', 1, 32, 256, 8, 8, 3, 1, 1),
+    ('co192', 2, 64, 192, 16, 16, 3, 1, 1),        # Co % 128 != 0: weight gradient must not take the whole-tile (FAST) form
+    ('h18', 2, 32, 128, 18, 16, 3, 1, 1),          # 18 rows: not a multiple of the 16 x 4 position tile (two images: a whole-tile read of image 0 would run into image 1)
+    ('ci48', 2, 48, 128, 16, 16, 3, 1, 1),         # Ci % 32 != 0
 ]
 
 
