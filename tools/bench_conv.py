@@ -18,6 +18,14 @@ def timeit(fn, reps=20, warm=3):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 B = int(os.environ.get('B', 4))
+DATA = os.environ.get('DATA', 'randn')   # 'sign': +-1 everywhere (no fp16-subnormal lo parts, minimal mantissa toggling)
+_randn = torch.randn
+if DATA == 'sign':
+    torch.randn = lambda *a, **k: torch.sign(_randn(*a, **k))
+if DATA == 'unif':      # magnitudes in [0.5, 1): full mantissa activity, lo parts in the fp16 NORMAL range
+    torch.randn = lambda *a, **k: torch.sign(_randn(*a, **k)) * (0.5 + 0.5 * torch.rand(*a, **k))
+if DATA == 'small':     # 90 % of the values 2^-8 of the rest: most lo parts are fp16 subnormals
+    torch.randn = lambda *a, **k: _randn(*a, **k) * torch.where(torch.rand(*a, **k) < 0.9, 2.0 ** -8, 1.0)
 SC = int(os.environ.get('SCALES', 0))   # 1: per-(image, channel) input/output scales as in the modulated convs
 which = sys.argv[1:] or ['fprop', 'dgrad', 'wgrad']
 shapes = [(512, 512, 4), (512, 512, 8), (512, 512, 16), (512, 512, 32), (512, 512, 64), (256, 256, 128), (128, 128, 256),
