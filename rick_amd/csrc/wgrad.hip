@@ -43,8 +43,8 @@ __device__ __forceinline__ int wg_pswz(int kg, int pix, int kb) { return kg ^ ((
 // FAST (pipelined form; the host selects it for layers whose position grid is an exact multiple of the tile and whose
 // channel counts fill the 128 x 32 block — every 3x3 / 1x1 convolution of both networks at >= 8x8): staging is stripped to
 // what such a layer needs.  gy items are always valid (one unconditional load, no mask bookkeeping); x items test two
-// unsigned compares (halo of the padding) and read the zero page when outside; conversion is the fp16 split plus, for
-// the modulated layers only, the scale multiply — no zero-select.  ~15 / ~22 instructions per item instead of ~30.  The
+// unsigned compares (halo of the padding) and take a buffer-load offset beyond the descriptor's range when outside (the
+// hardware returns zeros); conversion is the fp16 split with the scale folded in — no zero-select.  ~15 / ~22 instructions per item instead of ~30.  The
 // kernel is bound by the ISSUE of exactly these instructions (one wave per SIMD, 2-3 of them per MFMA, and an MFMA
 // leaves room for ~2), not by the matrix pipe: measured +20...27 % (280 -> 330-345 TFLOP/s on the 64^2...256^2 layers).
 template <int NT, int SPLIT, bool VEC, int PMAX, bool PIPE, int FAST = 0>   // FAST: 1 = no per-channel scales, 2 = with
@@ -313,12 +313,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         // in the shadow of the matrix pipe — and re-issues each register's global load for tile t+2 as soon as
         // the register is free.  One barrier per tile; a load has a whole tile period to land.
         constexpr int NITEM = 8 + PMAX, NSLOT = 2 * NT, IPS = (NITEM + NSLOT - 1) / NSLOT;
-        // the zero page's address as an opaque register value: left visible, hipcc sinks its materialisation (s_getpc + add)
-        // into a per-item branch (s_and_saveexec / s_cbranch_execz), which cuts the tile's code into basic blocks and keeps the
-        // scheduler from spreading the staging work under the MFMAs
-        const float *zero_page = g_zero_page;
-        asm volatile("" : "+s"(zero_page));
-        (void)zero_page;
         // FAST: buffer descriptors over the whole tensors (the host only selects FAST below 4 GB per tensor)
         const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(gy), 0, FAST ? (unsigned)((int64_t)g.N * g.OH * g.OW * g.Co * 4) : 0u, 0x00020000);

@@ -329,7 +329,6 @@ def _nccl_worker(q):
         out[mode].append(float(tr.losses['g']))
     res = {'equal': [bool(torch.equal(a, b)) for a, b in zip(out['plain'][:4], out['rccl'][:4])],
            'finite': [bool(torch.isfinite(a).all()) for a in out['rccl'][:4]],
-           'moved': bool((out['rccl'][0] != build()[0].state_dict()['convs.0.conv.weight'].new_zeros(1)).any()),
            'g_loss': (out['plain'][4], out['rccl'][4])}
     dist.destroy_process_group()
     q[0].put(res)
