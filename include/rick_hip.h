@@ -178,8 +178,10 @@ int64_t rick_convt2_workspace_bytes(int N, int IH, int IW, int Ci, int Co, int O
 int rick_convt2_f32(const float *x, const void *packed_w, float *out, const float *iscale, const float *oscale,
                     int N, int IH, int IW, int Ci, int Co, int OH, int OW, int split, float alpha,
                     void *workspace, void *stream);
-/* The tile / split plan the launch above will use: out6 = {TW, TH, NB, blocks before the split, nsplit, chunks per split}. */
-int rick_convt2_plan(int N, int IH, int IW, int Ci, int Co, int OH, int OW, int *out6);
+/* The tile / split plan the launch above will use: out8 = {TW, TH, NB, tiles, nsplit, chunks per split, nfull, subq}:
+ * tiles x nsplit work items; the first nfull run as one block each, every later one as subq blocks with 8 / subq of the
+ * tile's fragment columns (the last, partly filled round of 256 blocks). */
+int rick_convt2_plan(int N, int IH, int IW, int Ci, int Co, int OH, int OW, int *out8);
 /* The plan's lane-slot -> tile-position table (128 entries, bit 7 = unused slot) and its patch-window pitch in pixels:
  * the permutation that makes the kernel's LDS reads bank-conflict-free (tools/lds_sim.py checks it). */
 int rick_convt2_posmap(int N, int IH, int IW, int Ci, int Co, int OH, int OW, unsigned char *out128, int *pitch);

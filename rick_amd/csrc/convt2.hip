@@ -27,6 +27,10 @@
 #define CT_THREADS 512
 #define CT_PITEMS 3                       // patch float4 per thread: up to 192 patch pixels
 #define CT_MAX_NPP (CT_PITEMS * (CT_THREADS / 8))
+// time of a block that computes 4 / 2 of its tile's 8 fragment columns, % of a whole-tile block (measured,
+// tools/abl_ct2_subcal.sh: 67-70 % / 64 % — staging and the weight stream do not shrink with the columns)
+#define CT_SUB2_PCT 68
+#define CT_SUB4_PCT 64
 
 // zeros that out-of-range patch items load (no zero-select afterwards; see conv.hip)
 __device__ __attribute__((aligned(64))) float g_ct2_zero_page[16];
@@ -38,12 +42,16 @@ struct Ct2Plan {
     int PH, PW, NPP;                // patch = (TH+1) x (TW+1) input pixels per image, NB images
     int nchunks, ncot, nsplit, cps;
     float alpha;
+    // work items [0, nfull) run as whole-tile blocks; every later one is shared by subq blocks, each with 8 / subq of the
+    // tile's 8 fragment columns, in a second launch (ct2_plan: the last, partly filled round of a grid then takes a
+    // fraction of a round's time).  item0: first work item of the launch.
+    int nfull, subq, item0;
     // lane slot (j * 16 + l15) -> tile position (bit 7: slot unused), 4 slots per word; a permutation that makes every
     // ds_read_b128 of the patch conflict-free (ct2_position_map)
     unsigned posw[32];
 };
 
-template <int SPLIT>
+template <int SPLIT, int NJ>
 __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restrict__ x,
                                                            const unsigned char *__restrict__ wpk,
                                                            float *__restrict__ out, const float *__restrict__ iscale,
@@ -60,7 +68,11 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
         reinterpret_cast<unsigned *>(spos)[threadIdx.x] = w;
     }
 
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    // work item, and the fragment columns [jbase, jbase + NJ) of its tile this block computes (NJ < 8: the launch of the
+    // grid's last, partly filled round — 8 / NJ consecutive blocks, on one XCD, share a work item)
+    const int r = xcd_remap(blockIdx.x, gridDim.x);
+    const int lid = P.item0 + r / (8 / NJ);
+    const int jbase = (r % (8 / NJ)) * NJ;
     const int npos_tiles = P.ntx * P.nty * P.ntn;
     int pt = lid % npos_tiles;
     const int split = (lid / npos_tiles) % P.nsplit;
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     unsigned slotpos[2] = {0, 0};                             // this lane's 8 table entries (positions of slots j * 16 + l15)
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const unsigned ent = spos[j * 16 + l15];
+        const unsigned ent = spos[(jbase + (j < NJ ? j : 0)) * 16 + l15];
         slotpos[j >> 2] |= ent << (8 * (j & 3));
         const int pos = (int)(ent & 127u);
         int nbi = pos / tpos;
@@ -218,11 +230,11 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
         return -((!py && ty) ? P.PW : 0) - ((!px && tx) ? 1 : 0);
     };
 
-    f32x4 acc[4][8];
+    f32x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // A fragments of the NEXT tap roll into the registers the current tap releases: a tap multiplies positions 0-63
     // (all four 16-row groups), then positions 64-127; in that second half row group i is finished after its 12 MFMAs
@@ -236,11 +248,12 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
         if (SPLIT == 2) alo[i] = *reinterpret_cast<const f16x8 *>(wt + CV_WTILE_BYTES + i * 1024);
     };
     auto mma_tap = [&](const unsigned char *ph, const unsigned char *pl, int toff, const unsigned char *wnext) {
+        constexpr int NJH = NJ > 4 ? 2 : 1, NJJ = NJ < 4 ? NJ : 4;
 #pragma unroll
-        for (int jh = 0; jh < 2; jh++) {
-            f16x8 bhi[4], blo[4];
+        for (int jh = 0; jh < NJH; jh++) {
+            f16x8 bhi[NJJ], blo[NJJ];
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
+            for (int jj = 0; jj < NJJ; jj++) {
                 const int pp = pb[jh * 4 + jj] + toff;
                 const int off = pp * 64 + cv_swz(kg, pp) * 16;
                 bhi[jj] = *reinterpret_cast<const f16x8 *>(ph + off);
@@ -249,7 +262,7 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
             static_for<0, 4>([&](auto IC) {
                 constexpr int i = decltype(IC)::value;
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
+                for (int jj = 0; jj < NJJ; jj++) {
                     f32x4 &a = acc[i][jh * 4 + jj];
                     if (SPLIT == 2) {
                         a = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[i], bhi[jj], a, 0, 0, 0);
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
                     }
                     a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], bhi[jj], a, 0, 0, 0);
                 }
-                if (jh == 1) load_a(IC, wnext);
+                if (jh == NJH - 1) load_a(IC, wnext);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -295,7 +308,7 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     const int64_t osz = (int64_t)P.N * P.OH * P.OW * P.Co;
     const float oalpha = P.alpha * unscale;                   // exact: the exponents are powers of two
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < NJ; j++) {
         const unsigned ent = (slotpos[j >> 2] >> (8 * (j & 3))) & 255u;
         const int pos = (int)(ent & 127u);
         const int nbi = pos / tpos, rem = pos - nbi * tpos;
@@ -433,15 +446,24 @@ static int ct2_plan(int N, int IH, int IW, int Ci, int Co, int OH, int OW, float
                 const int cps = cdiv(p->nchunks, s), se = cdiv(p->nchunks, cps);
                 // (two double-buffered hi/lo patch images + the [nb][cps * 32] scale table must fit the LDS)
                 if (4 * (size_t)npp * 64 + (size_t)nb * cps * CV_CK * 4 > 160 * 1024) continue;
-                const long waves = (tiles * se + 255) / 256;
-                // rough time model in ns: a block needs ~6 us per channel chunk (9 taps x 96 MFMAs per wave) + ~4 us fixed;
+                // rough time model in ns: a block needs ~6 us per channel chunk (9 taps x 96 MFMAs per wave) + ~4 us fixed and
+                // the grid runs in rounds of 256.  The last, partly filled round would cost a whole round: its R work items
+                // are shared by 2 or 4 blocks each (4 / 2 of the tile's 8 fragment columns; CT_SUB2_PCT / CT_SUB4_PCT of a
+                // whole block's time) when they still fit one round — 286 blocks: 2 rounds -> 1.64.
+                const long blocks = tiles * se, full = blocks / 256, rest = blocks % 256;
+                const long tb = cps * 6000L + 4000L;
+                long tail = rest ? tb : 0;
+                int subq = 1;
+                if (rest && 2 * rest <= 256 && tb * CT_SUB2_PCT / 100 < tail) { tail = tb * CT_SUB2_PCT / 100; subq = 2; }
+                if (rest && 4 * rest <= 256 && tb * CT_SUB4_PCT / 100 < tail) { tail = tb * CT_SUB4_PCT / 100; subq = 4; }
                 // a split writes and re-reads se partial copies of the output (~4 TB/s) plus a second launch.  Patch rows
                 // shorter than 8 pixels stage poorly (tie-break towards wide tiles).
-                long cost = waves * (cps * 6000L + 4000L) + tiles * se * 40L + (tw < 8 ? 8 - tw : 0);
+                long cost = full * tb + tail + tiles * se * 40L + (tw < 8 ? 8 - tw : 0);
                 if (se > 1) cost += (long)((double)N * OH * OW * Co * 4.0 * (2 * se + 1) / 4000.0) + 3000L;
                 if (best < 0 || cost < best) {
                     best = cost;
                     p->TW = tw; p->TH = th; p->NB = nb; p->cps = cps; p->nsplit = se;
+                    p->subq = subq;
                 }
             }
         }
@@ -452,12 +474,18 @@ static int ct2_plan(int N, int IH, int IW, int Ci, int Co, int OH, int OW, float
         if (sscanf(ov, "%d,%d,%d,%d", &tw, &th, &nb, &ns) == 4 && tw * th * nb <= 128 && nb * (th + 1) * (tw + 1) <= CT_MAX_NPP) {
             p->TW = tw; p->TH = th; p->NB = nb < N ? nb : N;
             p->cps = cdiv(p->nchunks, ns); p->nsplit = cdiv(p->nchunks, p->cps);
+            p->subq = 1;
         }
     }
+    if (const char *ov = getenv("RICK_CT2_SUBQ")) p->subq = atoi(ov) == 4 ? 4 : atoi(ov) == 2 ? 2 : 1;   // (forced, even past one round)
 #endif
     p->ntx = cdiv(GW, p->TW);
     p->nty = cdiv(GH, p->TH);
     p->ntn = cdiv(N, p->NB);
+    {
+        const long blocks = (long)p->ntx * p->nty * p->ntn * p->ncot * p->nsplit;
+        p->nfull = p->subq > 1 ? (int)(blocks / 256 * 256) : (int)blocks;
+    }
     p->PH = p->TH + 1;
     p->PW = p->TW + 1;
     p->NPP = p->NB * p->PH * p->PW;
@@ -482,17 +510,25 @@ extern "C" int rick_convt2_f32(const float *x, const void *packed_w, float *out,
     if (p.nsplit > 1 && (!workspace || ((uintptr_t)workspace % 16))) return RICK_EINVAL;
     const size_t lds = ct2_lds_bytes(p);
     if (lds > 160 * 1024) return RICK_EINVAL;
-    const int64_t nwg = (int64_t)p.ntx * p.nty * p.ntn * p.ncot * p.nsplit;
-    if (nwg > 0x7fffffff) return RICK_EINVAL;
+    const int64_t nitems = (int64_t)p.ntx * p.nty * p.ntn * p.ncot * p.nsplit;
+    if (nitems * p.subq > 0x7fffffff) return RICK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    auto launch = [&](auto kern, int item0, int64_t nwg) {
+        if (nwg <= 0) return;
+        p.item0 = item0;
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(CT_THREADS), lds, st, x, (const unsigned char *)packed_w, out, iscale,
+                           oscale, (float *)workspace, p);
+    };
+    const int64_t nsub = (nitems - p.nfull) * p.subq;
     if (split == 2) {
-        (void)hipFuncSetAttribute((const void *)convt2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(convt2_kernel<2>, dim3((unsigned)nwg), dim3(CT_THREADS), lds, st, x, (const unsigned char *)packed_w,
-                           out, iscale, oscale, (float *)workspace, p);
+        launch(convt2_kernel<2, 8>, 0, p.nfull);
+        if (p.subq == 2) launch(convt2_kernel<2, 4>, p.nfull, nsub);
+        else if (p.subq == 4) launch(convt2_kernel<2, 2>, p.nfull, nsub);
     } else {
-        (void)hipFuncSetAttribute((const void *)convt2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(convt2_kernel<1>, dim3((unsigned)nwg), dim3(CT_THREADS), lds, st, x, (const unsigned char *)packed_w,
-                           out, iscale, oscale, (float *)workspace, p);
+        launch(convt2_kernel<1, 8>, 0, p.nfull);
+        if (p.subq == 2) launch(convt2_kernel<1, 4>, p.nfull, nsub);
+        else if (p.subq == 4) launch(convt2_kernel<1, 2>, p.nfull, nsub);
     }
     if (p.nsplit > 1) {
         const int64_t n4 = (int64_t)N * OH * OW * Co / 4;
@@ -504,12 +540,14 @@ extern "C" int rick_convt2_f32(const float *x, const void *packed_w, float *out,
     RICK_LAUNCH_STATUS();
 }
 
-// Plan introspection for tools/bench_conv.py and the tests: {TW, TH, NB, tiles, nsplit, cps}.
-extern "C" int rick_convt2_plan(int N, int IH, int IW, int Ci, int Co, int OH, int OW, int *out6) {
+// Plan introspection for tools/bench_conv.py and the tests: {TW, TH, NB, tiles, nsplit, cps, whole-tile blocks, blocks per
+// remaining work item}.
+extern "C" int rick_convt2_plan(int N, int IH, int IW, int Ci, int Co, int OH, int OW, int *out8) {
     Ct2Plan p;
     const int rc = ct2_plan(N, IH, IW, Ci, Co, OH, OW, 1.f, &p);
-    if (rc || !out6) return RICK_EINVAL;
-    out6[0] = p.TW; out6[1] = p.TH; out6[2] = p.NB; out6[3] = p.ntx * p.nty * p.ntn * p.ncot; out6[4] = p.nsplit; out6[5] = p.cps;
+    if (rc || !out8) return RICK_EINVAL;
+    out8[0] = p.TW; out8[1] = p.TH; out8[2] = p.NB; out8[3] = p.ntx * p.nty * p.ntn * p.ncot; out8[4] = p.nsplit; out8[5] = p.cps;
+    out8[6] = p.nfull; out8[7] = p.subq;
     return 0;
 }
 

@@ -202,6 +202,9 @@ CT2_CASES = [  # tag, N, Ci, Co, IH, IW, crop (output 2*IH instead of 2*IH+1), s
 ]
 
 
+CT2_SUBBLOCKS = {'g64': (True, 4), 'g128_n8': (True, 2), 'g8': (False, 2), 'g4': (False, 4)}   # tag -> (whole-tile launch too, blocks per tile)
+
+
 @pytest.mark.parametrize('case', CT2_CASES, ids=[c[0] for c in CT2_CASES])
 def test_convt2_single_staging_kernel(case):
     """rick_convt2_f32 (all four parity classes from one staged patch) vs F.conv_transpose2d in fp64 and vs the generic
@@ -223,6 +226,13 @@ def test_convt2_single_staging_kernel(case):
     wp = cv._pack(w.to(DEV), wscale)
     sid, sod = (si.to(DEV), so.to(DEV)) if scales else (None, None)
     assert cv._USE_CT2
+    if tag in CT2_SUBBLOCKS:     # these grids end in a partly filled round: its tiles run as 2 / 4 blocks of 4 / 2 fragment columns
+        import ctypes
+        from rick_amd._lib import lib
+        plan = (ctypes.c_int * 8)()
+        assert lib.rick_convt2_plan(N, IH, IW, Ci, Co, OH, OW, plan) == 0
+        items, nfull, subq = plan[3] * plan[4], plan[6], plan[7]
+        assert (nfull > 0, subq) == CT2_SUBBLOCKS[tag] and nfull < items, list(plan)
     y = cv._convT_launch(xd, wp, Co, 3, 3, 2, 0, (OH, OW), iscale=sid, oscale=sod)
     assert y.shape == ref.shape
     assert rel_err(y, ref) < 2e-6

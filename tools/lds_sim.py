@@ -46,7 +46,7 @@ def ct2(N, IH, IW, Ci, Co, swz=swz_default, use_map=True, verbose=True):
     position map (rick_convt2_posmap) or the identity map (round-2 behaviour: slot j*16 + l15 = position)."""
     sys.path.insert(0, '.')
     from rick_amd._lib import lib
-    out = (ctypes.c_int * 6)()
+    out = (ctypes.c_int * 8)()
     assert lib.rick_convt2_plan(N, IH, IW, Ci, Co, 2 * IH + 1, 2 * IW + 1, out) == 0
     TW, TH, NB = out[0], out[1], out[2]
     pm = (ctypes.c_ubyte * 128)()
