@@ -559,6 +559,60 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     }
 }
 
+// Second stage for the two dense destination layouts, written in runs of consecutive floats.  The partial tiles are
+// [tap][ci 32][co 128] (co fastest: what the MFMA accumulators hold); the gradient tensor is [co][ci][slice] (TR = false:
+// s_ci = nslices, s_t = 1) or [ci][co][slice] (TR = true: s_co = nslices, s_t = 1), so the element-per-thread kernel above
+// writes 4 bytes every Ci*9*4 B (or 36 B).  Here a block owns 32 co x 8 ci x taps of one (co tile, chunk) tile — 16 blocks
+// per tile, enough of them in flight per CU to keep the partial-sum reads streaming —, sums the splits with float4 loads
+// along co, transposes through LDS and writes runs of 8 * nslices (TR: 32 * nslices) consecutive floats.  Same
+// summation order as the kernel above: bit-identical results.
+template <bool TR>
+__global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float *__restrict__ ws, float *__restrict__ gw,
+                                                                int64_t s_outer, int Co, int Ci, int nchunks, int ntaps,
+                                                                int nsl, int nsplit, float alpha, int accumulate,
+                                                                rick_conv_geom g, int64_t per_split) {
+    extern __shared__ float wr_tile[];
+    const int pc = blockIdx.x & 3, pk = (blockIdx.x >> 2) & 3;   // 32-co quarter, 8-ci quarter of the tile
+    const int chunk = (blockIdx.x >> 4) % nchunks, cot = (blockIdx.x >> 4) / nchunks;
+    const float4 *src = reinterpret_cast<const float4 *>(ws + ((int64_t)(cot * nchunks + chunk) * ntaps) * CV_CK * CV_BM);
+    const int64_t split4 = per_split >> 2;
+    const int run = (TR ? 32 : 8) * nsl;                         // consecutive destination floats per LDS row
+    const int pitch = run + 1;
+    const int c4 = threadIdx.x & 7;                              // 8 float4 = the block's 32 co
+    for (int row = threadIdx.x >> 3; row < ntaps * 8; row += 32) {
+        const int tt = row >> 3, kl = row & 7;
+        const float4 *p = src + ((int64_t)(tt * CV_CK + pk * 8 + kl) * CV_BM + pc * 32) / 4 + c4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sp = 0; sp < nsplit; sp++) {
+            const float4 v = p[sp * split4];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        const int sl = g.wt[tt];
+        if (!TR) {
+            float *d = wr_tile + (c4 * 4) * pitch + kl * nsl + sl;
+            d[0] = a.x; d[pitch] = a.y; d[2 * pitch] = a.z; d[3 * pitch] = a.w;
+        } else {
+            float *d = wr_tile + kl * pitch + (c4 * 4) * nsl + sl;
+            d[0] = a.x; d[nsl] = a.y; d[2 * nsl] = a.z; d[3 * nsl] = a.w;
+        }
+    }
+    __syncthreads();
+    unsigned smask = 0;                                          // slices this launch produces (a tap subset leaves the others alone)
+    for (int tt = 0; tt < ntaps; tt++) smask |= 1u << g.wt[tt];
+    const int nrows = TR ? 8 : 32;
+    for (int e = threadIdx.x; e < nrows * run; e += 256) {
+        const int rl = e / run, c = e - rl * run;
+        const int inner = c / nsl, sl = c - inner * nsl;
+        // TR: row = ci, inner = co;  else: row = co, inner = ci
+        const int co = cot * CV_BM + pc * 32 + (TR ? inner : rl);
+        const int ci = chunk * CV_CK + pk * 8 + (TR ? rl : inner);
+        if (co >= Co || ci >= Ci || !((smask >> sl) & 1u)) continue;
+        float *dst = gw + (int64_t)(TR ? ci : co) * s_outer + (int64_t)(TR ? co : ci) * nsl + sl;
+        const float v = wr_tile[rl * pitch + c] * alpha;
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+
 // Split-K plan of the weight gradient: blocks = co-tiles x chunks x splits, one 400-register block per CU, so the grid
 // runs in waves of 256 blocks.  Minimise  waves x (tiles per block + fixed block cost)  plus a small charge per split
 // for the partial tiles the second stage has to read (measured: 512x512 @64^2, batch 4 runs best as 4 splits of 64
@@ -653,6 +707,22 @@ extern "C" int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw, i
     else if (g->ntaps <= 4) launch_wgrad<4>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
     else launch_wgrad<9>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
     const int64_t per_split = (int64_t)t.ncot * t.nchunks * g->ntaps * CV_BM * CV_CK;
+    const int nsl = g->nslices;
+    const unsigned ntile = (unsigned)(t.ncot * t.nchunks * 16);
+    // (the tile kernel needs >= 512 blocks to keep the partial-sum reads streaming: 4-5 us faster on the 512 x 512 x 9
+    // gradients, slower than the element-per-thread kernel on small tensors with many splits)
+    static const int tile_min = ablation_env("RICK_WR_TILE", 32);
+    const bool tile_reduce = tile_min > 0 && t.ncot * t.nchunks >= tile_min;
+    if (tile_reduce && s_t == 1 && s_ci == nsl && s_co >= (int64_t)g->Ci * nsl && nsl <= 16) {          // [co][ci][slice]
+        hipLaunchKernelGGL(wgrad_reduce_tile_kernel<false>, dim3(ntile), dim3(256), 32 * (8 * nsl + 1) * 4, st, ws, gw,
+                           s_co, g->Co, g->Ci, t.nchunks, g->ntaps, nsl, nsplit, g->alpha, accumulate, *g, per_split);
+        RICK_LAUNCH_STATUS();
+    }
+    if (tile_reduce && s_t == 1 && s_co == nsl && s_ci >= (int64_t)g->Co * nsl && nsl <= 16) {          // [ci][co][slice]
+        hipLaunchKernelGGL(wgrad_reduce_tile_kernel<true>, dim3(ntile), dim3(256), 8 * (32 * nsl + 1) * 4, st, ws, gw,
+                           s_ci, g->Co, g->Ci, t.nchunks, g->ntaps, nsl, nsplit, g->alpha, accumulate, *g, per_split);
+        RICK_LAUNCH_STATUS();
+    }
     int64_t nb = cdiv64(per_split, 256);
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, ws, gw, s_co, s_ci, s_t, g->Co, g->Ci,

@@ -135,6 +135,8 @@ CONV_CASES = [
     ('co192', 2, 64, 192, 16, 16, 3, 1, 1),        # Co % 128 != 0: weight gradient must not take the whole-tile (FAST) form
     ('h18', 2, 32, 128, 18, 16, 3, 1, 1),          # 18 rows: not a multiple of the 16 x 4 position tile (two images: a whole-tile read of image 0 would run into image 1)
     ('ci48', 2, 48, 128, 16, 16, 3, 1, 1),         # Ci % 32 != 0
+    ('w512', 2, 264, 500, 8, 8, 3, 1, 1),          # >= 32 (co tile, chunk) tiles: the weight gradient's second stage takes its tile form; ragged Co, Ci
+    ('w512_k1', 2, 512, 256, 8, 8, 1, 1, 0),       # ... with one slice per (co, ci)
 ]
 
 
@@ -165,6 +167,29 @@ def test_conv2d_vs_fp64(case):
     gg = torch.autograd.grad(pl, (xd, wd))
     assert rel_err(gg[0], ggr[0]) < 5e-6, 'second-order d/dx'
     assert rel_err(gg[1], ggr[1]) < 5e-6, 'second-order d/dw'
+
+
+@pytest.mark.parametrize('ci,co', [(512, 256), (64, 96)], ids=['tile_stage', 'element_stage'])
+def test_wgrad_accumulates_into_both_parameter_layouts(ci, co):
+    """rick_conv_wgrad_f32 with accumulate = 1 (the trainer's gradient sink): [O, I, kh, kw] and the transposed-conv
+    parameter layout [I, O, kh, kw] receive exactly the stand-alone result, on both second-stage kernels (>= 32 tiles:
+    the LDS-transposing one)."""
+    from rick_amd.op import conv as cv
+    a_cpu, b_cpu = synth_tensor(f'wacc/{ci}/a', (2, co, 8, 8)), synth_tensor(f'wacc/{ci}/b', (2, ci, 8, 8))
+    a = a_cpu.to(DEV).contiguous(memory_format=torch.channels_last)        # output-side operand
+    b = b_cpu.to(DEV).contiguous(memory_format=torch.channels_last)        # input-side operand
+    gw = cv._wgrad_launch(a, b, 3, 3, 1, 1, alpha=0.5)
+    assert gw.shape == (co, ci, 3, 3)
+    w0 = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    ref = torch.autograd.grad(F.conv2d(b_cpu.double(), w0, padding=1), w0, a_cpu.double())[0] * 0.5
+    assert rel_err(gw, ref) < 2e-6
+    base = synth_tensor(f'wacc/{ci}/base', (co, ci, 3, 3)).to(DEV)
+    sink = base.clone()
+    assert cv._wgrad_launch(a, b, 3, 3, 1, 1, alpha=0.5, out=sink) is None
+    assert torch.equal(sink, base + gw)
+    sink_t = base.transpose(0, 1).contiguous()
+    cv._wgrad_launch(a, b, 3, 3, 1, 1, alpha=0.5, out=sink_t, transposed=True)
+    assert torch.equal(sink_t, (base + gw).transpose(0, 1))
 
 
 @pytest.mark.parametrize('case', [('t_4', 2, 32, 64, 4, 4), ('t_8', 3, 64, 32, 8, 8), ('t_16', 1, 128, 128, 16, 16),
