@@ -19,6 +19,21 @@ for r in rows:
     agg[key][1] += d
     tot += d
 print(f'total {tot/1e3:.1f} ms, {len(rows)} launches')
+# the launch sequence of the last ~1.5 iterations, in order (for fusion hunting)
+seq = sorted(rows, key=lambda r: int(r['Start_Timestamp']))[-1800:]
+with open(sys.argv[1].rsplit('/', 1)[0] + '/../sequence.txt', 'w') as f:
+    for r in seq:
+        f.write(f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3:8.1f} us  grid {int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])):6d}  {r['Kernel_Name'].split('(')[0][:90]}\n")
+# idle time between consecutive kernels over the last half of the trace (graph replay): gap histogram
+ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in rows)
+ev = ev[len(ev) // 2:]
+busy = sum(e - s for s, e in ev) * 1e-3
+span = (max(e for s, e in ev) - ev[0][0]) * 1e-3
+gaps = [max(0, ev[i + 1][0] - max(e for s, e in ev[max(0, i - 3):i + 1])) * 1e-3 for i in range(len(ev) - 1)]
+import statistics
+print(f'last half: {len(ev)} launches, busy {busy/1e3:.2f} ms of span {span/1e3:.2f} ms = {100*busy/span:.1f} %; '
+      f'gap median {statistics.median(gaps):.2f} us, mean {sum(gaps)/len(gaps):.2f} us, total {sum(gaps)/1e3:.2f} ms; '
+      f'gaps > 20 us: {sum(1 for g in gaps if g > 20)} totalling {sum(g for g in gaps if g > 20)/1e3:.2f} ms')
 for (name, grid, wg), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:150]:
     print(f'{name:70s} grid {grid:6d} x{wg:4d}  n={n:5d}  avg {t/n:8.1f} us  total {t/1e3:8.2f} ms  {100*t/tot:5.2f} %')
 PY
