@@ -67,15 +67,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 
     // XCD-aware mapping: blocks with equal blockIdx % 8 share an XCD (and its L2).  Every XCD owns its own
     // slices of the position range; all (co-tile, chunk) blocks of a slice run there, so a gy tile is fetched
-    // into ONE L2 and re-used by the nchunks blocks that need it.  (Placement only affects speed.)
+    // into ONE L2 and re-used by the nchunks blocks that need it.  With 1 / 2 / 4 splits a slice is shared by 8 / 4 / 2
+    // XCDs, each with a contiguous (co-tile major) part of its blocks: an XCD then reads 1 / 8 ... 1 / 2 of the slice's gy
+    // tiles instead of all of them (512 x 512 @64^2, batch 8: 628 -> ~200 MB from HBM).  (Placement only affects speed.)
     int split, cc;
+    const int ncc = t.nchunks * t.ncot;
     if ((nsplit & 7) == 0) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, spx = nsplit >> 3;
         split = xcd + 8 * (j % spx);
         cc = j / spx;
+    } else if ((nsplit == 1 || nsplit == 2 || nsplit == 4) && ncc % (8 / nsplit) == 0 && !(t.debug & 16)) {
+        const int xps = 8 / nsplit, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        split = xcd / xps;
+        cc = (xcd % xps) * (ncc / xps) + j;
     } else {
-        split = blockIdx.x / (t.nchunks * t.ncot);
-        cc = blockIdx.x % (t.nchunks * t.ncot);
+        split = blockIdx.x / ncc;
+        cc = blockIdx.x % ncc;
     }
     const int chunk = cc % t.nchunks;
     const int cot = cc / t.nchunks;

@@ -20,4 +20,6 @@ for d in $o/k_*/; do rm -rf $d; done
 python3 tools/bench_conv.py > $o/conv_microbench.txt 2>&1
 B=8 python3 tools/bench_conv.py wgrad >> $o/conv_microbench.txt 2>&1
 python3 tools/bench_elem.py > $o/hbm_microbench.txt 2>&1
+python3 tools/ct2_rounds.py > $o/ct2_rounds.txt 2>&1
+[ -x tools/micro/mfma_power ] && tools/micro/mfma_power > $o/mfma_power.txt 2>&1
 du -sh $o
