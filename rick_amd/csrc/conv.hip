@@ -231,12 +231,13 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
 
     const int lid = xcd_remap(bid, nwg);
     const int npos_tiles = t.ntx * t.nty * t.ntn;
-    // co tile fastest: the ncot blocks of a position tile are neighbours in an XCD's block range and fetch the tile's input
-    // patch into ONE L2 (position tile fastest gave each co tile its own XCDs: every patch crossed the fabric ncot times;
-    // 512 -> 512 @64^2 read 163 MB for 43 MB of operands).  Split-K launches keep the old order (few position tiles, the
-    // weight stream dominates: -7 % with co tile fastest).
+    // Block order.  Position tile fastest gives each co tile its own XCDs: a co tile's weights stay in few L2s, but every input
+    // patch crosses the fabric ncot times.  Stride-2 launches (37 KB patches, 4x the input per output position) run the co tile
+    // fastest instead, so that the ncot blocks of a position tile fetch its patch into ONE L2: 609 -> 377 MB on 256 -> 512
+    // @129^2, +2-3 %.  Stride 1 keeps the old order (co tile fastest: 163 -> 153 MB and -0.2 % in bench.py: the 9.4 MB of
+    // packed weights, then needed by every XCD, take what the input saves), and so do split-K launches (-7 % otherwise).
     int pt, split, cot;
-    if (t.nsplit > 1 || (t.debug & 32)) {
+    if (t.nsplit > 1 || g.is < 2 || (t.debug & 32)) {
         pt = lid % npos_tiles;
         split = (lid / npos_tiles) % t.nsplit;
         cot = lid / (npos_tiles * t.nsplit);
