@@ -28,3 +28,33 @@ def test_wgrad_patch_swizzle_key_bit():
     bit 3 of the pixel index (2 cycles per ds_read_b64_tr_b16) and 2-way with the igemm's bit 2."""
     assert lds_sim.wgrad_patch_reads(4, 2, 18, 1, 3, verbose=False) == 2.0
     assert lds_sim.wgrad_patch_reads(4, 2, 18, 1, 2, verbose=False) == 4.0
+
+
+CT2_LAYERS = [(n, ih, ci, co) for n in (1, 2, 3, 4, 8, 25)
+              for ih, ci, co in ((4, 512, 512), (8, 512, 512), (16, 512, 512), (32, 512, 512), (64, 512, 256), (128, 256, 128))]
+
+
+@pytest.mark.parametrize('n,ih,ci,co', CT2_LAYERS)
+def test_convt2_plan_covers_every_tile_once_and_fills_rounds(n, ih, ci, co):
+    """rick_convt2_plan (host code): the grid of the one-pass transposed conv is whole-tile blocks in full rounds of 256 plus
+    the work items of the last, partly filled round as 2 / 4 blocks of 4 / 2 fragment columns (csrc/convt2.hip, DESIGN
+    §3.4) — every work item is covered exactly once, the sub-blocks fit one round, tiles hold <= 128 positions."""
+    import ctypes
+    from rick_amd._lib import lib
+    plan = (ctypes.c_int * 8)()
+    oh = 2 * ih + 1
+    assert lib.rick_convt2_plan(n, ih, ih, ci, co, oh, oh, plan) == 0
+    tw, th, nb, tiles, nsplit, cps, nfull, subq = list(plan)
+    assert 1 <= tw * th * nb <= 128 and nb <= n
+    g = ih + 1                                            # positions per image side
+    assert tiles == -(-g // tw) * -(-g // th) * -(-n // nb) * -(-co // 128)
+    nchunks = -(-ci // 32)
+    assert 1 <= nsplit <= 16 and nsplit == -(-nchunks // cps)
+    items = tiles * nsplit
+    assert subq in (1, 2, 4) and 0 <= nfull <= items
+    if subq == 1:
+        assert nfull == items
+    else:
+        assert nfull % 256 == 0 and nfull == items // 256 * 256 and 0 < (items - nfull) * subq <= 256
+    ws = lib.rick_convt2_workspace_bytes(n, ih, ih, ci, co, oh, oh)
+    assert ws == (nsplit * n * oh * oh * co * 4 if nsplit > 1 else 0)
