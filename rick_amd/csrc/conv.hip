@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
                                                           const float *__restrict__ trailer) {
     const int nchunks = (Ci + CV_CK - 1) / CV_CK;
     const float pscale = trailer[1];
+    cv_fp16_saturate();
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int k = (int)(i & 31);
         const int r = (int)((i >> 5) & 127);
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const rick_pack_
     for (int i = 1; i < n; i++)
         if ((int)blockIdx.x >= descs[i].blk_begin) d = i;
     const rick_pack_desc ds = descs[d];
+    cv_fp16_saturate();
     const int nchunks = (ds.Ci + CV_CK - 1) / CV_CK;
     const float pscale =
         reinterpret_cast<const float *>((const unsigned char *)ds.packed + packed_tile_bytes(ds.Co, ds.Ci, ds.nslices))[1];
@@ -222,6 +224,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                                            const rick_conv_geom &g, const ConvTiling &t, const int bid, const int nwg,
                                            const rick_conv_epilogue &epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cv_fp16_saturate();
     unsigned char *wbuf = smem;                               // [2][16 KB]
     unsigned char *ph = smem + (WDMA == 3 ? 3 : 2) * CV_WSTEP_BYTES;   // [NPP + 1][64 B]  (WDMA = 3: a ring of 3 weight tiles)
     unsigned char *pl = ph + (t.NPP + 1) * 64;                // (+1: spare row for out-of-patch items)
@@ -375,9 +378,9 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         }
     };
     // ---- operand exponent of this block: amax of |input scale * x| over the first channel chunk's patch, which
-    // issue_patch has just put into the registers of set 0 (no extra loads: 32 channels x the whole patch), reduced over
-    // the block -> x * 2^e (conv_common.h).  An all-zero first chunk (padding, pruned channels) falls back to explicit
-    // samples over all of the block's chunks.  Called between issue_patch(c_begin) and commit_patch(c_begin).
+    // issue_patch has just put into the registers of set 0 (no extra loads: 32 channels x the whole patch), and over
+    // samples of the block's other chunks, reduced over the block -> x * 2^e (conv_common.h).  Called between
+    // issue_patch(c_begin) and commit_patch(c_begin).
     auto block_exponent = [&]() {
         float *red = sct + t.nbe * cspan;                             // 16 floats behind the scale table, used for nothing else
 #ifdef RICK_ABLATION
@@ -386,6 +389,23 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             return;
         }
 #endif
+        // the block's OTHER chunks: 8 float4 per thread (2 048 x 4 values), every thread group of 8 starting at its own
+        // chunk so that all chunks are visited — channel groups of very different magnitude (pruned filters, dead
+        // channels of a gradient) are the case a first-chunk exponent gets wrong: 1e-4 x smaller first 32 channels were
+        // enough for inf.  Issued before the first chunk is reduced: one memory latency for both.
+        const int ncl = c_end - c_begin;
+        float4 sv[8];
+        if (ncl > 1) {
+#pragma unroll
+            for (int sidx = 0; sidx < 8; sidx++) {
+                const int k = (sidx * 5 + 1) % PSET;
+                const int chunk = c_begin + 1 + (sidx + (int)(threadIdx.x >> 3)) % (ncl - 1);
+                const int ci = chunk * CV_CK + c4 * 4;
+                const bool ok = ((p_ok >> k) & 1u) && ci < g.Ci;
+                sv[sidx] = load4<VEC>(ok ? xt + p_rel[k] + chunk * CV_CK : (VEC ? g_zero_page : x), ok, ci, g.Ci);
+                if (!VEC && !ok) sv[sidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         float m = 0.f;
 #pragma unroll
         for (int k = 0; k < PSET; k++) {
@@ -394,31 +414,17 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             if (iscale) v = mul4(v, *reinterpret_cast<const float4 *>(sct + p_sc[k]));
             m = amax4(m, v);
         }
-        m = block_amax(m, red);
-        if (m == 0.f) {                 // block-uniform
-            const int ncl = c_end - c_begin;
-#pragma unroll 1
+        if (ncl > 1) {
+#pragma unroll
             for (int sidx = 0; sidx < 8; sidx++) {
-                const int pix = (threadIdx.x >> 3) + 32 * ((sidx * 5 + 1) % PSET);
-                const int chunk = c_begin + (sidx * ncl) / 8;
-                const int ci = chunk * CV_CK + c4 * 4;
-                bool ok = pix < t.NPP && ci < g.Ci;
-                int nbi = 0, n = 0, iy = 0, ix = 0;
-                if (ok) {
-                    const unsigned e = ptab[pix];
-                    nbi = (int)(e >> 20);
-                    n = n0 + nbi;
-                    iy = iy0 + (int)((e >> 10) & 1023);
-                    ix = ix0 + (int)(e & 1023);
-                    ok = n < g.N && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
-                }
-                float4 v = load4<VEC>(ok ? x + (((int64_t)n * g.IH + iy) * g.IW + ix) * g.Ci + ci : (VEC ? g_zero_page : x), ok, ci, g.Ci);
-                if (iscale) v = mul4(v, *reinterpret_cast<const float4 *>(sct + nbi * cspan + (chunk - c_begin) * CV_CK + c4 * 4));
-                if (ok) m = amax4(m, v);
+                const int k = (sidx * 5 + 1) % PSET;
+                const int chunk = c_begin + 1 + (sidx + (int)(threadIdx.x >> 3)) % (ncl - 1);
+                float4 v = sv[sidx];
+                if (iscale) v = mul4(v, *reinterpret_cast<const float4 *>(sct + p_sc[k] + (chunk - c_begin) * CV_CK));
+                m = amax4(m, v);
             }
-            __syncthreads();            // every thread has read `red`
-            m = block_amax(m, red);
         }
+        m = block_amax(m, red);
         float xs, xu;
         cv_pow2_scale(m, xs, xu);
         xscale = cv_uniform(xs);

@@ -54,6 +54,14 @@ __device__ __forceinline__ void cv_pow2_scale(float amax, float &scale, float &u
     unscale = __uint_as_float((unsigned)(eb - CV_EXP_TARGET) << 23);
 }
 
+// MODE.FP16_OVFL = 1: an fp32 -> fp16 conversion that overflows gives +-65504 instead of +-inf.  The operand exponent
+// comes from a SAMPLE of the block's data (below); a value more than 2^(13 - T) = 8 188 times the largest sample would
+// otherwise turn into inf and, through inf - inf in the `lo` part, into NaN in every output it touches.  With the bit set
+// such a value saturates (finite, wrong by its excess) — called once at the start of every kernel that splits operands.
+__device__ __forceinline__ void cv_fp16_saturate() {
+    __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1);       // hwreg(HW_REG_MODE, offset 23, size 1)
+}
+
 // a block-uniform float as an SGPR operand (the exponents come out of an LDS reduction, which the compiler treats as
 // divergent: without this every scale multiply would hold VGPRs)
 __device__ __forceinline__ float cv_uniform(float v) {

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
                                                            const float *__restrict__ oscale, float *__restrict__ ws,
                                                            const Ct2Plan P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cv_fp16_saturate();
     const int pbuf = P.NPP * 64;                              // one of hi / lo of one patch buffer
     float *sct = reinterpret_cast<float *>(smem + 4 * pbuf);  // [NB][cps * 32] input scales
     unsigned char *spos = reinterpret_cast<unsigned char *>(sct + P.NB * P.cps * CV_CK);   // [128] lane slot -> tile position
@@ -163,10 +164,22 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     };
 
     // ---- operand exponent of this block (conv_common.h): amax of |input scale * x| over the first channel chunk's patch
-    // (already in registers: 32 channels x the whole window), reduced over the block -> x * 2^e.  An all-zero first chunk
-    // falls back to explicit samples over all of the block's chunks.
+    // (already in registers: 32 channels x the whole window) and over samples of the other chunks, reduced over the
+    // block -> x * 2^e.
     auto block_exponent = [&]() {
         float *red = reinterpret_cast<float *>(smem + 2 * pbuf);   // second patch buffer: not written before the chunk loop
+        // samples of the block's other chunks (see conv.hip): 8 float4 per thread, issued before the first chunk is reduced
+        const int ncl = c_end - c_begin;
+        float4 sv[8];
+        if (ncl > 1) {
+#pragma unroll
+            for (int sidx = 0; sidx < 8; sidx++) {
+                const int k = sidx % CT_PITEMS;
+                const int chunk = c_begin + 1 + (sidx + (int)(threadIdx.x >> 3)) % (ncl - 1);
+                const bool ok = ((p_ok >> k) & 1u) && chunk * CV_CK + c4 * 4 < P.Ci;
+                sv[sidx] = *reinterpret_cast<const float4 *>(ok ? xt + p_rel[k] + chunk * CV_CK : g_ct2_zero_page);
+            }
+        }
         float m = 0.f;
 #pragma unroll
         for (int k = 0; k < CT_PITEMS; k++) {
@@ -174,22 +187,17 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
             if (iscale) v = mul4(v, *reinterpret_cast<const float4 *>(sct + ((p_nbi >> (8 * k)) & 255u) * cspan + c4 * 4));
             m = amax4(m, v);
         }
-        m = block_amax(m, red);
-        if (m == 0.f) {                                       // block-uniform
-            const int ncl = c_end - c_begin;
-#pragma unroll 1
+        if (ncl > 1) {
+#pragma unroll
             for (int sidx = 0; sidx < 8; sidx++) {
                 const int k = sidx % CT_PITEMS;
-                const int chunk = c_begin + (sidx * ncl) / 8;
-                const int ci = chunk * CV_CK + c4 * 4;
-                const bool ok = ((p_ok >> k) & 1u) && ci < P.Ci;
-                float4 v = *reinterpret_cast<const float4 *>(ok ? xt + p_rel[k] + chunk * CV_CK : g_ct2_zero_page);
+                const int chunk = c_begin + 1 + (sidx + (int)(threadIdx.x >> 3)) % (ncl - 1);
+                float4 v = sv[sidx];
                 if (iscale) v = mul4(v, *reinterpret_cast<const float4 *>(sct + ((p_nbi >> (8 * k)) & 255u) * cspan + (chunk - c_begin) * CV_CK + c4 * 4));
                 m = amax4(m, v);
             }
-            __syncthreads();                                  // every thread has read `red`
-            m = block_amax(m, red);
         }
+        m = block_amax(m, red);
         float xs, xu;
         cv_pow2_scale(m, xs, xu);
         xscale = cv_uniform(xs);

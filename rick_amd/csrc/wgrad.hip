@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                                                          const float *__restrict__ bscale, const rick_conv_geom g,
                                                          const ConvTiling t, int nsplit, int tiles_per_split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cv_fp16_saturate();
     // one operand buffer = [gy hi 16 KB][gy lo 16 KB][patch hi (NPP+1) x 64 B][patch lo]; PIPE keeps two of them
     // (+1 patch row: spare row for out-of-patch items)
     const int bufsz = 2 * WG_GY_BYTES + 2 * (t.NPP + 1) * 64;

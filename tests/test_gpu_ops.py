@@ -271,6 +271,49 @@ def test_convt2_single_staging_kernel(case):
     assert rel_err(y, y_old.double()) < 2e-6      # same products, different summation order over channel chunks
 
 
+@pytest.mark.parametrize('case', ['small_first_chunk', 'spike'])
+def test_conv_operand_exponent_covers_all_chunks(case):
+    """Blocks that walk several channel chunks (no split-K: 512 blocks of 4 chunks here) take the operand exponent from
+    the first chunk AND from samples of the others: first 32 channels 1e-6 of the rest (pruned / dead channels) gave inf
+    with a first-chunk exponent.  A lone value 1e7 x everything else that no sample happens to see saturates at the fp16
+    maximum instead of turning into inf / NaN (MODE.FP16_OVFL): finite everywhere, exact in the blocks without it."""
+    from rick_amd import op
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 128, 64, 64, generator=g)
+    w = torch.randn(512, 128, 3, 3, generator=g)
+    gy = torch.randn(4, 512, 64, 64, generator=g)
+    wscale = 1 / math.sqrt(128 * 9)
+    if case == 'small_first_chunk':
+        x[:, :32] *= 1e-6
+        gy[:, :32] *= 1e-6
+    else:
+        x[1, 77, 40, 21] = 1e7
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = op.conv2d(xd, wd, 1, 1, wscale=wscale)
+    gx, gw = torch.autograd.grad(y, (xd, wd), gy.to(DEV))
+    yt = op.conv_transpose2d(xd[:, :, :32, :32].contiguous(), wd[:128], 2, 0, wscale=wscale)
+    for name, t in (('y', y), ('gx', gx), ('gw', gw), ('yt', yt)):
+        assert torch.isfinite(t).all(), name
+    xr = x.double().requires_grad_(True)
+    yr = F.conv2d(xr, w.double() * wscale, padding=1)
+    (gxr,) = torch.autograd.grad(yr, xr, gy.double())
+    if case == 'small_first_chunk':
+        assert rel_err(y, yr) < 2e-6, rel_err(y, yr)
+        assert rel_err(gx, gxr) < 2e-6, rel_err(gx, gxr)
+        ytr = F.conv_transpose2d(x[:, :, :32, :32].double(), (w[:128].double() * wscale).transpose(0, 1), stride=2)
+        assert rel_err(yt, ytr) < 2e-6, rel_err(yt, ytr)
+    else:
+        # blocks that hold the spike either saw it in their sample (exponent from 1e7: their O(1) values keep 2^-27 of the
+        # block maximum, the documented block-exponent behaviour) or saturate it; every other image is untouched
+        err = (y.cpu().double() - yr).abs()
+        others = [0, 2, 3]
+        assert float(err[others].max()) < 2e-6 * float(yr[others].abs().max())
+        reach = torch.zeros(64, 64, dtype=torch.bool)
+        reach[39:42, 20:23] = True                       # outputs the spike reaches
+        assert float(err[1][:, ~reach].max()) < 2e-6 * float(yr.abs().max())
+        assert rel_err(gx, gxr) < 2e-6                    # (the data gradient does not read x)
+
+
 def test_conv_fp16_single_pass_is_coarser():
     """split=1 (plain fp16 MFMA) is a speed option, not the parity path: ~2^-12 per product instead of ~2^-22."""
     from rick_amd import op
