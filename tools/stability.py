@@ -1,11 +1,12 @@
 """Long steady-state run of the trainer with step graphs: time per 100 iterations, losses, peak memory (GPU)."""
-import os, sys, time
+import os, random, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rick_amd.models import Discriminator, Generator
 from rick_amd.synth import synth_reals
 from rick_amd.train import RickTrainer, TrainConfig
 torch.manual_seed(1)
+random.seed(int(os.environ.get('SEED', 1)))      # the mixing decisions (train.py: random.random / randint) — unseeded, every run takes its own trajectory
 dev = 'cuda'
 cfg = TrainConfig(batch=4)
 g, d = Generator(256, 512, 8).to(dev), Discriminator(256).to(dev)
