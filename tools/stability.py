@@ -3,7 +3,7 @@ import os, random, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rick_amd.models import Discriminator, Generator
-from rick_amd.synth import synth_reals
+from rick_amd.synth import synth_latents, synth_reals
 from rick_amd.train import RickTrainer, TrainConfig
 torch.manual_seed(1)
 random.seed(int(os.environ.get('SEED', 1)))      # the mixing decisions (train.py: random.random / randint) — unseeded, every run takes its own trajectory
@@ -16,10 +16,18 @@ real = [synth_reals(4, 256, seed=s).to(dev) for s in range(4)]
 tr.enable_graphs('--eager' not in sys.argv)
 tr.prepare_graphs(real[0])
 i0 = cfg.warmup_iter + 1
+# FISHER=1: the full RICK loop — a Fisher sweep and new filter masks every cfg.fisher_freq iterations (pruned filters are the
+# channel groups of zeros / tiny values that the conv kernels' operand exponent has to survive)
+fisher_in = None
+if os.environ.get('FISHER'):
+    nf = cfg.num_fisher_img
+    fisher_in = ([synth_latents(1, seed=500 + j).to(dev) for j in range(nf)], [synth_reals(1, 256, seed=600 + j).to(dev) for j in range(nf)])
+    tr.fisher_sweep(*fisher_in, first=True)
+    i0 = cfg.warmup_iter
 for blk in range(int(os.environ.get('BLOCKS', 5))):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for k in range(100):
-        tr.iteration(i0 + blk * 100 + k, real[k % 4])
+        tr.iteration(i0 + blk * 100 + k, real[k % 4], fisher_in)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 100 * 1e3
     L = {k: float(v) for k, v in tr.losses.items()}
     print(f'block {blk}: {dt:.2f} ms/iter  d={L["d"]:.4f} g={L["g"]:.4f} r1={L["r1"]:.5f} path={L["path"]:.5f} '
