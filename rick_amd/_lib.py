@@ -10,7 +10,11 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('RICK_HIP_LIB') or os.path.join(_HERE, 'lib', 'librick_hip.so')   # override: kernel experiments
+LIB_PATH = os.path.join(_HERE, 'lib', 'librick_hip.so')
+if os.environ.get('RICK_HIP_LIB'):          # kernel experiments (ablation builds): never silent
+    import warnings
+    LIB_PATH = os.environ['RICK_HIP_LIB']
+    warnings.warn(f'rick_amd: RICK_HIP_LIB overrides the product library with {LIB_PATH}', RuntimeWarning)
 MAX_TAPS = 16
 
 c_fp = ctypes.c_void_p

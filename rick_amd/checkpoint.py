@@ -85,6 +85,9 @@ def resume(trainer, ckpt):
     """Continue a run from a checkpoint written by `save` or by the reference script (needs "g_optim"/"d_optim")."""
     if not isinstance(ckpt, dict):
         ckpt = torch.load(ckpt, map_location='cpu')
+    # a deferred optimiser step (data-parallel pipelining) belongs to the OLD state: it lands before anything is loaded —
+    # replayed afterwards it would apply pre-load gradients to the restored weights / moments and bump their step counts
+    getattr(trainer, '_finish_pending', lambda: None)()
     load_source(ckpt, trainer.g, trainer.g_ema, trainer.d, trainer.d_ema)
     if 'g_optim' in ckpt:
         load_adam_state_dict(trainer.g_optim, ckpt['g_optim'])

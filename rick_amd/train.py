@@ -560,6 +560,12 @@ class RickTrainer:
             self._after_optimizer(st, flat, optim)
             return
         if gh is not None:
+            # The head may only run ahead of a pending step that updates a DIFFERENT network (the generator forward while
+            # D's buckets travel).  A pending step on the head's own parameters (two G steps in a row through the step API)
+            # must land first: the head would otherwise read pre-update weights that the backward then no longer matches,
+            # and its replay would run before the optimiser graph captured behind it in the shared memory pool.
+            if self._pending is not None and self._pending[1] is flat:
+                self._finish_pending()
             for grp in self._pack_groups:                     # (the head only reads networks no pending step is updating)
                 grp.refresh(skip=self._pending_params())
             gh.replay()                                       # ... while the previous step's buckets are on the wire

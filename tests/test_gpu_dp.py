@@ -282,7 +282,7 @@ def test_bench_self_launch_two_ranks_one_gpu():
     assert out['ranks']['backend'] == 'gloo' and out['ranks']['rccl_ranks'] == 0
 
 
-def _nccl_worker(q):
+def _nccl_worker(q, direct_steps=False):
     """Single rank, backend 'nccl' (= RCCL): the data-parallel code path — bucket launches with ncclAvg, work.wait() stream
     semantics around replayed step graphs, the deferred optimiser graph with the generator forward running while the D
     gradients are "on the wire" — on the one GPU this box has.  With one rank the exchange is the identity, so the result
@@ -319,8 +319,20 @@ def _nccl_worker(q):
             assert dp.active and dist.get_backend() == 'nccl' and len(dp._state[id(tr.d_flat)]['buckets']) >= 3
         tr.enable_graphs(True)
         reals = [synth_reals(B, size=size, seed=40 + k).to(dev) for k in range(3)]
-        for i in range(16, 16 + 9):                      # i = 16: R1 + path length; captures happen on each step type's 3rd call
-            tr.iteration(i, reals[i % 3])
+        if direct_steps:
+            # the step API used directly: consecutive graph G steps — the second one's head (generator
+            # forward) must not run ahead of the first one's still pending optimiser graph, which updates G itself
+            tr._real = reals[0].clone()
+            for k in range(4):
+                tr.d_step(tr._real, None, graph=True)
+                tr.g_step(None, graph=True)
+                tr.g_step(None, graph=True)
+            if dp is not None:
+                assert tr._pending is not None and tr._pending[1] is tr.g_flat
+            tr.ema_step()
+        else:
+            for i in range(16, 16 + 9):                  # i = 16: R1 + path length; captures happen on each step type's 3rd call
+                tr.iteration(i, reals[i % 3])
         if dp is not None:
             assert tr._gs['g']['graphs'][0] is not None and tr._gs['g']['graphs'][2] is not None    # head | fwd/bwd | optimiser
             assert tr._pending is None                   # ema_step completed the deferred optimiser step
@@ -346,6 +358,25 @@ def test_rccl_code_path_single_rank_pipelined_graphs():
     port = s.getsockname()[1]
     s.close()
     p = ctx.Process(target=_nccl_worker, args=((q, port),))
+    p.start()
+    out = _get(q, [p], 600)
+    p.join(60)
+    assert p.exitcode == 0
+    assert all(out['equal']) and all(out['finite']), out
+    assert out['g_loss'][0] == out['g_loss'][1]
+
+
+def test_rccl_consecutive_graph_g_steps_finish_their_own_pending_step():
+    """Two graph G steps in a row through the step API under the pipelined data-parallel mode: the pending optimiser graph
+    of the first updates G, so it has to land before the second step's head replays (train.py `_run`).  Parameters equal the
+    plain trainer's bit for bit."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    p = ctx.Process(target=_nccl_worker, args=((q, port), True))
     p.start()
     out = _get(q, [p], 600)
     p.join(60)
