@@ -199,6 +199,38 @@ int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw,
                         const rick_conv_geom *g, int accumulate, void *workspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Split images — activations / gradients stored pre-split for the MFMA kernels (no counterpart in the reference: its
+ * convolutions are cuDNN's, model_probe_tune.py:122,265,274,280; this is how the fp16x3 arithmetic of this build avoids
+ * converting the same fp32 operand once per co-tile block, again in dgrad and again in wgrad).
+ * A split image of an NHWC fp32 tensor [npix, C] (C % 32 == 0) has the same byte size and pixel pitch; the 128 bytes of a
+ * pixel's 32-channel chunk hold [hi: 32 x fp16][lo: 32 x fp16], hi = fp16(v * 2^e), lo = fp16(v * 2^e - hi), with ONE
+ * exponent per tensor in a 16-byte device header {2^e, 2^-e, bound, 0}.  The exponent comes from a guaranteed bound
+ * coef * (*amax0 + *amax1) on |v| (amax1 may be NULL), placed in [2^13, 2^14): nothing can saturate, and values down to
+ * 2^-10 of the bound keep 2^-22 relative precision.  rick_amax_f32 folds max |x| into *amax_word with an atomic max
+ * (callers zero the word first); the kernels that produce activations measure the same maximum in their epilogues. */
+int rick_amax_f32(const float *x, int64_t n, float *amax_word, void *stream);
+int rick_split_pack_f32(const float *x, void *out, float *hdr, const float *amax0, const float *amax1, float coef,
+                        int64_t npix, int C, void *stream);
+int rick_split_unpack_f32(const void *split, const float *hdr, float *out, int64_t npix, int C, void *stream);
+/* Weight gradient (rick_conv_wgrad_f32) with one or both operands given as split images: x_hdr / gy_hdr non-NULL marks
+ * the operand as a split image (its per-channel scales, if the layer has any, are already folded in by the producer).
+ * Only geometries for which rick_conv_wgrad_split_supported() returns 1 (whole 64-position tiles, Co % 128 == 0,
+ * Ci % 32 == 0: every 3x3 / 1x1 layer of both networks at >= 8x8). */
+int rick_conv_wgrad_split_supported(const rick_conv_geom *g);
+/* rick_conv_igemm_act_f32 / rick_convt2_f32 with the input given as a split image (Ci % 32 == 0; per-channel input scales
+ * are folded into the image by its producer).  The igemm entry serves the 3x3 stride-1 / stride-2 forms with a full grid and
+ * the small-patch (1x1, parity-class) form; other geometries return RICK_EINVAL and take the fp32 entry. */
+int rick_conv_igemm_split_supported(const rick_conv_geom *g);
+int rick_conv_igemm_split_f32(const void *x_split, const float *x_hdr, const void *packed_w, float *out,
+                              const float *oscale, const rick_conv_geom *g, const rick_conv_epilogue *epilogue,
+                              void *workspace, void *stream);
+int rick_convt2_split_f32(const void *x_split, const float *x_hdr, const void *packed_w, float *out, const float *oscale,
+                          int N, int IH, int IW, int Ci, int Co, int OH, int OW, float alpha, void *workspace, void *stream);
+int rick_conv_wgrad_split_f32(const void *x, const float *x_hdr, const void *gy, const float *gy_hdr, float *gw,
+                              int64_t s_co, int64_t s_ci, int64_t s_t, const rick_conv_geom *g, int accumulate,
+                              void *workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Thin (J <= 4 channel) products for the RGB side (ToRGB 1x1 modulated conv,
  * model_probe_tune.py:351-370; discriminator input conv, :679).  x is NHWC [N, P, C],
  * the thin tensor is planar [N, J, P], W is [N or 1, J, C] (w_bstride = J*C or 0).

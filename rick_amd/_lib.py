@@ -50,6 +50,16 @@ SIGNATURES = {
     'rick_bias_act_bwd_blocks': (c_int, [c_i64, c_int]),
     'rick_bias_act_bwd_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_i64, c_i64, c_i64,
                                       c_f, c_f, c_fp, c_int, c_fp]),
+    'rick_amax_f32': (c_int, [c_fp, c_i64, c_fp, c_fp]),
+    'rick_split_pack_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i64, c_int, c_fp]),
+    'rick_split_unpack_f32': (c_int, [c_fp, c_fp, c_fp, c_i64, c_int, c_fp]),
+    'rick_conv_wgrad_split_supported': (c_int, [ctypes.POINTER(ConvGeom)]),
+    'rick_conv_wgrad_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, ctypes.POINTER(ConvGeom), c_int,
+                                          c_fp, c_fp]),
+    'rick_conv_igemm_split_supported': (c_int, [ctypes.POINTER(ConvGeom)]),
+    'rick_conv_igemm_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue),
+                                          c_fp, c_fp]),
+    'rick_convt2_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp] + [c_int] * 7 + [c_f, c_fp, c_fp]),
     'rick_conv_packed_bytes': (c_i64, [c_int, c_int, c_int]),
     'rick_conv_pack_weight': (c_int, [c_fp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_f, c_int, c_fp, c_fp]),
     'rick_conv_pack_blocks': (c_int, [c_int, c_int]),

@@ -217,7 +217,9 @@ __device__ __forceinline__ void cv_lds_barrier() {   // raw barrier: no vmcnt(0)
     asm volatile("" ::: "memory");
 }
 
-template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, int WDMA = 0>
+// PKX: the input is a split image (conv_common.h): `iscale` points at its header {2^e, 2^-e, ..}, per-channel input scales
+// are already folded in by the producer, a staging item is one 16-byte granule of 8 channels (hi or lo) copied to LDS as it is.
+template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, int WDMA = 0, bool PKX = false>
 __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const unsigned char *__restrict__ wpk,
                                            float *__restrict__ out, const float *__restrict__ iscale,
                                            const float *__restrict__ oscale, float *__restrict__ ws,
@@ -262,7 +264,8 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     // per-(image, input channel) scales of this block's images and channel range (1 without an input scale): read from HBM
     // once, multiplied by the block exponent below, then applied from LDS while the patch is converted — no global-load
     // round trip and no branch per patch item
-    if (iscale) {
+    static_assert(!PKX || (SPLIT == 2 && VEC), "split-image input: fp16x3, vector path");
+    if (!PKX && iscale) {
         for (int i = threadIdx.x; i < t.nbe * cspan; i += 256) {
             const int nbi = i / cspan, c = c_begin * CV_CK + (i - nbi * cspan);
             sct[i] = (n0 + nbi < g.N && c < g.Ci) ? iscale[(int64_t)(n0 + nbi) * g.Ci + c] : 0.f;
@@ -314,6 +317,8 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         p_sc[k] = 0;
         // items past the patch land in a spare row behind it, so the LDS writes need no guard
         p_lds[k] = (pix < t.NPP ? pix : t.NPP) * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
+        if constexpr (PKX)   // granule c4 of the chunk's 128 bytes: hi / lo plane = bit 2, k-group = c4 & 3
+            p_lds[k] = (c4 >> 2) * (t.NPP + 1) * 64 + (pix < t.NPP ? pix : t.NPP) * 64 + cv_swz(c4 & 3, pix) * 16;
         if (pix < t.NPP) {
             const unsigned e = ptab[pix];
             const int nbi = (int)(e >> 20), py = (int)((e >> 10) & 1023), px = (int)(e & 1023);
@@ -345,6 +350,10 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         auto items = [&](auto ISC) {
 #pragma unroll
             for (int k = 0; k < PSET; k++) {
+                if constexpr (PKX) {
+                    *reinterpret_cast<float4 *>(ph + p_lds[k]) = pq[S * PSET + k];
+                    continue;
+                }
                 const bool ok = (cur_ok[S] >> k) & 1u;
                 float4 v = pq[S * PSET + k];
                 if (!VEC && !ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -356,9 +365,9 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds[k]) = lo;
             }
         };
-        if (iscale) items(std::true_type{});
+        if (!PKX && iscale) items(std::true_type{});
         else items(std::false_type{});
-        if (!DEEP) {
+        if (!DEEP && !PKX) {
             // patches larger than IG_PMAX*32 pixels (stride-2 geometry): remaining items, synchronously
             for (int it = threadIdx.x + 256 * PSET; it < p_items; it += 256) {
                 const int pix = it >> 3;
@@ -382,6 +391,10 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     // samples of the block's other chunks, reduced over the block -> x * 2^e (conv_common.h).  Called between
     // issue_patch(c_begin) and commit_patch(c_begin).
     auto block_exponent = [&]() {
+        if constexpr (PKX) {   // the image's own exponent (header) x the packed weights' (trailer); nothing to measure
+            unscale = cv_uniform(iscale[1] * *reinterpret_cast<const float *>(wpk + (int64_t)t.ncot * t.nchunks * g.nslices * CV_WSTEP_BYTES));
+            return;
+        }
         float *red = sct + t.nbe * cspan;                             // 16 floats behind the scale table, used for nothing else
 #ifdef RICK_ABLATION
         if (t.debug & 8) {   // timing-only ablation (RICK_CONV_DEBUG=8): no exponent (values are wrong for data far from 1)
@@ -773,14 +786,14 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     else epilogue(std::false_type{}, std::false_type{});
 }
 
-template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, int WDMA = 0>
+template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, int WDMA = 0, bool PKX = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restrict__ x,
                                                             const unsigned char *__restrict__ wpk,
                                                             float *__restrict__ out, const float *__restrict__ iscale,
                                                             const float *__restrict__ oscale, float *__restrict__ ws,
                                                             const rick_conv_geom g, const ConvTiling t,
                                                             const rick_conv_epilogue epi) {
-    igemm_body<SPLIT, VEC, DEEP, NJ, NT, WDMA>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x, epi);
+    igemm_body<SPLIT, VEC, DEEP, NJ, NT, WDMA, PKX>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x, epi);
 }
 
 // Several geometries (the output-parity classes of a transposed convolution) in ONE launch: block ranges
@@ -897,20 +910,20 @@ extern "C" int64_t rick_conv_igemm_workspace_bytes(const rick_conv_geom *g) {
     return t.nsplit > 1 ? (int64_t)t.nsplit * g->N * g->GH * g->GW * g->Co * 4 : 0;
 }
 
-template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT = 0, int WDMA = 0>
+template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT = 0, int WDMA = 0, bool PKX = false>
 static void launch_igemm_k(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
                            const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
                            const ConvTiling &t, const rick_conv_epilogue &epi) {
-    (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT, WDMA>,
+    (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT, WDMA, PKX>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT, WDMA>), dim3(nwg), dim3(256), lds + (WDMA == 3 ? CV_WSTEP_BYTES : 0), st,
+    hipLaunchKernelGGL((conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT, WDMA, PKX>), dim3(nwg), dim3(256), lds + (WDMA == 3 ? CV_WSTEP_BYTES : 0), st,
                        x, wp, out, iscale, oscale, ws, *g, t, epi);
 }
 
 template <int SPLIT, bool VEC>
-static void launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
-                         const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
-                         const ConvTiling &t, const rick_conv_epilogue &epi) {
+static int launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
+                        const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
+                        const ConvTiling &t, const rick_conv_epilogue &epi, bool pkx = false) {
     // production path (fp16x3, vector loads), 3x3 layers with a full grid: the straight-line 9-tap k-loop.  Its
     // loop body carries 0.65 non-MFMA VALU + 0.2 SALU instructions per MFMA against 1.4 + 1.2 (stride 1) / 2.2 + 2.3
     // (stride 2) of the generic tap loop (SQ_INSTS_* counters, profiles/r02_pmc_conv.json): +3..8 % on the Ci >= 256
@@ -924,6 +937,17 @@ static void launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *
                       (t.nsplit == 1 || (u9_split && t.cps >= u9_split)) && t.cps >= u9_minchunks;
     // (stride 2: a k-step has half the MFMAs per weight tile, so the register-staged weight store weighed twice as much:
     // +11..17 % with the tiles by LDS-DMA into the two existing slots)
+    if constexpr (SPLIT == 2 && VEC) {
+        if (pkx) {   // split-image input (`iscale` = its header): the three forms that carry the FLOPs
+            if (u9s2) launch_igemm_k<2, true, false, 2, 9, 2, true>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
+            else if (igemm_tile_positions(g) == 64) return RICK_EINVAL;
+            else if (u9 && lds + CV_WSTEP_BYTES <= 80 * 1024) launch_igemm_k<2, true, false, 4, 9, 3, true>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
+            else if (t.NPP <= IG_DEEP_NPP) launch_igemm_k<2, true, true, 4, 0, 0, true>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
+            else return RICK_EINVAL;
+            return 0;
+        }
+    }
+    if (pkx) return RICK_EINVAL;
     if (u9s2 && ablation_env("RICK_WDMA2", 1)) launch_igemm_k<2, true, false, 2, 9, 2>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
     else if (u9s2) launch_igemm_k<2, true, false, 2, 9>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
     else if (igemm_tile_positions(g) == 64) launch_igemm_k<SPLIT, VEC, false, 2>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
@@ -933,6 +957,7 @@ static void launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *
     else if (u9) launch_igemm_k<2, true, false, 4, 9>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
     else if (t.NPP <= IG_DEEP_NPP) launch_igemm_k<SPLIT, VEC, true, 4>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
     else launch_igemm_k<SPLIT, VEC, false, 4>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
+    return 0;
 }
 
 extern "C" int rick_conv_igemm_act_f32(const float *x, const void *packed_w, float *out, const float *iscale,
@@ -944,9 +969,38 @@ extern "C" int rick_conv_igemm_f32(const float *x, const void *packed_w, float *
     return rick_conv_igemm_act_f32(x, packed_w, out, iscale, oscale, g, nullptr, workspace, stream);
 }
 
+static int igemm_run(const float *x, const void *packed_w, float *out, const float *iscale, const float *oscale,
+                     const rick_conv_geom *g, const rick_conv_epilogue *epilogue, void *workspace, void *stream, bool pkx);
+
 extern "C" int rick_conv_igemm_act_f32(const float *x, const void *packed_w, float *out, const float *iscale,
                                        const float *oscale, const rick_conv_geom *g, const rick_conv_epilogue *epilogue,
                                        void *workspace, void *stream) {
+    return igemm_run(x, packed_w, out, iscale, oscale, g, epilogue, workspace, stream, false);
+}
+
+extern "C" int rick_conv_igemm_split_f32(const void *x_split, const float *x_hdr, const void *packed_w, float *out,
+                                         const float *oscale, const rick_conv_geom *g, const rick_conv_epilogue *epilogue,
+                                         void *workspace, void *stream) {
+    if (!x_hdr || !g || (g->Ci & 31) || g->split != 2) return RICK_EINVAL;
+    return igemm_run((const float *)x_split, packed_w, out, x_hdr, oscale, g, epilogue, workspace, stream, true);
+}
+
+// 1 when rick_conv_igemm_split_f32 has a kernel form for this geometry (mirrors launch_igemm's selection)
+extern "C" int rick_conv_igemm_split_supported(const rick_conv_geom *g) {
+    if (check_geom(g) || (g->Ci & 31) || g->split != 2) return 0;
+    ConvTiling t;
+    if (make_tiling(g, igemm_tile_positions(g), &t)) return 0;
+    igemm_plan_split(&t, g->ntaps);
+    const size_t lds = igemm_lds_bytes(t, false);
+    if (lds > 160 * 1024 || t.PH > 1023 || t.PW > 1023) return 0;
+    const bool fullk = t.nsplit == 1 || t.cps >= 4;
+    if (igemm_tile_positions(g) == 64) return g->ntaps == 9 && t.NPP <= 32 * IG_PMAX && fullk && t.cps >= 4;
+    if (g->ntaps == 9 && t.NPP <= IG_DEEP_NPP && fullk && t.cps >= 4 && lds + CV_WSTEP_BYTES <= 80 * 1024) return 1;
+    return t.NPP <= IG_DEEP_NPP;
+}
+
+static int igemm_run(const float *x, const void *packed_w, float *out, const float *iscale, const float *oscale,
+                     const rick_conv_geom *g, const rick_conv_epilogue *epilogue, void *workspace, void *stream, bool pkx) {
     if (!x || !packed_w || !out || check_geom(g)) return RICK_EINVAL;
     rick_conv_epilogue epi = kNoEpilogue;
     if (epilogue) {
@@ -969,13 +1023,15 @@ extern "C" int rick_conv_igemm_act_f32(const float *x, const void *packed_w, flo
     float *ws = (float *)workspace;
     const unsigned char *wp = (const unsigned char *)packed_w;
     const bool vec = (g->Ci & 3) == 0;
+    int rc;
     if (g->split == 2) {
-        if (vec) launch_igemm<2, true>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
-        else launch_igemm<2, false>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
+        if (vec) rc = launch_igemm<2, true>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi, pkx);
+        else rc = launch_igemm<2, false>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi, pkx);
     } else {
-        if (vec) launch_igemm<1, true>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
-        else launch_igemm<1, false>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
+        if (vec) rc = launch_igemm<1, true>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi, pkx);
+        else rc = launch_igemm<1, false>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi, pkx);
     }
+    if (rc) return rc;
     if (t.nsplit > 1) launch_splitk_reduce(ws, out, oscale, g, t.nsplit, st, epi);
     RICK_LAUNCH_STATUS();
 }

@@ -45,14 +45,29 @@ __device__ __forceinline__ unsigned pack_f16_rne(float a, float b) {   // v_cvt_
 }
 
 // amax (>= 0, finite) -> scale = 2^e and unscale = 2^-e with  amax * scale in [2^T, 2^(T+1));  amax == 0 -> 1, 1.
-__device__ __forceinline__ void cv_pow2_scale(float amax, float &scale, float &unscale) {
+template <int T>
+__device__ __forceinline__ void cv_pow2_scale_t(float amax, float &scale, float &unscale) {
     int eb = (int)((__float_as_uint(amax) >> 23) & 0xffu);           // biased exponent (0 for zero / fp32 subnormals)
-    if (amax == 0.f) eb = 127 + CV_EXP_TARGET;
-    eb = eb < CV_EXP_TARGET + 1 ? CV_EXP_TARGET + 1 : eb;            // keeps both exponent fields in [1, 254]
+    if (amax == 0.f) eb = 127 + T;
+    eb = eb < T + 1 ? T + 1 : eb;                                     // keeps both exponent fields in [1, 254]
     eb = eb > 253 ? 253 : eb;                                         // (inf / nan samples: finite scale, the nan propagates)
-    scale = __uint_as_float((unsigned)(254 + CV_EXP_TARGET - eb) << 23);
-    unscale = __uint_as_float((unsigned)(eb - CV_EXP_TARGET) << 23);
+    scale = __uint_as_float((unsigned)(254 + T - eb) << 23);
+    unscale = __uint_as_float((unsigned)(eb - T) << 23);
 }
+__device__ __forceinline__ void cv_pow2_scale(float amax, float &scale, float &unscale) {
+    cv_pow2_scale_t<CV_EXP_TARGET>(amax, scale, unscale);
+}
+
+// ---- split images (split.hip): an activation / gradient tensor stored pre-split in HBM -------------------------------------
+// A split image of an NHWC fp32 tensor [N, H, W, C] (C % 32 == 0) has the SAME size and pixel pitch: the 128 bytes of a
+// pixel's 32-channel chunk hold [hi: 32 x fp16][lo: 32 x fp16] with hi = fp16(v * 2^e), lo = fp16(v * 2^e - hi) — exactly
+// what the MFMA kernels write into LDS when they split on the fly, so a consumer stages 16-byte granules with no VALU work.
+// ONE exponent per tensor, kept in a 16-byte device header {2^e, 2^-e, bound, 0}.  The exponent is not sampled: the producer
+// is handed a guaranteed BOUND on |v| (exact running maxima its own producers measured with atomic max, combined by the
+// triangle inequality) and places it in [2^13, 2^14): no value can reach the fp16 maximum, and everything within 2^10 of the
+// bound keeps both halves normal (2^-22 relative) — a wider window than the sampled per-block exponents above (2^5).
+#define CV_SPLIT_TARGET 13
+struct cv_split_hdr { float scale, unscale, bound, pad; };
 
 // MODE.FP16_OVFL = 1: an fp32 -> fp16 conversion that overflows gives +-65504 instead of +-inf.  The operand exponent
 // comes from a SAMPLE of the block's data (below); a value more than 2^(13 - T) = 8 188 times the largest sample would

@@ -51,7 +51,8 @@ struct Ct2Plan {
     unsigned posw[32];
 };
 
-template <int SPLIT, int NJ>
+// PKX: x is a split image (conv_common.h), `iscale` its header; staging copies 16-byte granules (see conv.hip).
+template <int SPLIT, int NJ, bool PKX = false>
 __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restrict__ x,
                                                            const unsigned char *__restrict__ wpk,
                                                            float *__restrict__ out, const float *__restrict__ iscale,
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     int p_rel[CT_PITEMS];
     unsigned p_ok = 0, p_nbi = 0;                             // validity bits; image-in-tile of each item, 8 bits each
     const int pix0 = threadIdx.x >> 3;
-    const int p_lds0 = pix0 * 64 + cv_swz(c4 >> 1, pix0) * 16 + (c4 & 1) * 8;
+    const int p_lds0 = PKX ? (c4 >> 2) * pbuf + pix0 * 64 + cv_swz(c4 & 3, pix0) * 16
+                           : pix0 * 64 + cv_swz(c4 >> 1, pix0) * 16 + (c4 & 1) * 8;
     const int phw = P.PH * P.PW;
 #pragma unroll
     for (int k = 0; k < CT_PITEMS; k++) {
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
         }
     }
     // per-(image, input channel) scales of the block's images and channel range; multiplied by the block exponent below
-    if (iscale) {
+    if (!PKX && iscale) {
         for (int i = threadIdx.x; i < P.NB * cspan; i += CT_THREADS) {
             const int nbi = i / cspan, c = c_begin * CV_CK + (i - nbi * cspan);
             sct[i] = (n0 + nbi < P.N && c < P.Ci) ? iscale[(int64_t)(n0 + nbi) * P.Ci + c] : 0.f;
@@ -150,6 +152,10 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
 #pragma unroll
             for (int k = 0; k < CT_PITEMS; k++) {
                 const float4 v = pq[k];       // (an out-of-range item has read the zero page)
+                if constexpr (PKX) {
+                    if (pix0 + (CT_THREADS / 8) * k < P.NPP) *reinterpret_cast<float4 *>(ph + p_lds0 + k * 4096) = v;
+                    continue;
+                }
                 uint2 hi, lo;
                 if constexpr (decltype(ISC)::value) split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sc + ((p_nbi >> (8 * k)) & 255u) * cspan), hi, lo);
                 else split4s<SPLIT>(v, xscale, hi, lo);
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
                 }
             }
         };
-        if (iscale) items(std::true_type{});
+        if (!PKX && iscale) items(std::true_type{});
         else items(std::false_type{});
     };
 
@@ -167,6 +173,10 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     // (already in registers: 32 channels x the whole window) and over samples of the other chunks, reduced over the
     // block -> x * 2^e.
     auto block_exponent = [&]() {
+        if constexpr (PKX) {
+            unscale = cv_uniform(iscale[1] * *reinterpret_cast<const float *>(wpk + (int64_t)P.ncot * P.nchunks * 9 * CV_WSTEP_BYTES));
+            return;
+        }
         float *red = reinterpret_cast<float *>(smem + 2 * pbuf);   // second patch buffer: not written before the chunk loop
         // samples of the block's other chunks (see conv.hip): 8 float4 per thread, issued before the first chunk is reduced
         const int ncl = c_end - c_begin;
@@ -507,9 +517,26 @@ extern "C" int64_t rick_convt2_workspace_bytes(int N, int IH, int IW, int Ci, in
     return p.nsplit > 1 ? (int64_t)p.nsplit * N * OH * OW * Co * 4 : 0;
 }
 
+static int convt2_run(const float *x, const void *packed_w, float *out, const float *iscale, const float *oscale,
+                      int N, int IH, int IW, int Ci, int Co, int OH, int OW, int split, float alpha,
+                      void *workspace, void *stream, bool pkx);
+
 extern "C" int rick_convt2_f32(const float *x, const void *packed_w, float *out, const float *iscale, const float *oscale,
                                int N, int IH, int IW, int Ci, int Co, int OH, int OW, int split, float alpha,
                                void *workspace, void *stream) {
+    return convt2_run(x, packed_w, out, iscale, oscale, N, IH, IW, Ci, Co, OH, OW, split, alpha, workspace, stream, false);
+}
+
+extern "C" int rick_convt2_split_f32(const void *x_split, const float *x_hdr, const void *packed_w, float *out,
+                                     const float *oscale, int N, int IH, int IW, int Ci, int Co, int OH, int OW, float alpha,
+                                     void *workspace, void *stream) {
+    if (!x_hdr || (Ci & 31)) return RICK_EINVAL;
+    return convt2_run((const float *)x_split, packed_w, out, x_hdr, oscale, N, IH, IW, Ci, Co, OH, OW, 2, alpha, workspace, stream, true);
+}
+
+static int convt2_run(const float *x, const void *packed_w, float *out, const float *iscale, const float *oscale,
+                      int N, int IH, int IW, int Ci, int Co, int OH, int OW, int split, float alpha,
+                      void *workspace, void *stream, bool pkx) {
     if (!x || !packed_w || !out || (split != 1 && split != 2)) return RICK_EINVAL;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed_w | (uintptr_t)(iscale ? iscale : x) | (uintptr_t)(oscale ? oscale : x)) % 16)
         return RICK_EINVAL;
@@ -529,7 +556,11 @@ extern "C" int rick_convt2_f32(const float *x, const void *packed_w, float *out,
                            oscale, (float *)workspace, p);
     };
     const int64_t nsub = (nitems - p.nfull) * p.subq;
-    if (split == 2) {
+    if (pkx) {
+        launch(convt2_kernel<2, 8, true>, 0, p.nfull);
+        if (p.subq == 2) launch(convt2_kernel<2, 4, true>, p.nfull, nsub);
+        else if (p.subq == 4) launch(convt2_kernel<2, 2, true>, p.nfull, nsub);
+    } else if (split == 2) {
         launch(convt2_kernel<2, 8>, 0, p.nfull);
         if (p.subq == 2) launch(convt2_kernel<2, 4>, p.nfull, nsub);
         else if (p.subq == 4) launch(convt2_kernel<2, 2>, p.nfull, nsub);

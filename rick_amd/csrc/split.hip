@@ -1,0 +1,106 @@
+// Split images: fp32 NHWC tensors stored as fp16 hi/lo chunk pairs with one power-of-two exponent per tensor
+// (conv_common.h).  Producers of activations / gradients write them next to (or instead of) the fp32 tensor; the MFMA
+// kernels stage them with plain 16-byte copies.  This file: the exact running maximum (atomic max on the float's bits),
+// the stand-alone fp32 -> split-image pass (layers whose producer is not fused yet, tests) and its inverse (tests).
+#include "conv_common.h"
+
+// |x| maximum of n floats, atomically folded into *word (non-negative floats order like their bit patterns).
+__global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ word) {
+    float m = 0.f;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+        m = amax4(m, reinterpret_cast<const float4 *>(x)[i]);
+    if (blockIdx.x == 0)
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(word), __float_as_uint(m));
+}
+
+extern "C" int rick_amax_f32(const float *x, int64_t n, float *amax_word, void *stream) {
+    if (!x || !amax_word || n < 0 || ((uintptr_t)x % 16)) return RICK_EINVAL;
+    if (n == 0) return 0;
+    int64_t nb = cdiv64(n >> 2, 256 * 8);
+    nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, n, amax_word);
+    RICK_LAUNCH_STATUS();
+}
+
+// bound = coef * (*a0 + *a1) -> header.  Every producer of a split image evaluates this itself (block-uniform scalar work)
+// and block 0 publishes the header for the consumers.
+__device__ __forceinline__ cv_split_hdr split_header(const float *a0, const float *a1, float coef) {
+    cv_split_hdr h;
+    h.bound = coef * (a0[0] + (a1 ? a1[0] : 0.f));
+    cv_pow2_scale_t<CV_SPLIT_TARGET>(h.bound, h.scale, h.unscale);
+    h.pad = 0.f;
+    return h;
+}
+
+__global__ __launch_bounds__(256) void split_pack_kernel(const float *__restrict__ x, unsigned char *__restrict__ out,
+                                                         cv_split_hdr *__restrict__ hdr, const float *__restrict__ a0,
+                                                         const float *__restrict__ a1, float coef, int64_t total8, int C8,
+                                                         unsigned *__restrict__ sat) {
+    const cv_split_hdr h = split_header(a0, a1, coef);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *hdr = h;
+    const float s = cv_uniform(h.scale);
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
+        const float4 v0 = reinterpret_cast<const float4 *>(x)[2 * i], v1 = reinterpret_cast<const float4 *>(x)[2 * i + 1];
+        uint2 h0, l0, h1, l1;
+        split4s<2>(v0, s, h0, l0);
+        split4s<2>(v1, s, h1, l1);
+        m = amax4(amax4(m, v0), v1);
+        const int64_t pix = i / C8;
+        const int g = (int)(i - pix * C8);                     // 8-channel group of the pixel: chunk g >> 2, granule g & 3
+        unsigned char *dst = out + (pix * C8 + (g >> 2) * 4) * 32 + (g & 3) * 16;
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        *reinterpret_cast<uint4 *>(dst + 64) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+    // a value above the bound means the caller's bound was no bound: counted, never silent (rick_split_saturation_count)
+    if (m * s >= 65504.f) atomicAdd(sat, 1u);
+}
+
+__global__ __launch_bounds__(256) void split_unpack_kernel(const unsigned char *__restrict__ pk, const cv_split_hdr *__restrict__ hdr,
+                                                           float *__restrict__ out, int64_t total8, int C8) {
+    const float u = hdr->unscale;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / C8;
+        const int g = (int)(i - pix * C8);
+        const unsigned char *src = pk + (pix * C8 + (g >> 2) * 4) * 32 + (g & 3) * 16;
+        const f16x8 hi = *reinterpret_cast<const f16x8 *>(src), lo = *reinterpret_cast<const f16x8 *>(src + 64);
+        float r[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = ((float)hi[k] + (float)lo[k]) * u;
+        reinterpret_cast<float4 *>(out)[2 * i] = make_float4(r[0], r[1], r[2], r[3]);
+        reinterpret_cast<float4 *>(out)[2 * i + 1] = make_float4(r[4], r[5], r[6], r[7]);
+    }
+}
+
+static __device__ unsigned g_split_sat;     // values that reached the fp16 maximum in a split-image producer of this file
+
+extern "C" int rick_split_pack_f32(const float *x, void *out, float *hdr, const float *amax0, const float *amax1, float coef,
+                                   int64_t npix, int C, void *stream) {
+    if (!x || !out || !hdr || !amax0 || npix < 0 || C <= 0 || (C & 31) || !(coef > 0.f)) return RICK_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)hdr) % 16) return RICK_EINVAL;
+    if (npix == 0) return 0;
+    const int64_t total8 = npix * (C / 8);
+    int64_t nb = cdiv64(total8, 256 * 4);
+    nb = nb < 1 ? 1 : (nb > 8192 ? 8192 : nb);
+    unsigned *sat;
+    if (hipGetSymbolAddress((void **)&sat, HIP_SYMBOL(g_split_sat)) != hipSuccess) return RICK_EINVAL;
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, (unsigned char *)out,
+                       (cv_split_hdr *)hdr, amax0, amax1, coef, total8, C / 8, sat);
+    RICK_LAUNCH_STATUS();
+}
+
+extern "C" int rick_split_unpack_f32(const void *pk, const float *hdr, float *out, int64_t npix, int C, void *stream) {
+    if (!pk || !hdr || !out || npix < 0 || C <= 0 || (C & 31)) return RICK_EINVAL;
+    if (((uintptr_t)pk | (uintptr_t)out | (uintptr_t)hdr) % 16) return RICK_EINVAL;
+    if (npix == 0) return 0;
+    const int64_t total8 = npix * (C / 8);
+    int64_t nb = cdiv64(total8, 256 * 4);
+    nb = nb < 1 ? 1 : (nb > 8192 ? 8192 : nb);
+    hipLaunchKernelGGL(split_unpack_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const unsigned char *)pk,
+                       (const cv_split_hdr *)hdr, out, total8, C / 8);
+    RICK_LAUNCH_STATUS();
+}

@@ -47,11 +47,16 @@ __device__ __forceinline__ int wg_pswz(int kg, int pix, int kb) { return kg ^ ((
 // hardware returns zeros); conversion is the fp16 split with the scale folded in — no zero-select.  ~15 / ~22 instructions per item instead of ~30.  The
 // kernel is bound by the ISSUE of exactly these instructions (one wave per SIMD, 2-3 of them per MFMA, and an MFMA
 // leaves room for ~2), not by the matrix pipe: measured +20...27 % (280 -> 330-345 TFLOP/s on the 64^2...256^2 layers).
-template <int NT, int SPLIT, bool VEC, int PMAX, bool PIPE, int FAST = 0>   // FAST: 1 = no per-channel scales, 2 = with
+// PK (FAST == 1 only): bit 0 = gy is a split image, bit 1 = x is a split image (conv_common.h; `ascale` / `bscale` then point
+// at the image's header instead of a scale table).  A split image has the fp32 tensor's pixel pitch and 16-byte granules of 8
+// channels, so the staging items keep their addresses; an item is copied to LDS as it is (one ds_write_b128, no conversion)
+// and the operand's exponent comes from the header.
+template <int NT, int SPLIT, bool VEC, int PMAX, bool PIPE, int FAST = 0, int PK = 0>   // FAST: 1 = no per-channel scales, 2 = with
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                          float *__restrict__ ws, const float *__restrict__ ascale,
                                                          const float *__restrict__ bscale, const rick_conv_geom g,
                                                          const ConvTiling t, int nsplit, int tiles_per_split) {
+    static_assert(PK == 0 || (FAST == 1 && SPLIT == 2 && PIPE), "split-image operands: the scale-free pipelined form");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cv_fp16_saturate();
     // one operand buffer = [gy hi 16 KB][gy lo 16 KB][patch hi (NPP+1) x 64 B][patch lo]; PIPE keeps two of them
@@ -129,11 +134,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     // a global-load round trip per item)
     for (int i = threadIdx.x; i < g.N * CV_BM; i += 256) {
         const int n = i >> 7, co = co_base + (i & 127);
-        sA[i] = !ascale ? 1.f : co < g.Co ? ascale[(int64_t)n * g.Co + co] : 0.f;
+        sA[i] = (!ascale || (PK & 1)) ? 1.f : co < g.Co ? ascale[(int64_t)n * g.Co + co] : 0.f;
     }
     for (int i = threadIdx.x; i < g.N * CV_CK; i += 256) {
         const int n = i >> 5, ci = ci_base + (i & 31);
-        sB[i] = !bscale ? 1.f : ci < g.Ci ? bscale[(int64_t)n * g.Ci + ci] : 0.f;
+        sB[i] = (!bscale || (PK & 2)) ? 1.f : ci < g.Ci ? bscale[(int64_t)n * g.Ci + ci] : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -143,6 +148,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         g_rel[k] = ((nbi * g.OH + py * g.os) * g.OW + px * g.os) * g.Co;
         g_pyx[k] = (gco < g.Co && nbi < t.nbe) ? (((unsigned)nbi << 20) | ((unsigned)py << 10) | (unsigned)px) : 0xffffffffu;
         g_lds[k] = r * 256 + ((gc4 * 8) ^ (wg_key(r) * 32));
+        if constexpr ((PK & 1) != 0)     // granule gc4 of the pixel's 512 bytes: chunk gc4 >> 3, hi / lo plane bit 2, 8 channels each
+            g_lds[k] = ((gc4 >> 2) & 1) * WG_GY_BYTES + r * 256 + ((((gc4 >> 3) * 32 + (gc4 & 3) * 8) * 2) ^ (wg_key(r) * 32));
     }
 #pragma unroll
     for (int k = 0; k < PMAX; k++) {
@@ -150,6 +157,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         p_rel[k] = 0;
         p_pyx[k] = 0xffffffffu;
         p_lds[k] = (pix < t.NPP ? pix : t.NPP) * 64 + wg_pswz(pc4 >> 1, pix, t.pkb) * 16 + (pc4 & 1) * 8;
+        if constexpr ((PK & 2) != 0)     // granule pc4 of the chunk's 128 bytes: hi / lo plane bit 2, k-group pc4 & 3
+            p_lds[k] = (pc4 >> 2) * (t.NPP + 1) * 64 + (pix < t.NPP ? pix : t.NPP) * 64 + wg_pswz(pc4 & 3, pix, t.pkb) * 16;
         if (pix < t.NPP) {
             const unsigned e = ptab[pix];
             p_rel[k] = (((int)(e >> 20) * g.IH + (int)((e >> 10) & 1023)) * g.IW + (int)(e & 1023)) * g.Ci;
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             const int nrem = g.N - n0, yrem = g.GH - gy0, xrem = g.GW - gx0;
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {
-                {
+                if constexpr ((PK & 1) == 0) {
                     const int k = (2 * sidx + 5 * kk + 1) & 7;
                     const unsigned e = g_pyx[k];
                     const int nbi = (int)(e >> 20), py = (int)((e >> 10) & 1023), px = (int)(e & 1023);
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                     v = mul4(v, *reinterpret_cast<const float4 *>(sA + (ok ? (n0 + nbi) * CV_BM : 0) + gc4 * 4));
                     if (ok) ma = amax4(ma, v);
                 }
-                {
+                if constexpr ((PK & 2) == 0) {
                     const int k = (3 * sidx + 7 * kk + 2) % PMAX;
                     const unsigned e = p_pyx[k];
                     const int nbi = (int)(e >> 20), iy = iy0 + (int)((e >> 10) & 1023), ix = ix0 + (int)(e & 1023);
@@ -204,6 +213,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         float sa, ua, sb, ub;
         cv_pow2_scale(ma, sa, ua);
         cv_pow2_scale(mb, sb, ub);
+        if constexpr ((PK & 1) != 0) { sa = 1.f; ua = ascale[1]; }      // header {2^e, 2^-e, ..} of the split image
+        if constexpr ((PK & 2) != 0) { sb = 1.f; ub = bscale[1]; }
         punscale = cv_uniform(ua * ub);
         xsa = cv_uniform(sa);
         xsb = cv_uniform(sb);
@@ -396,7 +407,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             const bool ok = (mask_cv >> K) & 1u;
             if constexpr (FAST) {
                 uint2 hi, lo;
-                if constexpr (K < 8) {
+                if constexpr (K < 8 && (PK & 1) != 0) {
+                    *reinterpret_cast<float4 *>(buf + g_lds[K]) = gq[K];
+                } else if constexpr (K >= 8 && (PK & 2) != 0) {
+                    *reinterpret_cast<float4 *>(buf + 2 * WG_GY_BYTES + p_lds[K - 8]) = pq[K - 8];
+                } else if constexpr (K < 8) {
                     const float4 v = gq[K];
                     if constexpr (FAST == 2) {     // modulated layers (G) carry per-(image, channel) scales (x block exponent)
                         if constexpr (ONE_IMG) split4v_mix<SPLIT>(v, sa_cv, hi, lo);
@@ -652,13 +667,13 @@ extern "C" int64_t rick_conv_wgrad_workspace_bytes(const rick_conv_geom *g) {
     return (int64_t)nsplit * t.ncot * t.nchunks * g->ntaps * CV_BM * CV_CK * 4;
 }
 
-template <int NT, int SPLIT, bool VEC, int PMAX, bool PIPE, int FAST = 0>
+template <int NT, int SPLIT, bool VEC, int PMAX, bool PIPE, int FAST = 0, int PK = 0>
 static void launch_wgrad_k(const float *x, const float *gy, float *ws, const float *ascale, const float *bscale,
                            const rick_conv_geom *g, const ConvTiling &t, int nsplit, int tps, size_t lds, hipStream_t st) {
     const unsigned nwg = (unsigned)(nsplit * t.ncot * t.nchunks);
-    (void)hipFuncSetAttribute((const void *)conv_wgrad_kernel<NT, SPLIT, VEC, PMAX, PIPE, FAST>,
+    (void)hipFuncSetAttribute((const void *)conv_wgrad_kernel<NT, SPLIT, VEC, PMAX, PIPE, FAST, PK>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv_wgrad_kernel<NT, SPLIT, VEC, PMAX, PIPE, FAST>), dim3(nwg), dim3(256), lds, st, x, gy, ws, ascale,
+    hipLaunchKernelGGL((conv_wgrad_kernel<NT, SPLIT, VEC, PMAX, PIPE, FAST, PK>), dim3(nwg), dim3(256), lds, st, x, gy, ws, ascale,
                        bscale, *g, t, nsplit, tps);
 }
 
@@ -672,18 +687,35 @@ static bool wgrad_use_pipe(const rick_conv_geom *g, const ConvTiling &t) {
     return !off && g->split == 2 && ((g->Ci | g->Co) & 3) == 0 && wgrad_lds_bytes(g, t, true) <= 160 * 1024;
 }
 
+// FAST: position grid an exact multiple of the tile, full 128 x 32 channel blocks
+static bool wgrad_fast(const rick_conv_geom *g, const ConvTiling &t, int NT) {
+    return wgrad_use_pipe(g, t) && g->ntaps == NT &&
+           (int64_t)g->N * g->IH * g->IW * g->Ci < (1LL << 29) && (int64_t)g->N * g->OH * g->OW * g->Co < (1LL << 29) &&   // (32-bit byte offsets of the buffer loads)
+           !(g->Co % CV_BM) && !(g->Ci % CV_CK) && !(g->GH & ((1 << t.th_log2) - 1)) &&
+           !(g->GW & ((1 << t.tw_log2) - 1)) && !(g->N % t.nbe) && (t.nb == t.nbe);
+}
+
 template <int NT>
-static void launch_wgrad(const float *x, const float *gy, float *ws, const float *ascale, const float *bscale,
-                         const rick_conv_geom *g, const ConvTiling &t, int nsplit, int tps, hipStream_t st) {
+static int launch_wgrad(const float *x, const float *gy, float *ws, const float *ascale, const float *bscale,
+                        const rick_conv_geom *g, const ConvTiling &t, int nsplit, int tps, hipStream_t st, int pk = 0) {
     const bool vec = ((g->Ci | g->Co) & 3) == 0;
     const bool small = t.NPP <= 4 * 32;
     const bool pipe = wgrad_use_pipe(g, t);
     const size_t lds = wgrad_lds_bytes(g, t, pipe);
-    // FAST: position grid an exact multiple of the tile, full 128 x 32 channel blocks
-    const bool fast = pipe && g->ntaps == NT &&
-                      (int64_t)g->N * g->IH * g->IW * g->Ci < (1LL << 29) && (int64_t)g->N * g->OH * g->OW * g->Co < (1LL << 29) &&   // (32-bit byte offsets of the buffer loads)
-                      !(g->Co % CV_BM) && !(g->Ci % CV_CK) && !(g->GH & ((1 << t.th_log2) - 1)) &&
-                      !(g->GW & ((1 << t.tw_log2) - 1)) && !(g->N % t.nbe) && (t.nb == t.nbe);
+    const bool fast = wgrad_fast(g, t, NT);
+    if (pk) {   // split-image operands (`ascale` / `bscale` carry the headers): only the whole-tile form
+        if (!fast || g->split != 2) return RICK_EINVAL;
+        if (small) {
+            if (pk == 3) launch_wgrad_k<NT, 2, true, 4, true, 1, 3>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+            else if (pk == 2) launch_wgrad_k<NT, 2, true, 4, true, 1, 2>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+            else launch_wgrad_k<NT, 2, true, 4, true, 1, 1>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+        } else {
+            if (pk == 3) launch_wgrad_k<NT, 2, true, 12, true, 1, 3>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+            else if (pk == 2) launch_wgrad_k<NT, 2, true, 12, true, 1, 2>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+            else launch_wgrad_k<NT, 2, true, 12, true, 1, 1>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+        }
+        return 0;
+    }
     const bool scaled = ascale != nullptr || bscale != nullptr;
     // ONE chain: exactly one kernel per call
     if (g->split == 1 && vec) launch_wgrad_k<NT, 1, true, 12, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
@@ -696,11 +728,40 @@ static void launch_wgrad(const float *x, const float *gy, float *ws, const float
     else if (small) launch_wgrad_k<NT, 2, true, 4, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
     else if (pipe) launch_wgrad_k<NT, 2, true, 12, true>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
     else launch_wgrad_k<NT, 2, true, 12, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
+    return 0;
 }
+
+static int wgrad_run(const float *x, const float *gy, float *gw, int64_t s_co, int64_t s_ci, int64_t s_t,
+                     const float *ascale, const float *bscale, const rick_conv_geom *g, int accumulate,
+                     void *workspace, void *stream, int pk);
 
 extern "C" int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw, int64_t s_co, int64_t s_ci, int64_t s_t,
                                    const float *ascale, const float *bscale, const rick_conv_geom *g, int accumulate,
                                    void *workspace, void *stream) {
+    return wgrad_run(x, gy, gw, s_co, s_ci, s_t, ascale, bscale, g, accumulate, workspace, stream, 0);
+}
+
+// 1 when the geometry runs the whole-tile form that accepts split-image operands (rick_conv_wgrad_split_f32)
+extern "C" int rick_conv_wgrad_split_supported(const rick_conv_geom *g) {
+    if (check_geom(g) || g->ntaps > 9 || g->split != 2) return 0;
+    ConvTiling t;
+    int nsplit, tps;
+    wgrad_plan(g, &t, &nsplit, &tps);
+    if (t.NPP > 12 * 32) return 0;
+    return wgrad_fast(g, t, g->ntaps == 1 ? 1 : g->ntaps <= 4 ? 4 : 9) ? 1 : 0;
+}
+
+extern "C" int rick_conv_wgrad_split_f32(const void *x, const float *x_hdr, const void *gy, const float *gy_hdr, float *gw,
+                                         int64_t s_co, int64_t s_ci, int64_t s_t, const rick_conv_geom *g, int accumulate,
+                                         void *workspace, void *stream) {
+    const int pk = (gy_hdr ? 1 : 0) | (x_hdr ? 2 : 0);
+    if (!pk) return RICK_EINVAL;
+    return wgrad_run((const float *)x, (const float *)gy, gw, s_co, s_ci, s_t, gy_hdr, x_hdr, g, accumulate, workspace, stream, pk);
+}
+
+static int wgrad_run(const float *x, const float *gy, float *gw, int64_t s_co, int64_t s_ci, int64_t s_t,
+                     const float *ascale, const float *bscale, const rick_conv_geom *g, int accumulate,
+                     void *workspace, void *stream, int pk) {
     if (!x || !gy || !gw || !workspace || check_geom(g)) return RICK_EINVAL;
     if (g->ntaps > 9) return RICK_EINVAL;
     if (((uintptr_t)x | (uintptr_t)gy | (uintptr_t)(ascale ? ascale : x) | (uintptr_t)(bscale ? bscale : x)) % 16) return RICK_EINVAL;
@@ -711,9 +772,11 @@ extern "C" int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw, i
     if (g->split == 1 && (((g->Ci | g->Co) & 3) != 0)) return RICK_EINVAL;   // plain-fp16 option: vector path only
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
-    if (g->ntaps == 1) launch_wgrad<1>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
-    else if (g->ntaps <= 4) launch_wgrad<4>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
-    else launch_wgrad<9>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
+    int rc;
+    if (g->ntaps == 1) rc = launch_wgrad<1>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st, pk);
+    else if (g->ntaps <= 4) rc = launch_wgrad<4>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st, pk);
+    else rc = launch_wgrad<9>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st, pk);
+    if (rc) return rc;
     const int64_t per_split = (int64_t)t.ncot * t.nchunks * g->ntaps * CV_BM * CV_CK;
     const int nsl = g->nslices;
     const unsigned ntile = (unsigned)(t.ncot * t.nchunks * 16);

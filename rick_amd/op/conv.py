@@ -296,8 +296,9 @@ def _epilogue(bias, noise, noise_w, slope, gain):
     return e
 
 
-def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0, epi=None):
-    x = _nhwc(x)
+def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0, epi=None, x_split=None):
+    """`x_split`: the input as a split image (op/split.py; its producer has folded `iscale` in) — `x` may then be None."""
+    x = _nhwc(x) if x_split is None else x_split.data
     N, I, IH, IW = x.shape
     key = ('c', N, I, IH, IW, O, kh, kw, s, p, alpha, _SPLIT)
     ent = _geom_cache.get(key)
@@ -314,6 +315,11 @@ def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0, ep
     g, gref, nbytes, OH, OW, flops, tag, abytes = ent
     y = _empty_nhwc(N, O, OH, OW, x)
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
+    if x_split is not None:
+        check(_launch('igemm', flops, lib.rick_conv_igemm_split_f32, ptr(x), ptr(x_split.hdr), ptr(wp), ptr(y), ptr(oscale), gref,
+                      ctypes.byref(epi) if epi is not None else None, ptr(ws), stream_ptr(), tag=tag, abytes=abytes),
+              'rick_conv_igemm_split_f32')
+        return y
     if epi is not None:
         check(_launch('igemm', flops, lib.rick_conv_igemm_act_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), gref,
                       ctypes.byref(epi), ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_conv_igemm_act_f32')
@@ -326,7 +332,7 @@ def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0, ep
 _USE_CT2 = True     # tools/bench_conv.py switches the dedicated stride-2 kernel off to time the generic multi-class launch
 
 
-def _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha):
+def _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha, x_split=None):
     """3x3 stride-2 padding-0 transposed convolution on the single-staging kernel (csrc/convt2.hip)."""
     N, I, IH, IW = x.shape
     OH, OW = out_hw
@@ -348,21 +354,28 @@ def _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha):
         return None
     y = _empty_nhwc(N, O, OH, OW, x)
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
+    if x_split is not None:
+        check(_launch('igemm', flops, lib.rick_convt2_split_f32, ptr(x), ptr(x_split.hdr), ptr(wp), ptr(y), ptr(oscale), N, IH, IW,
+                      I, O, OH, OW, alpha, ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_convt2_split_f32')
+        return y
     check(_launch('igemm', flops, lib.rick_convt2_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), N, IH, IW, I, O,
                   OH, OW, _SPLIT, alpha, ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_convt2_f32')
     return y
 
 
-def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alpha=1.0):
-    """y[q] += w[k] x[pos], q = pos*s + k - p: the output parity classes (s*s of them) run as one launch."""
-    x = _nhwc(x)
+def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alpha=1.0, x_split=None):
+    """y[q] += w[k] x[pos], q = pos*s + k - p: the output parity classes (s*s of them) run as one launch.
+    `x_split`: the input as a split image (stride 1, or the 3x3 stride-2 single-staging kernel)."""
+    x = _nhwc(x) if x_split is None else x_split.data
     N, I, IH, IW = x.shape
     OH, OW = out_hw
     if (_USE_CT2 and kh == 3 and kw == 3 and s == 2 and p == 0 and I % 4 == 0 and O % 4 == 0
             and OH in (2 * IH, 2 * IH + 1) and OW in (2 * IW, 2 * IW + 1)):
-        y = _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha)
+        y = _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha, x_split=x_split)
         if y is not None:            # (None: the single-staging kernel has no plan for this size -> generic launch below)
             return y
+    if x_split is not None and s != 1:
+        raise RuntimeError('convT: no split-image form for this geometry')
     key = ('t', N, I, IH, IW, O, kh, kw, s, p, OH, OW, alpha, _SPLIT)
     ent = _geom_cache.get(key)
     if ent is None:
@@ -410,6 +423,10 @@ def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alph
     if not full:
         y.zero_()
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
+    if x_split is not None:          # stride 1: one class
+        check(_launch('igemm', flops, lib.rick_conv_igemm_split_f32, ptr(x), ptr(x_split.hdr), ptr(wp), ptr(y), ptr(oscale),
+                      ctypes.byref(geoms[0]), None, ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_conv_igemm_split_f32')
+        return y
     check(_launch('igemm', flops, lib.rick_conv_igemm_multi_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale),
                   geoms, ngeom, ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_conv_igemm_multi_f32')
     return y
@@ -477,10 +494,15 @@ def _sink_target(key, shape, enabled):
     return p.grad.view(shape)
 
 
-def _wgrad_launch(a, b, kh, kw, s, p, alpha=1.0, ascale=None, bscale=None, out=None, transposed=False):
+def _wgrad_launch(a, b, kh, kw, s, p, alpha=1.0, ascale=None, bscale=None, out=None, transposed=False, a_split=None,
+                  b_split=None):
     """gw[o,i,ky,kx] = alpha * sum a[n,o,pos] b[n,i,pos*s + k - p]  -> contiguous [O, I, kh, kw].
     `out`: ADD the result into this contiguous tensor instead ([O, I, kh, kw], or [I, O, kh, kw] when `transposed` — the
     parameter layout of a transposed convolution's weight gradient)."""
+    if a_split is not None:
+        a = a_split.data                 # (shape carrier; `a` / `b` may be None when only the image exists)
+    if b_split is not None:
+        b = b_split.data
     a, b = _nhwc(a), _nhwc(b)
     N, O, AH, AW = a.shape
     _, I, BH, BW = b.shape
@@ -500,6 +522,20 @@ def _wgrad_launch(a, b, kh, kw, s, p, alpha=1.0, ascale=None, bscale=None, out=N
     g, gref, nbytes, flops, tag, abytes = ent
     ws = torch.empty(nbytes, device=a.device, dtype=torch.uint8)
     K = kh * kw
+    if a_split is not None or b_split is not None:
+        # split-image operands (op/split.py): no fp32 -> fp16 conversion inside the kernel
+        if not lib.rick_conv_wgrad_split_supported(gref):
+            raise RuntimeError('wgrad: geometry has no split-image form')
+        if out is not None:
+            s_co, s_ci, acc, dst = (K, O * K, 1, out) if transposed else (I * K, K, 1, out)
+        else:
+            dst = torch.empty((O, I, kh, kw), device=a.device, dtype=torch.float32)
+            s_co, s_ci, acc = I * K, K, 0
+        check(_launch('wgrad', flops, lib.rick_conv_wgrad_split_f32, ptr(b_split.data if b_split is not None else b),
+                      ptr(b_split.hdr) if b_split is not None else None, ptr(a_split.data if a_split is not None else a),
+                      ptr(a_split.hdr) if a_split is not None else None, ptr(dst), s_co, s_ci, 1, gref, acc, ptr(ws),
+                      stream_ptr(), tag=tag, abytes=abytes), 'rick_conv_wgrad_split_f32')
+        return None if out is not None else dst
     if out is not None:
         s_co, s_ci = (K, O * K) if transposed else (I * K, K)
         check(_launch('wgrad', flops, lib.rick_conv_wgrad_f32, ptr(b), ptr(a), ptr(out), s_co, s_ci, 1,
