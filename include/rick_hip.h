@@ -145,6 +145,8 @@ typedef struct {
     int noise_nb;           /* 1 (shared map) or N */
     int act;                /* 0: none, 1: LeakyReLU(slope) * gain */
     float slope, gain;
+    float *amax;            /* NULL, or a device word: max |out| is folded into it with an atomic max (the exact bound the
+                             * producer of the next split image needs; see "Split images" below) */
 } rick_conv_epilogue;
 int rick_conv_igemm_f32(const float *x, const void *packed_w, float *out,
                         const float *iscale, const float *oscale,
@@ -209,6 +211,35 @@ int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw,
  * 2^-10 of the bound keep 2^-22 relative precision.  rick_amax_f32 folds max |x| into *amax_word with an atomic max
  * (callers zero the word first); the kernels that produce activations measure the same maximum in their epilogues. */
 int rick_amax_f32(const float *x, int64_t n, float *amax_word, void *stream);
+/* What a producer kernel does with its result besides (or instead of) the fp32 store. */
+typedef struct {
+    void *split_out;        /* also write the result as a split image (NULL: no) */
+    float *split_hdr;       /* its 16-byte header, published by the launch */
+    const float *bound0;    /* |result| <= bound_coef * (*bound0 + *bound1); bound1 may be NULL */
+    const float *bound1;
+    float bound_coef;
+    float *amax;            /* NULL, or: fold max |result| (after accumulation) into this word */
+    int accumulate;         /* add the result to what the fp32 output holds (a second gradient arriving at a branch point) */
+    int no_f32;             /* do not write the fp32 result (the output pointer may be NULL) */
+} rick_split_out;
+/* values that exceeded their producer's bound since the last reset (0 unless a caller passed a wrong bound); host-synchronous */
+int rick_saturation_count(unsigned *count, int reset);
+/* Producers.  rick_upfirdn2d_f32 / rick_upfirdn2d_act_f32 (tail may be NULL) with the extended result handling, channels-last
+ * only; `out` may be NULL with ex->no_f32.  The activation adjoint (rick_bias_act_bwd_f32) leaving as split images:
+ * out1 = g * (ref > 0 ? 1 : alpha) * scale and, when out2 != NULL, out2 = g * mul2 (the same gradient entering a parallel linear
+ * branch), both bounded through *amax_g >= max |g|.  The ResBlock merge y = (a + b) * alpha (rick_add_scale_f32) written as
+ * fp32 and as a split image. */
+int rick_upfirdn2d_ex_f32(const float *input, const float *kernel, float *out,
+                          int64_t major, int in_h, int in_w, int minor, int kh, int kw,
+                          int up_x, int up_y, int down_x, int down_y,
+                          int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                          const rick_conv_epilogue *tail, const rick_split_out *ex, void *stream);
+int rick_bias_act_bwd_split_f32(const float *g, const float *ref, void *out1, float *hdr1, void *out2, float *hdr2,
+                                float mul2, const float *amax_g, float *gb, float *gnw, const float *noise,
+                                int64_t rows, int C, int64_t rows_per_img, int64_t noise_nb, int64_t noise_hw,
+                                float alpha, float scale, float *partials, int accumulate, void *stream);
+int rick_add_scale_split_f32(const float *a, const float *b, float *y, void *y_split, float *hdr,
+                             const float *amax_a, const float *amax_b, int64_t rows, int C, float alpha, void *stream);
 int rick_split_pack_f32(const float *x, void *out, float *hdr, const float *amax0, const float *amax1, float coef,
                         int64_t npix, int C, void *stream);
 int rick_split_unpack_f32(const void *split, const float *hdr, float *out, int64_t npix, int C, void *stream);

@@ -37,7 +37,13 @@ class ConvGeom(ctypes.Structure):
 class ConvEpilogue(ctypes.Structure):
     """rick_conv_epilogue (include/rick_hip.h)."""
     _fields_ = [('bias', c_fp), ('noise', c_fp), ('noise_w', c_fp), ('noise_nb', c_int), ('act', c_int),
-                ('slope', c_f), ('gain', c_f)]
+                ('slope', c_f), ('gain', c_f), ('amax', c_fp)]
+
+
+class SplitOut(ctypes.Structure):
+    """rick_split_out (include/rick_hip.h)."""
+    _fields_ = [('split_out', c_fp), ('split_hdr', c_fp), ('bound0', c_fp), ('bound1', c_fp), ('bound_coef', c_f),
+                ('amax', c_fp), ('accumulate', c_int), ('no_f32', c_int)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/rick_hip.h
@@ -56,6 +62,12 @@ SIGNATURES = {
     'rick_conv_wgrad_split_supported': (c_int, [ctypes.POINTER(ConvGeom)]),
     'rick_conv_wgrad_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, ctypes.POINTER(ConvGeom), c_int,
                                           c_fp, c_fp]),
+    'rick_saturation_count': (c_int, [ctypes.POINTER(ctypes.c_uint), c_int]),
+    'rick_upfirdn2d_ex_f32': (c_int, [c_fp, c_fp, c_fp, c_i64] + [c_int] * 13 + [ctypes.POINTER(ConvEpilogue),
+                                                                                 ctypes.POINTER(SplitOut), c_fp]),
+    'rick_bias_act_bwd_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_i64,
+                                            c_i64, c_i64, c_f, c_f, c_fp, c_int, c_fp]),
+    'rick_add_scale_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_f, c_fp]),
     'rick_conv_igemm_split_supported': (c_int, [ctypes.POINTER(ConvGeom)]),
     'rick_conv_igemm_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue),
                                           c_fp, c_fp]),

@@ -691,6 +691,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     const bool covec = (g.Co & 3) == 0;
     const float oalpha = g.alpha * unscale;   // exact: the exponents are powers of two
     const float nwv = epi.noise ? epi.noise_w[0] : 0.f;
+    float out_amax = 0.f;      // running max |out| of this thread's stores (epi.amax)
     auto epilogue = [&](auto HAS_OS, auto HAS_EP) {
         constexpr bool OS = decltype(HAS_OS)::value;
         constexpr bool EP = decltype(HAS_EP)::value;   // fused bias (+ noise) + LeakyReLU tail (rick_conv_epilogue)
@@ -756,6 +757,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                             }
                         }
                         *reinterpret_cast<float4 *>(orow + co) = v;
+                        out_amax = amax4(out_amax, v);
                     }
                 }
                 continue;
@@ -773,9 +775,10 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                     if (co + 3 < g.Co) v[3] *= sp[3];
                 }
                 orow[co] = v[0];
-                if (co + 1 < g.Co) orow[co + 1] = v[1];
-                if (co + 2 < g.Co) orow[co + 2] = v[2];
-                if (co + 3 < g.Co) orow[co + 3] = v[3];
+                out_amax = fmaxf(out_amax, fabsf(v[0]));
+                if (co + 1 < g.Co) { orow[co + 1] = v[1]; out_amax = fmaxf(out_amax, fabsf(v[1])); }
+                if (co + 2 < g.Co) { orow[co + 2] = v[2]; out_amax = fmaxf(out_amax, fabsf(v[2])); }
+                if (co + 3 < g.Co) { orow[co + 3] = v[3]; out_amax = fmaxf(out_amax, fabsf(v[3])); }
             }
         }
     };
@@ -784,6 +787,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     else if (oscale) epilogue(std::true_type{}, std::false_type{});
     else if (has_ep) epilogue(std::false_type{}, std::true_type{});
     else epilogue(std::false_type{}, std::false_type{});
+    if (epi.amax && t.nsplit == 1) cv_amax_publish(out_amax, epi.amax);     // (split-K: the second stage measures)
 }
 
 template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, int WDMA = 0, bool PKX = false>
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_multi_kernel(const float *_
         }
     // every parity class of a transposed conv has a patch of <= 160 pixels (tile + at most one halo row/col)
     // (the host only uses this kernel when every class qualifies for the two-ahead prefetch)
-    const rick_conv_epilogue none = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f};
+    const rick_conv_epilogue none = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f, nullptr};
     igemm_body<SPLIT, VEC, true, 4, 0>(x, wpk, out, iscale, oscale, ws + m.ws_off[c], m.g[c], m.t[c], (int)blockIdx.x - start,
                                        m.blk_end[c] - start, none);
 }
@@ -840,6 +844,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float *_
     const float nwv = epi.noise ? epi.noise_w[0] : 0.f;
     const unsigned per = (unsigned)g.N * g.GH * g.GW * g.Co;
     const unsigned cow = (unsigned)g.Co / W;
+    float ram = 0.f;
     for (unsigned iw = blockIdx.x * 256 + threadIdx.x; iw < per / W; iw += gridDim.x * 256) {
         const unsigned cq = iw % cow;
         unsigned pos = iw / cow;
@@ -879,17 +884,20 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float *_
                 v.w = (v.w > 0.f ? v.w : v.w * epi.slope) * epi.gain;
             }
             *reinterpret_cast<float4 *>(out + o) = v;
+            ram = amax4(ram, v);
         } else {
             float s = 0.f;
             for (int sp = 0; sp < nsplit; sp++) s += ws[(size_t)sp * per + iw];
             s *= g.alpha;
             if (oscale) s *= oscale[(size_t)n * g.Co + co];
             out[o] = s;
+            ram = fmaxf(ram, fabsf(s));
         }
     }
+    if (epi.amax) cv_amax_publish(ram, epi.amax);
 }
 
-static const rick_conv_epilogue kNoEpilogue = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f};
+static const rick_conv_epilogue kNoEpilogue = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f, nullptr};
 
 static void launch_splitk_reduce(const float *ws, float *out, const float *oscale, const rick_conv_geom *g, int nsplit,
                                  hipStream_t st, const rick_conv_epilogue &epi = kNoEpilogue) {
@@ -898,7 +906,11 @@ static void launch_splitk_reduce(const float *ws, float *out, const float *oscal
     int64_t nb = cdiv64(vec ? per / 4 : per, 256);
     if (nb > 8192) nb = 8192;
     if (vec) hipLaunchKernelGGL(igemm_splitk_reduce_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, nsplit, epi);
-    else hipLaunchKernelGGL(igemm_splitk_reduce_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, nsplit, kNoEpilogue);
+    else {
+        rick_conv_epilogue e2 = kNoEpilogue;
+        e2.amax = epi.amax;
+        hipLaunchKernelGGL(igemm_splitk_reduce_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, nsplit, e2);
+    }
 }
 
 

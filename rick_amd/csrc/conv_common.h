@@ -206,3 +206,43 @@ __device__ __forceinline__ void static_for(F &&f) {   // f(integral_constant<int
     }
 }
 
+
+// ---- split-image producers (epilogues of the kernels that write activations / gradients) ---------------------------------
+// header from the producer's bound  coef * (*b0 + *b1)  (b1 may be NULL); every thread evaluates it (block-uniform scalar
+// work), ONE thread of the launch publishes it for the consumers
+__device__ __forceinline__ cv_split_hdr cv_split_header(const float *b0, const float *b1, float coef) {
+    cv_split_hdr h;
+    h.bound = coef * (b0[0] + (b1 ? b1[0] : 0.f));
+    cv_pow2_scale_t<CV_SPLIT_TARGET>(h.bound, h.scale, h.unscale);
+    h.pad = 0.f;
+    return h;
+}
+// channels c .. c+3 (c % 4 == 0) of the pixel whose first chunk starts at `pixel`:  hi -> 8 bytes, lo -> 8 bytes 64 further
+__device__ __forceinline__ void cv_split_store4(unsigned char *pixel, int c, const float4 v, float s) {
+    uint2 hi, lo;
+    split4s<2>(v, s, hi, lo);
+    unsigned char *d = pixel + (c >> 5) * 128 + (c & 31) * 2;
+    *reinterpret_cast<uint2 *>(d) = hi;
+    *reinterpret_cast<uint2 *>(d + 64) = lo;
+}
+// Saturation is impossible while the bound holds; a producer whose values exceed its bound (a caller's mistake, never silent)
+// bumps this per-translation-unit counter, which rick_saturation_count() sums.
+static __device__ unsigned g_cv_sat;
+__device__ __forceinline__ void cv_sat_check(float thread_amax, float scale) {
+    if (thread_amax * scale >= 65504.f) atomicAdd(&g_cv_sat, 1u);
+}
+// running maximum of a thread -> wave -> one atomic max on the float's bits (values are >= 0)
+__device__ __forceinline__ void cv_amax_publish(float m, float *word) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(word), __float_as_uint(m));
+}
+#define CV_DEFINE_SAT_ACCESSOR(fn)                                                                    \
+    extern "C" int fn(unsigned *count, int reset) {                                                   \
+        unsigned *p = nullptr, v = 0, z = 0;                                                          \
+        if (hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_cv_sat)) != hipSuccess) return 1;           \
+        if (hipMemcpy(&v, p, 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;                       \
+        if (reset && hipMemcpy(p, &z, 4, hipMemcpyHostToDevice) != hipSuccess) return 1;              \
+        *count = v;                                                                                   \
+        return 0;                                                                                     \
+    }

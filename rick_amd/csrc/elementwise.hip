@@ -1,7 +1,7 @@
 // HBM-bound kernels of the hot path: fused bias/noise/LeakyReLU (+ one-pass backward with
 // wavefront-shuffle reductions), modulation helpers, ResBlock merge, minibatch-stddev,
 // Fisher grad^2 accumulation, per-filter reduction, masked Adam, EMA.
-#include "common.h"
+#include "conv_common.h"
 
 // ------------------------------------------------------------------------ bias + act (fwd)
 // Semantics: op/fused_bias_act_kernel.cu:18-49 (+ fused NoiseInjection, model_probe_tune.py:293-298)
@@ -105,13 +105,47 @@ extern "C" int rick_bias_act_bwd_blocks(int64_t rows, int C) {
     return (int)nb;
 }
 
-template <bool VEC4>
+// SPL: the adjoint leaves as split images instead of an fp32 tensor (its only consumers are the data- and weight-gradient
+// MFMA kernels): image 1 = the adjoint itself, optional image 2 = g * mul2 (the same incoming gradient on its way into a
+// parallel linear branch — the ResBlock skip path), both with bounds derived from one measured maximum of g.
+struct BabSplit {
+    unsigned char *s1, *s2;
+    cv_split_hdr *h1, *h2;
+    const float *bound;          // max |g| (exact or an upper bound)
+    float coef1, coef2, mul2;
+};
+
+template <bool VEC4, bool SPL = false>
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restrict__ g, const float *__restrict__ ref,
                                                            float *__restrict__ gx, const float *__restrict__ noise,
                                                            float *__restrict__ partials, int64_t rows, int C,
                                                            int64_t rows_per_img, int64_t noise_nb, int64_t noise_hw,
-                                                           float alpha, float scale, int want_gb) {
+                                                           float alpha, float scale, int want_gb, BabSplit sp) {
     extern __shared__ float lds[];   // [256 * (VEC4 ? 4 : 1)] column partials + 4 for block_sum
+    float sc1 = 1.f, sc2 = 1.f, am1 = 0.f, am2 = 0.f;
+    if (SPL) {
+        const cv_split_hdr h1 = cv_split_header(sp.bound, nullptr, sp.coef1);
+        sc1 = cv_uniform(h1.scale);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *sp.h1 = h1;
+        if (sp.s2) {
+            const cv_split_hdr h2 = cv_split_header(sp.bound, nullptr, sp.coef2);
+            sc2 = cv_uniform(h2.scale);
+            if (blockIdx.x == 0 && threadIdx.x == 0) *sp.h2 = h2;
+        }
+    }
+    auto put = [&](float *op, int64_t row, int c, const float4 o, const float4 gv) {
+        if (!SPL) {
+            *reinterpret_cast<float4 *>(op) = o;
+            return;
+        }
+        cv_split_store4(sp.s1 + row * C * 4, c, o, sc1);
+        am1 = amax4(am1, o);
+        if (sp.s2) {
+            const float4 g2 = make_float4(gv.x * sp.mul2, gv.y * sp.mul2, gv.z * sp.mul2, gv.w * sp.mul2);
+            cv_split_store4(sp.s2 + row * C * 4, c, g2, sc2);
+            am2 = amax4(am2, g2);
+        }
+    };
     const int W = VEC4 ? 4 : 1;
     const int ncol = C / W;                       // column groups per row
     const int nb = gridDim.x;
@@ -168,7 +202,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restri
                         o.y = gv[u].y * (rv[u].y > 0.f ? 1.f : alpha) * scale;
                         o.z = gv[u].z * (rv[u].z > 0.f ? 1.f : alpha) * scale;
                         o.w = gv[u].w * (rv[u].w > 0.f ? 1.f : alpha) * scale;
-                        *reinterpret_cast<float4 *>(op + u * step) = o;
+                        put(op + u * step, r + (int64_t)u * rpb, (cbase + lane_c) * 4, o, gv[u]);
                         acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
                         nsum += (o.x + o.y + o.z + o.w) * nv[u];
                     }
@@ -197,7 +231,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restri
                     o.y = gv.y * (rv.y > 0.f ? 1.f : alpha) * scale;
                     o.z = gv.z * (rv.z > 0.f ? 1.f : alpha) * scale;
                     o.w = gv.w * (rv.w > 0.f ? 1.f : alpha) * scale;
-                    *reinterpret_cast<float4 *>(op) = o;
+                    put(op, r, (cbase + lane_c) * 4, o, gv);
                     acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
                     nsum += (o.x + o.y + o.z + o.w) * nv;
                 } else {
@@ -228,6 +262,10 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restri
     if (noise) {
         const float tot = block_sum_256(nsum, lds + 256 * W);
         if (threadIdx.x == 0) pb[C] = tot;
+    }
+    if (SPL) {
+        cv_sat_check(am1, sc1);
+        cv_sat_check(am2, sc2);
     }
 }
 
@@ -291,10 +329,38 @@ static void launch_colsum(const float *partials, float *out, int nb, int stride,
                            col0, o);
 }
 
+static int bias_act_bwd_run(const float *g, const float *ref, float *gx, float *gb, float *gnw,
+                            const float *noise, int64_t rows, int C, int64_t rows_per_img,
+                            int64_t noise_nb, int64_t noise_hw, float alpha, float scale,
+                            float *partials, int accumulate, void *stream, const BabSplit *sp);
+
 extern "C" int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx, float *gb, float *gnw,
                                      const float *noise, int64_t rows, int C, int64_t rows_per_img,
                                      int64_t noise_nb, int64_t noise_hw, float alpha, float scale,
                                      float *partials, int accumulate, void *stream) {
+    return bias_act_bwd_run(g, ref, gx, gb, gnw, noise, rows, C, rows_per_img, noise_nb, noise_hw, alpha, scale, partials,
+                            accumulate, stream, nullptr);
+}
+
+// The activation adjoint written as split images: out1 = g * (ref > 0 ? 1 : alpha) * scale (bound |scale| * *amax_g) and,
+// when out2 != NULL, out2 = g * mul2 (bound |mul2| * *amax_g).  C % 32 == 0; gb / gnw as in rick_bias_act_bwd_f32.
+extern "C" int rick_bias_act_bwd_split_f32(const float *g, const float *ref, void *out1, float *hdr1, void *out2, float *hdr2,
+                                           float mul2, const float *amax_g, float *gb, float *gnw, const float *noise,
+                                           int64_t rows, int C, int64_t rows_per_img, int64_t noise_nb, int64_t noise_hw,
+                                           float alpha, float scale, float *partials, int accumulate, void *stream) {
+    if (!out1 || !hdr1 || !amax_g || (C & 31) || (out2 && (!hdr2 || mul2 == 0.f)) || scale == 0.f) return RICK_EINVAL;
+    if (((uintptr_t)out1 | (uintptr_t)(out2 ? out2 : out1) | (uintptr_t)g | (uintptr_t)ref) % 16) return RICK_EINVAL;
+    const float slope = fabsf(alpha) > 1.f ? fabsf(alpha) : 1.f;
+    const BabSplit sp = {(unsigned char *)out1, (unsigned char *)out2, (cv_split_hdr *)hdr1, (cv_split_hdr *)hdr2, amax_g,
+                         fabsf(scale) * slope, fabsf(mul2), mul2};
+    return bias_act_bwd_run(g, ref, (float *)out1, gb, gnw, noise, rows, C, rows_per_img, noise_nb, noise_hw, alpha, scale,
+                            partials, accumulate, stream, &sp);
+}
+
+static int bias_act_bwd_run(const float *g, const float *ref, float *gx, float *gb, float *gnw,
+                            const float *noise, int64_t rows, int C, int64_t rows_per_img,
+                            int64_t noise_nb, int64_t noise_hw, float alpha, float scale,
+                            float *partials, int accumulate, void *stream, const BabSplit *sp) {
     if (!g || !ref || !gx || rows <= 0 || C <= 0 || ((gb || gnw) && !partials)) return RICK_EINVAL;
     if (gnw && !noise) return RICK_EINVAL;
     if (noise && (rows_per_img <= 0 || noise_nb <= 0 || noise_hw != rows_per_img)) return RICK_EINVAL;
@@ -303,12 +369,18 @@ extern "C" int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx
     const bool vec = (C % 4 == 0) && (((uintptr_t)g | (uintptr_t)ref | (uintptr_t)gx) % 16 == 0);
     const size_t lds = (256 * 4 + 8) * sizeof(float);
     const float *nz = gnw ? noise : nullptr;
-    if (vec)
-        hipLaunchKernelGGL(bias_act_bwd_kernel<true>, dim3(nb), dim3(256), lds, st, g, ref, gx, nz, partials, rows, C,
-                           rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0);
+    const BabSplit none = {nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f, 1.f};
+    if (sp && vec)
+        hipLaunchKernelGGL((bias_act_bwd_kernel<true, true>), dim3(nb), dim3(256), lds, st, g, ref, gx, nz, partials, rows, C,
+                           rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0, *sp);
+    else if (sp)
+        return RICK_EINVAL;
+    else if (vec)
+        hipLaunchKernelGGL((bias_act_bwd_kernel<true, false>), dim3(nb), dim3(256), lds, st, g, ref, gx, nz, partials, rows, C,
+                           rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0, none);
     else
-        hipLaunchKernelGGL(bias_act_bwd_kernel<false>, dim3(nb), dim3(256), lds, st, g, ref, gx, nz, partials, rows, C,
-                           rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0);
+        hipLaunchKernelGGL((bias_act_bwd_kernel<false, false>), dim3(nb), dim3(256), lds, st, g, ref, gx, nz, partials, rows, C,
+                           rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0, none);
     // one second-stage launch for both parameter gradients; accumulate: gb / gnw are the parameters' .grad (gradient sink)
     if (gb && gnw) launch_colsum(partials, gb, nb, C + 1, C + 1, 0, st, nullptr, accumulate, gnw, C);
     else if (gb) launch_colsum(partials, gb, nb, C + 1, C, 0, st, nullptr, accumulate);
@@ -523,6 +595,43 @@ __global__ __launch_bounds__(256) void add_scale_kernel(const float *__restrict_
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
         y[i] = (a[i] + (b ? b[i] : 0.f)) * alpha;
 }
+
+// y = (a + b) * alpha as fp32 AND as a split image (the ResBlock merge feeds the next block's convolutions), bound
+// |alpha| * (*amax_a + *amax_b).  Rows of C channels, C % 32 == 0.
+__global__ __launch_bounds__(256) void add_scale_split_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                              float *__restrict__ y, unsigned char *__restrict__ sy,
+                                                              cv_split_hdr *__restrict__ hdr, const float *__restrict__ ba,
+                                                              const float *__restrict__ bb, float coef, int64_t n4, int C4,
+                                                              float alpha) {
+    const cv_split_hdr h = cv_split_header(ba, bb, coef);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *hdr = h;
+    const float sc = cv_uniform(h.scale);
+    float am = 0.f;
+    for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += (int64_t)gridDim.x * 256) {
+        float4 av = reinterpret_cast<const float4 *>(a)[i4];
+        const float4 bv = reinterpret_cast<const float4 *>(b)[i4];
+        av.x += bv.x; av.y += bv.y; av.z += bv.z; av.w += bv.w;
+        const float4 o = make_float4(av.x * alpha, av.y * alpha, av.z * alpha, av.w * alpha);
+        reinterpret_cast<float4 *>(y)[i4] = o;
+        const int64_t row = i4 / C4;
+        cv_split_store4(sy + row * C4 * 16, (int)(i4 - row * C4) * 4, o, sc);
+        am = amax4(am, o);
+    }
+    cv_sat_check(am, sc);
+}
+
+extern "C" int rick_add_scale_split_f32(const float *a, const float *b, float *y, void *y_split, float *hdr,
+                                        const float *amax_a, const float *amax_b, int64_t rows, int C, float alpha, void *stream) {
+    if (!a || !b || !y || !y_split || !hdr || !amax_a || !amax_b || rows < 0 || C <= 0 || (C & 31) || alpha == 0.f) return RICK_EINVAL;
+    if (rows == 0) return 0;
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)y | (uintptr_t)y_split | (uintptr_t)hdr) % 16 != 0) return RICK_EINVAL;
+    const int64_t n4 = rows * (C / 4);
+    hipLaunchKernelGGL(add_scale_split_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, a, b, y,
+                       (unsigned char *)y_split, (cv_split_hdr *)hdr, amax_a, amax_b, fabsf(alpha), n4, C / 4, alpha);
+    RICK_LAUNCH_STATUS();
+}
+
+CV_DEFINE_SAT_ACCESSOR(rick_sat_elementwise)
 
 extern "C" int rick_add_scale_f32(const float *a, const float *b, float *y, int64_t n, float alpha, void *stream) {
     if (!a || !y || n < 0) return RICK_EINVAL;

@@ -26,21 +26,10 @@ extern "C" int rick_amax_f32(const float *x, int64_t n, float *amax_word, void *
     RICK_LAUNCH_STATUS();
 }
 
-// bound = coef * (*a0 + *a1) -> header.  Every producer of a split image evaluates this itself (block-uniform scalar work)
-// and block 0 publishes the header for the consumers.
-__device__ __forceinline__ cv_split_hdr split_header(const float *a0, const float *a1, float coef) {
-    cv_split_hdr h;
-    h.bound = coef * (a0[0] + (a1 ? a1[0] : 0.f));
-    cv_pow2_scale_t<CV_SPLIT_TARGET>(h.bound, h.scale, h.unscale);
-    h.pad = 0.f;
-    return h;
-}
-
 __global__ __launch_bounds__(256) void split_pack_kernel(const float *__restrict__ x, unsigned char *__restrict__ out,
                                                          cv_split_hdr *__restrict__ hdr, const float *__restrict__ a0,
-                                                         const float *__restrict__ a1, float coef, int64_t total8, int C8,
-                                                         unsigned *__restrict__ sat) {
-    const cv_split_hdr h = split_header(a0, a1, coef);
+                                                         const float *__restrict__ a1, float coef, int64_t total8, int C8) {
+    const cv_split_hdr h = cv_split_header(a0, a1, coef);
     if (blockIdx.x == 0 && threadIdx.x == 0) *hdr = h;
     const float s = cv_uniform(h.scale);
     float m = 0.f;
@@ -57,7 +46,7 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float *__restrict
         *reinterpret_cast<uint4 *>(dst + 64) = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
     // a value above the bound means the caller's bound was no bound: counted, never silent (rick_split_saturation_count)
-    if (m * s >= 65504.f) atomicAdd(sat, 1u);
+    cv_sat_check(m, s);
 }
 
 __global__ __launch_bounds__(256) void split_unpack_kernel(const unsigned char *__restrict__ pk, const cv_split_hdr *__restrict__ hdr,
@@ -76,7 +65,17 @@ __global__ __launch_bounds__(256) void split_unpack_kernel(const unsigned char *
     }
 }
 
-static __device__ unsigned g_split_sat;     // values that reached the fp16 maximum in a split-image producer of this file
+CV_DEFINE_SAT_ACCESSOR(rick_sat_split)
+extern "C" int rick_sat_upfirdn2d(unsigned *, int);
+extern "C" int rick_sat_elementwise(unsigned *, int);
+
+extern "C" int rick_saturation_count(unsigned *count, int reset) {
+    if (!count) return RICK_EINVAL;
+    unsigned a = 0, b = 0, c = 0;
+    if (rick_sat_split(&a, reset) || rick_sat_upfirdn2d(&b, reset) || rick_sat_elementwise(&c, reset)) return 1;
+    *count = a + b + c;
+    return 0;
+}
 
 extern "C" int rick_split_pack_f32(const float *x, void *out, float *hdr, const float *amax0, const float *amax1, float coef,
                                    int64_t npix, int C, void *stream) {
@@ -86,10 +85,8 @@ extern "C" int rick_split_pack_f32(const float *x, void *out, float *hdr, const 
     const int64_t total8 = npix * (C / 8);
     int64_t nb = cdiv64(total8, 256 * 4);
     nb = nb < 1 ? 1 : (nb > 8192 ? 8192 : nb);
-    unsigned *sat;
-    if (hipGetSymbolAddress((void **)&sat, HIP_SYMBOL(g_split_sat)) != hipSuccess) return RICK_EINVAL;
     hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, (unsigned char *)out,
-                       (cv_split_hdr *)hdr, amax0, amax1, coef, total8, C / 8, sat);
+                       (cv_split_hdr *)hdr, amax0, amax1, coef, total8, C / 8);
     RICK_LAUNCH_STATUS();
 }
 

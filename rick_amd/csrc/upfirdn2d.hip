@@ -11,7 +11,7 @@
 // Two kernels, both LDS-staged with coalesced HBM reads:
 //   planar  (minor == 1, e.g. the RGB skip path): 16x64 output tile per 256-thread block
 //   nhwc    (minor % 4 == 0): 64-channel slab x TOHxTOW pixel tile, float4 per lane
-#include "common.h"
+#include "conv_common.h"
 #include <stdlib.h>
 
 struct UfdParams {
@@ -73,10 +73,36 @@ __global__ __launch_bounds__(256) void upfirdn2d_planar_kernel(const float *__re
 
 // ------------------------------------------------------------------------------- NHWC
 // blockIdx.x: pixel tile, blockIdx.y: 64-channel slab, blockIdx.z: image.
+// XO: extended result handling (rick_split_out): add into `out`, fold max |result| into a word, write a split image.
+static const rick_split_out kNoSplitOut = {nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, 0, 0};
+
+template <bool XO>
+__device__ __forceinline__ void ufd_store(float *dst, unsigned char *spix, int c, float4 v, const rick_split_out &xo, float sscale,
+                                          float &am) {
+    if (!XO) {
+        *reinterpret_cast<float4 *>(dst) = v;
+        return;
+    }
+    if (xo.accumulate) {
+        const float4 o = *reinterpret_cast<const float4 *>(dst);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    am = amax4(am, v);
+    if (!xo.no_f32) *reinterpret_cast<float4 *>(dst) = v;
+    if (xo.split_out) cv_split_store4(spix, c, v, sscale);
+}
+
+template <bool XO>
 __global__ __launch_bounds__(256) void upfirdn2d_nhwc_kernel(const float *__restrict__ in,
                                                              const float *__restrict__ kern,
-                                                             float *__restrict__ out, UfdParams p, int cb4) {
+                                                             float *__restrict__ out, UfdParams p, int cb4, rick_split_out xo) {
     extern __shared__ float smem[];
+    float sscale = 1.f, am = 0.f;
+    if (XO && xo.split_out) {
+        const cv_split_hdr h = cv_split_header(xo.bound0, xo.bound1, xo.bound_coef);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *reinterpret_cast<cv_split_hdr *>(xo.split_hdr) = h;
+        sscale = cv_uniform(h.scale);
+    }
     float *sk = smem;                                            // [kh*kw] (padded to x4)
     float4 *sx = reinterpret_cast<float4 *>(smem + ((p.kh * p.kw + 3) & ~3));   // [tih][tiw][cb4]
     const int tile_x = blockIdx.x % p.tiles_x, tile_y = blockIdx.x / p.tiles_x;
@@ -100,7 +126,6 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_kernel(const float *__rest
     }
     __syncthreads();
 
-    float *dst = out + n * (int64_t)p.out_h * p.out_w * p.minor + c0;
     const int nout = p.toh * p.tow * cb4;
     for (int i = threadIdx.x; i < nout; i += 256) {
         const int c4 = i % cb4, pix = i / cb4;
@@ -129,7 +154,12 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_kernel(const float *__rest
             }
             xr += p.tiw * cb4;
         }
-        *reinterpret_cast<float4 *>(dst + ((int64_t)oy * p.out_w + ox) * p.minor + c4 * 4) = v;
+        const int64_t po = n * (int64_t)p.out_h * p.out_w + (int64_t)oy * p.out_w + ox;
+        ufd_store<XO>(out + po * p.minor + c0 + c4 * 4, (unsigned char *)xo.split_out + po * p.minor * 4, c0 + c4 * 4, v, xo, sscale, am);
+    }
+    if (XO) {
+        if (xo.amax) cv_amax_publish(am, xo.amax);
+        if (xo.split_out) cv_sat_check(am, sscale);
     }
 }
 
@@ -138,13 +168,19 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_kernel(const float *__rest
 // decimation are all 4x4 kernels with up == 1 and down in {1, 2} on >= 64 channels.  Compile-time tile,
 // tap count and strides: 16 unrolled fmaf per output float4, y-outer / x-inner exactly like the generic
 // kernel and the C oracle (bit-identical results).
-template <int DOWN, int TOH, int TOW, bool TAIL>
+template <int DOWN, int TOH, int TOW, bool TAIL, bool XO = false>
 __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__restrict__ in,
                                                                 const float *__restrict__ kern,
                                                                 float *__restrict__ out, UfdParams p,
-                                                                rick_conv_epilogue tail) {
+                                                                rick_conv_epilogue tail, rick_split_out xo) {
     constexpr int TIH = (TOH - 1) * DOWN + 4, TIW = (TOW - 1) * DOWN + 4, CB4 = 16;
     __shared__ float4 sx[TIH * TIW * CB4];
+    float sscale = 1.f, am = 0.f;
+    if (XO && xo.split_out) {
+        const cv_split_hdr h = cv_split_header(xo.bound0, xo.bound1, xo.bound_coef);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *reinterpret_cast<cv_split_hdr *>(xo.split_hdr) = h;
+        sscale = cv_uniform(h.scale);
+    }
     // blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of tiles (row-major), so the
     // halo rows / columns that neighbouring tiles share are re-read from the same L2 (placement only)
     int tile = blockIdx.x;
@@ -179,7 +215,6 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
         if (pix < TIH * TIW) sx[pix * CB4 + c4] = ((okm >> k) & 1u) ? stage[k] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    float *dst = out + n * (int64_t)p.out_h * p.out_w * p.minor + c0;
 #pragma unroll
     for (int j = 0; j < TOH * TOW / 16; j++) {
         const int pix = (threadIdx.x >> 4) + 16 * j;
@@ -216,8 +251,13 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
                     v.w = (v.w > 0.f ? v.w : v.w * tail.slope) * tail.gain;
                 }
             }
-            *reinterpret_cast<float4 *>(dst + ((int64_t)oy * p.out_w + ox) * p.minor + c4 * 4) = v;
+            const int64_t po = n * (int64_t)p.out_h * p.out_w + (int64_t)oy * p.out_w + ox;
+            ufd_store<XO>(out + po * p.minor + c0 + c4 * 4, (unsigned char *)xo.split_out + po * p.minor * 4, c0 + c4 * 4, v, xo, sscale, am);
         }
+    }
+    if (XO) {
+        if (xo.amax) cv_amax_publish(am, xo.amax);
+        if (xo.split_out) cv_sat_check(am, sscale);
     }
 }
 
@@ -228,7 +268,7 @@ static int tile_in_extent(int tile_out, int down, int k, int up) {
 
 static int upfirdn2d_impl(const float *input, const float *kernel, float *out, int64_t major, int in_h, int in_w, int minor,
                           int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
-                          int pad_y1, const rick_conv_epilogue *tail, void *stream);
+                          int pad_y1, const rick_conv_epilogue *tail, void *stream, const rick_split_out *xo = nullptr);
 
 extern "C" int rick_upfirdn2d_f32(const float *input, const float *kernel, float *out,
                                   int64_t major, int in_h, int in_w, int minor, int kh, int kw,
@@ -248,9 +288,24 @@ extern "C" int rick_upfirdn2d_act_f32(const float *input, const float *kernel, f
                           pad_y0, pad_y1, tail, stream);
 }
 
+// The same FIR with the extended result handling (split image / accumulate / running maximum): channels-last, minor % 64 == 0
+// for the 4x4 up = 1 form, minor % 4 == 0 for the generic one (split images need minor % 32 == 0).
+extern "C" int rick_upfirdn2d_ex_f32(const float *input, const float *kernel, float *out,
+                                     int64_t major, int in_h, int in_w, int minor, int kh, int kw,
+                                     int up_x, int up_y, int down_x, int down_y,
+                                     int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                     const rick_conv_epilogue *tail, const rick_split_out *ex, void *stream) {
+    if (!ex || (minor & 3)) return RICK_EINVAL;
+    if (ex->split_out && (!ex->split_hdr || !ex->bound0 || (minor & 31) || !(ex->bound_coef > 0.f) || ((uintptr_t)ex->split_out % 16)))
+        return RICK_EINVAL;
+    if (!out && !(ex->no_f32 && !ex->accumulate)) return RICK_EINVAL;
+    return upfirdn2d_impl(input, kernel, out ? out : (float *)ex->split_out, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x,
+                          down_y, pad_x0, pad_x1, pad_y0, pad_y1, tail, stream, ex);
+}
+
 static int upfirdn2d_impl(const float *input, const float *kernel, float *out, int64_t major, int in_h, int in_w, int minor,
                           int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
-                          int pad_y1, const rick_conv_epilogue *tail, void *stream) {
+                          int pad_y1, const rick_conv_epilogue *tail, void *stream, const rick_split_out *xo) {
     if (!input || !kernel || !out || major <= 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kh <= 0 ||
         kw <= 0 || up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0)
         return RICK_EINVAL;
@@ -264,7 +319,7 @@ static int upfirdn2d_impl(const float *input, const float *kernel, float *out, i
     hipStream_t st = (hipStream_t)stream;
     if (minor % 64 == 0 && kh == 4 && kw == 4 && up_x == 1 && up_y == 1 && down_x == down_y && (down_x == 1 || down_x == 2) &&
         major <= 65535 && minor / 64 <= 65535 && (((uintptr_t)input | (uintptr_t)out) % 16 == 0)) {
-        const rick_conv_epilogue none = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f};
+        const rick_conv_epilogue none = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f, nullptr};
         if (tail) {
             if (tail->noise && (!tail->noise_w || (tail->noise_nb != 1 && tail->noise_nb != major))) return RICK_EINVAL;
             if (tail->bias && ((uintptr_t)tail->bias % 16)) return RICK_EINVAL;
@@ -272,13 +327,17 @@ static int upfirdn2d_impl(const float *input, const float *kernel, float *out, i
         if (down_x == 1) {
             p.tiles_x = cdiv(p.out_w, 8);
             dim3 grid(p.tiles_x * cdiv(p.out_h, 8), minor / 64, (unsigned)major);
-            if (tail) hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<1, 8, 8, true>), grid, dim3(256), 0, st, input, kernel, out, p, *tail);
-            else hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<1, 8, 8, false>), grid, dim3(256), 0, st, input, kernel, out, p, none);
+            if (xo && tail) hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<1, 8, 8, true, true>), grid, dim3(256), 0, st, input, kernel, out, p, *tail, *xo);
+            else if (xo) hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<1, 8, 8, false, true>), grid, dim3(256), 0, st, input, kernel, out, p, none, *xo);
+            else if (tail) hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<1, 8, 8, true>), grid, dim3(256), 0, st, input, kernel, out, p, *tail, kNoSplitOut);
+            else hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<1, 8, 8, false>), grid, dim3(256), 0, st, input, kernel, out, p, none, kNoSplitOut);
         } else {
             p.tiles_x = cdiv(p.out_w, 8);
             dim3 grid(p.tiles_x * cdiv(p.out_h, 4), minor / 64, (unsigned)major);
-            if (tail) hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<2, 4, 8, true>), grid, dim3(256), 0, st, input, kernel, out, p, *tail);
-            else hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<2, 4, 8, false>), grid, dim3(256), 0, st, input, kernel, out, p, none);
+            if (xo && tail) hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<2, 4, 8, true, true>), grid, dim3(256), 0, st, input, kernel, out, p, *tail, *xo);
+            else if (xo) hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<2, 4, 8, false, true>), grid, dim3(256), 0, st, input, kernel, out, p, none, *xo);
+            else if (tail) hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<2, 4, 8, true>), grid, dim3(256), 0, st, input, kernel, out, p, *tail, kNoSplitOut);
+            else hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<2, 4, 8, false>), grid, dim3(256), 0, st, input, kernel, out, p, none, kNoSplitOut);
         }
         RICK_LAUNCH_STATUS();
     }
@@ -297,13 +356,15 @@ static int upfirdn2d_impl(const float *input, const float *kernel, float *out, i
                 p.tiles_x = cdiv(p.out_w, tow);
                 if (major > 65535 || minor / (cb4 * 4) > 65535) return RICK_EINVAL;
                 dim3 grid(p.tiles_x * cdiv(p.out_h, toh), minor / (cb4 * 4), (unsigned)major);
-                hipLaunchKernelGGL(upfirdn2d_nhwc_kernel, grid, dim3(256), lds, st, input, kernel, out, p, cb4);
+                if (xo) hipLaunchKernelGGL(upfirdn2d_nhwc_kernel<true>, grid, dim3(256), lds, st, input, kernel, out, p, cb4, *xo);
+                else hipLaunchKernelGGL(upfirdn2d_nhwc_kernel<false>, grid, dim3(256), lds, st, input, kernel, out, p, cb4, kNoSplitOut);
                 RICK_LAUNCH_STATUS();
             }
             if (toh >= tow && toh > 1) toh >>= 1; else tow >>= 1;
         }
     }
 planar_like:
+    if (xo) return RICK_EINVAL;           // the extended result handling exists on the channels-last kernels only
     if (minor != 1) return RICK_EINVAL;   // callers re-layout to planar or channels-last x4
     {
         int toh = 16, tow = 64;
@@ -335,3 +396,5 @@ planar_like:
         }
     }
 }
+
+CV_DEFINE_SAT_ACCESSOR(rick_sat_upfirdn2d)

@@ -24,6 +24,7 @@ from .op.fused_act import FusedLeakyReLU, fused_leaky_relu, fused_noise_bias_act
 from .op.upfirdn2d import upfirdn2d
 
 CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512}
+_USE_DBLOCK = True      # tests / tools switch the one-node split-image ResBlock (op/dblock.py) off to compare with the per-layer path
 
 
 def _channels(res, channel_multiplier):
@@ -491,12 +492,55 @@ class ResBlock(nn.Module):
         y = upfirdn2d(x, blur.kernel, up=1, down=2, pad=blur.pad)
         return op.conv2d(y, conv.weight, 1, 0, wscale=conv.scale, key=(conv.weight, 'w'))
 
-    def forward(self, x, feat=None):
+    def _per_layer(self, x):
         t1 = self.conv1(x)
         t2 = self.conv2(t1)
+        return op.add_scale(t2, self._skip(x), 1 / math.sqrt(2)), t1, t2
+
+    def _fused_cfg(self):
+        """Arguments of the one-node, split-image form of the block (op/dblock.py), or None when the block is not the
+        reference's standard shape (3x3 -> blur + 3x3 stride 2, blur + 1x1 stride 2 skip, one shared 4x4 FIR).  Built per
+        call from the live modules (a cached tuple would keep pointing at the parameters of a module this one was copied
+        from); only the shape test is cached."""
+        c1, c2, sk = list(self.conv1), list(self.conv2), list(self.skip)
+        std = self.__dict__.get('_dblock_std')
+        if std is None:
+            std = (len(c1) == 2 and len(c2) == 3 and len(sk) == 2 and isinstance(c2[0], _Fir) and isinstance(sk[0], _Fir)
+                   and isinstance(c1[1], FusedLeakyReLU) and isinstance(c2[2], FusedLeakyReLU) and c2[1].stride == 2
+                   and sk[1].stride == 2 and sk[1].bias is None and c1[0].bias is None and c2[1].bias is None
+                   and tuple(c2[0].kernel.shape) == (4, 4) and c2[0].up == c2[0].down == 1 and sk[0].up == sk[0].down == 1
+                   and c1[1].negative_slope == c2[2].negative_slope and c1[1].scale == c2[2].scale
+                   and bool(torch.equal(c2[0].kernel, sk[0].kernel)) and bool((c2[0].kernel >= 0).all())
+                   and abs(float(c2[0].kernel.sum()) - 1.0) < 1e-5)      # (the blur's bound is its input's maximum)
+            self.__dict__['_dblock_std'] = std
+        if not std:
+            return None
+
+        def compose(x_, w1_, b1_, w2_, b2_, ws_):      # the same block from the twice-differentiable per-layer ops
+            t1 = op.conv2d_bias_act(x_, w1_, b1_, 1, 1, wscale=c1[0].scale, key=(c1[0].weight, 'w'),
+                                    negative_slope=c1[1].negative_slope, gain=c1[1].scale)
+            t2 = op.conv2d_bias_act(c2[0](t1), w2_, b2_, 2, 0, wscale=c2[1].scale, key=(c2[1].weight, 'w'),
+                                    negative_slope=c2[2].negative_slope, gain=c2[2].scale)
+            y = upfirdn2d(x_, sk[0].kernel, up=1, down=2, pad=sk[0].pad)
+            s_ = op.conv2d(y, ws_, 1, 0, wscale=sk[1].scale, key=(sk[1].weight, 'w'))
+            return op.add_scale(t2, s_, 1 / math.sqrt(2)), t1, t2
+        return (c1[0].scale, c2[1].scale, sk[1].scale, c1[1].negative_slope, c1[1].scale, c2[0].pad, sk[0].pad,
+                c1[0].weight, c2[1].weight, sk[1].weight, compose)
+
+    def forward(self, x, feat=None):
+        from .op import dblock
+        cfg = None
+        if (x.is_cuda and x.dtype == torch.float32 and not op.second_order_enabled() and op.get_precision() == 'fp16x3' and _USE_DBLOCK
+                and dblock.block_supported(x, self.conv1[0].weight, self.conv2[-2].weight, self.skip[-1].weight)):
+            cfg = self._fused_cfg()
+        if cfg is not None:
+            out, t1, t2 = dblock.d_resblock(x, self.conv1[0].weight, self.conv1[1].bias, self.conv2[1].weight, self.conv2[2].bias,
+                                            self.skip[1].weight, self.conv2[0].kernel, cfg)
+        else:
+            out, t1, t2 = self._per_layer(x)
         if feat is not None:
             feat += [t1, t2]
-        return op.add_scale(t2, self._skip(x), 1 / math.sqrt(2))
+        return out
 
 
 class Discriminator(nn.Module, _FisherMixin):
