@@ -204,12 +204,16 @@ int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw,
  * Split images — activations / gradients stored pre-split for the MFMA kernels (no counterpart in the reference: its
  * convolutions are cuDNN's, model_probe_tune.py:122,265,274,280; this is how the fp16x3 arithmetic of this build avoids
  * converting the same fp32 operand once per co-tile block, again in dgrad and again in wgrad).
- * A split image of an NHWC fp32 tensor [npix, C] (C % 32 == 0) has the same byte size and pixel pitch; the 128 bytes of a
- * pixel's 32-channel chunk hold [hi: 32 x fp16][lo: 32 x fp16], hi = fp16(v * 2^e), lo = fp16(v * 2^e - hi), with ONE
+ * A split image of an NHWC fp32 tensor [npix, C] (C % 4 == 0) has the same byte size and addressing; the 16 bytes of
+ * channels c .. c+3 hold {hi x 4 | lo x 4} as fp16, hi = fp16(v * 2^e), lo = fp16(v * 2^e - hi), with ONE
  * exponent per tensor in a 16-byte device header {2^e, 2^-e, bound, 0}.  The exponent comes from a guaranteed bound
  * coef * (*amax0 + *amax1) on |v| (amax1 may be NULL), placed in [2^13, 2^14): nothing can saturate, and values down to
- * 2^-10 of the bound keep 2^-22 relative precision.  rick_amax_f32 folds max |x| into *amax_word with an atomic max
- * (callers zero the word first); the kernels that produce activations measure the same maximum in their epilogues. */
+ * 2^-10 of the bound keep 2^-22 relative precision.  A RUNNING MAXIMUM ("amax word": every `amax`, `amax0`, `bound0` ...
+ * pointer below) is RICK_AMAX_FLOATS floats: RICK_AMAX_SLOTS slots, one per 128-byte line, the value being the maximum over
+ * the slots (thousands of blocks folding into one address serialise in the L2).  Callers zero the word; rick_amax_f32 folds
+ * max |x| into it with atomic max, the kernels that produce activations do the same in their epilogues. */
+#define RICK_AMAX_SLOTS 16
+#define RICK_AMAX_FLOATS (16 * 32)
 int rick_amax_f32(const float *x, int64_t n, float *amax_word, void *stream);
 /* What a producer kernel does with its result besides (or instead of) the fp32 store. */
 typedef struct {

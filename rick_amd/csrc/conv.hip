@@ -218,7 +218,7 @@ __device__ __forceinline__ void cv_lds_barrier() {   // raw barrier: no vmcnt(0)
 }
 
 // PKX: the input is a split image (conv_common.h): `iscale` points at its header {2^e, 2^-e, ..}, per-channel input scales
-// are already folded in by the producer, a staging item is one 16-byte granule of 8 channels (hi or lo) copied to LDS as it is.
+// are already folded in by the producer, a staging item is the 16 bytes {hi x 4 | lo x 4} of 4 channels, copied to LDS as it is.
 template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, int WDMA = 0, bool PKX = false>
 __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const unsigned char *__restrict__ wpk,
                                            float *__restrict__ out, const float *__restrict__ iscale,
@@ -317,8 +317,6 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         p_sc[k] = 0;
         // items past the patch land in a spare row behind it, so the LDS writes need no guard
         p_lds[k] = (pix < t.NPP ? pix : t.NPP) * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
-        if constexpr (PKX)   // granule c4 of the chunk's 128 bytes: hi / lo plane = bit 2, k-group = c4 & 3
-            p_lds[k] = (c4 >> 2) * (t.NPP + 1) * 64 + (pix < t.NPP ? pix : t.NPP) * 64 + cv_swz(c4 & 3, pix) * 16;
         if (pix < t.NPP) {
             const unsigned e = ptab[pix];
             const int nbi = (int)(e >> 20), py = (int)((e >> 10) & 1023), px = (int)(e & 1023);
@@ -350,8 +348,10 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         auto items = [&](auto ISC) {
 #pragma unroll
             for (int k = 0; k < PSET; k++) {
-                if constexpr (PKX) {
-                    *reinterpret_cast<float4 *>(ph + p_lds[k]) = pq[S * PSET + k];
+                if constexpr (PKX) {      // the item already IS {hi x 4 | lo x 4}
+                    const float4 pv = pq[S * PSET + k];
+                    *reinterpret_cast<float2 *>(ph + p_lds[k]) = make_float2(pv.x, pv.y);
+                    *reinterpret_cast<float2 *>(pl + p_lds[k]) = make_float2(pv.z, pv.w);
                     continue;
                 }
                 const bool ok = (cur_ok[S] >> k) & 1u;
@@ -787,7 +787,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     else if (oscale) epilogue(std::true_type{}, std::false_type{});
     else if (has_ep) epilogue(std::false_type{}, std::true_type{});
     else epilogue(std::false_type{}, std::false_type{});
-    if (epi.amax && t.nsplit == 1) cv_amax_publish(out_amax, epi.amax);     // (split-K: the second stage measures)
+    if (epi.amax && t.nsplit == 1) cv_amax_publish(out_amax, epi.amax, reinterpret_cast<float *>(smem));     // (split-K: the second stage measures)
 }
 
 template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, int WDMA = 0, bool PKX = false>
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_multi_kernel(const float *_
 // out[n, pix(gy,gx), co] = alpha * oscale[n,co] * sum_s ws[s][n,gy,gx][co]
 // VEC4 (Co % 4 == 0): one float4 of 4 consecutive channels per thread and split, 32-bit index math (the guard in
 // check_geom keeps N*OH*OW*Co below 2^31).
-template <bool VEC4>
+template <bool VEC4, bool AMAX = false>
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
                                                                   const float *__restrict__ oscale, rick_conv_geom g,
                                                                   int nsplit, rick_conv_epilogue epi) {
@@ -884,17 +884,20 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float *_
                 v.w = (v.w > 0.f ? v.w : v.w * epi.slope) * epi.gain;
             }
             *reinterpret_cast<float4 *>(out + o) = v;
-            ram = amax4(ram, v);
+            if (AMAX) ram = amax4(ram, v);
         } else {
             float s = 0.f;
             for (int sp = 0; sp < nsplit; sp++) s += ws[(size_t)sp * per + iw];
             s *= g.alpha;
             if (oscale) s *= oscale[(size_t)n * g.Co + co];
             out[o] = s;
-            ram = fmaxf(ram, fabsf(s));
+            if (AMAX) ram = fmaxf(ram, fabsf(s));
         }
     }
-    if (epi.amax) cv_amax_publish(ram, epi.amax);
+    if (AMAX) {
+        __shared__ float red[4];
+        cv_amax_publish(ram, epi.amax, red);
+    }
 }
 
 static const rick_conv_epilogue kNoEpilogue = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f, nullptr};
@@ -905,12 +908,12 @@ static void launch_splitk_reduce(const float *ws, float *out, const float *oscal
     const bool vec = (g->Co & 3) == 0 && (((uintptr_t)ws | (uintptr_t)out | (uintptr_t)(oscale ? oscale : out)) % 16) == 0;
     int64_t nb = cdiv64(vec ? per / 4 : per, 256);
     if (nb > 8192) nb = 8192;
-    if (vec) hipLaunchKernelGGL(igemm_splitk_reduce_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, nsplit, epi);
-    else {
-        rick_conv_epilogue e2 = kNoEpilogue;
-        e2.amax = epi.amax;
-        hipLaunchKernelGGL(igemm_splitk_reduce_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, nsplit, e2);
-    }
+    rick_conv_epilogue e2 = kNoEpilogue;
+    e2.amax = epi.amax;
+    if (vec && epi.amax) hipLaunchKernelGGL((igemm_splitk_reduce_kernel<true, true>), dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, nsplit, epi);
+    else if (vec) hipLaunchKernelGGL((igemm_splitk_reduce_kernel<true, false>), dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, nsplit, epi);
+    else if (epi.amax) hipLaunchKernelGGL((igemm_splitk_reduce_kernel<false, true>), dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, nsplit, e2);
+    else hipLaunchKernelGGL((igemm_splitk_reduce_kernel<false, false>), dim3((unsigned)nb), dim3(256), 0, st, ws, out, oscale, *g, nsplit, e2);
 }
 
 

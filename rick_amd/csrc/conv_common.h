@@ -59,9 +59,10 @@ __device__ __forceinline__ void cv_pow2_scale(float amax, float &scale, float &u
 }
 
 // ---- split images (split.hip): an activation / gradient tensor stored pre-split in HBM -------------------------------------
-// A split image of an NHWC fp32 tensor [N, H, W, C] (C % 32 == 0) has the SAME size and pixel pitch: the 128 bytes of a
-// pixel's 32-channel chunk hold [hi: 32 x fp16][lo: 32 x fp16] with hi = fp16(v * 2^e), lo = fp16(v * 2^e - hi) — exactly
-// what the MFMA kernels write into LDS when they split on the fly, so a consumer stages 16-byte granules with no VALU work.
+// A split image of an NHWC fp32 tensor [N, H, W, C] (C % 4 == 0) has the SAME size and addressing: the 16 bytes that hold
+// channels c .. c+3 of a pixel in the fp32 tensor hold {hi x 4 | lo x 4} (8 x fp16) with hi = fp16(v * 2^e),
+// lo = fp16(v * 2^e - hi) — exactly the two 8-byte pieces the MFMA kernels write into LDS when they split on the fly, so a
+// consumer stages its usual 16-byte items with no VALU work, and any kernel that stores float4 can store an image instead.
 // ONE exponent per tensor, kept in a 16-byte device header {2^e, 2^-e, bound, 0}.  The exponent is not sampled: the producer
 // is handed a guaranteed BOUND on |v| (exact running maxima its own producers measured with atomic max, combined by the
 // triangle inequality) and places it in [2^13, 2^14): no value can reach the fp16 maximum, and everything within 2^10 of the
@@ -210,20 +211,29 @@ __device__ __forceinline__ void static_for(F &&f) {   // f(integral_constant<int
 // ---- split-image producers (epilogues of the kernels that write activations / gradients) ---------------------------------
 // header from the producer's bound  coef * (*b0 + *b1)  (b1 may be NULL); every thread evaluates it (block-uniform scalar
 // work), ONE thread of the launch publishes it for the consumers
+// A running maximum is kept in CV_AMAX_SLOTS words, one per 128-byte line (the launch's blocks are dealt over the slots):
+// same-address atomics serialise in the L2 at ~70 ns each, which turned a launch of 16 K blocks folding into ONE word into a
+// millisecond.  Readers take the maximum over the slots.
+#define CV_AMAX_SLOTS 16
+#define CV_AMAX_STRIDE 32
+__device__ __forceinline__ float cv_amax_read(const float *w) {
+    float m = w[0];
+#pragma unroll
+    for (int s = 1; s < CV_AMAX_SLOTS; s++) m = fmaxf(m, w[s * CV_AMAX_STRIDE]);
+    return m;
+}
 __device__ __forceinline__ cv_split_hdr cv_split_header(const float *b0, const float *b1, float coef) {
     cv_split_hdr h;
-    h.bound = coef * (b0[0] + (b1 ? b1[0] : 0.f));
+    h.bound = coef * (cv_amax_read(b0) + (b1 ? cv_amax_read(b1) : 0.f));
     cv_pow2_scale_t<CV_SPLIT_TARGET>(h.bound, h.scale, h.unscale);
     h.pad = 0.f;
     return h;
 }
-// channels c .. c+3 (c % 4 == 0) of the pixel whose first chunk starts at `pixel`:  hi -> 8 bytes, lo -> 8 bytes 64 further
+// channels c .. c+3 (c % 4 == 0) of the pixel that starts at `pixel`: one 16-byte store at the float4's own address
 __device__ __forceinline__ void cv_split_store4(unsigned char *pixel, int c, const float4 v, float s) {
     uint2 hi, lo;
     split4s<2>(v, s, hi, lo);
-    unsigned char *d = pixel + (c >> 5) * 128 + (c & 31) * 2;
-    *reinterpret_cast<uint2 *>(d) = hi;
-    *reinterpret_cast<uint2 *>(d + 64) = lo;
+    *reinterpret_cast<uint4 *>(pixel + c * 4) = make_uint4(hi.x, hi.y, lo.x, lo.y);
 }
 // Saturation is impossible while the bound holds; a producer whose values exceed its bound (a caller's mistake, never silent)
 // bumps this per-translation-unit counter, which rick_saturation_count() sums.
@@ -232,10 +242,24 @@ __device__ __forceinline__ void cv_sat_check(float thread_amax, float scale) {
     if (thread_amax * scale >= 65504.f) atomicAdd(&g_cv_sat, 1u);
 }
 // running maximum of a thread -> wave -> one atomic max on the float's bits (values are >= 0)
-__device__ __forceinline__ void cv_amax_publish(float m, float *word) {
+// The thread first reads the slot (device-scope load: from the L2, where the atomics act) and only issues the atomic when it
+// would raise it.
+// Called by every thread of the block: block maximum through `red` (>= blockDim.x / 64 floats of LDS; a barrier on either
+// side, so it may alias buffers the block is done with), then ONE thread folds it into the block's slot.
+__device__ __forceinline__ void cv_amax_publish(float m, float *word, float *cv_amax_red) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(word), __float_as_uint(m));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) cv_amax_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = ((int)blockDim.x + 63) >> 6;
+        for (int i = 1; i < nw; i++) m = fmaxf(m, cv_amax_red[i]);
+        const unsigned slot = (blockIdx.x + blockIdx.y * 5u + blockIdx.z * 11u) & (CV_AMAX_SLOTS - 1);
+        unsigned *w = reinterpret_cast<unsigned *>(word) + slot * CV_AMAX_STRIDE;
+        const unsigned bits = __float_as_uint(m);
+        if (bits > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(w, bits);
+    }
 }
 #define CV_DEFINE_SAT_ACCESSOR(fn)                                                                    \
     extern "C" int fn(unsigned *count, int reset) {                                                   \

@@ -108,8 +108,7 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     int p_rel[CT_PITEMS];
     unsigned p_ok = 0, p_nbi = 0;                             // validity bits; image-in-tile of each item, 8 bits each
     const int pix0 = threadIdx.x >> 3;
-    const int p_lds0 = PKX ? (c4 >> 2) * pbuf + pix0 * 64 + cv_swz(c4 & 3, pix0) * 16
-                           : pix0 * 64 + cv_swz(c4 >> 1, pix0) * 16 + (c4 & 1) * 8;
+    const int p_lds0 = pix0 * 64 + cv_swz(c4 >> 1, pix0) * 16 + (c4 & 1) * 8;
     const int phw = P.PH * P.PW;
 #pragma unroll
     for (int k = 0; k < CT_PITEMS; k++) {
@@ -152,8 +151,11 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
 #pragma unroll
             for (int k = 0; k < CT_PITEMS; k++) {
                 const float4 v = pq[k];       // (an out-of-range item has read the zero page)
-                if constexpr (PKX) {
-                    if (pix0 + (CT_THREADS / 8) * k < P.NPP) *reinterpret_cast<float4 *>(ph + p_lds0 + k * 4096) = v;
+                if constexpr (PKX) {      // the item already IS {hi x 4 | lo x 4}
+                    if (pix0 + (CT_THREADS / 8) * k < P.NPP) {
+                        *reinterpret_cast<float2 *>(ph + p_lds0 + k * 4096) = make_float2(v.x, v.y);
+                        *reinterpret_cast<float2 *>(pl + p_lds0 + k * 4096) = make_float2(v.z, v.w);
+                    }
                     continue;
                 }
                 uint2 hi, lo;

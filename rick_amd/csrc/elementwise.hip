@@ -348,7 +348,7 @@ extern "C" int rick_bias_act_bwd_split_f32(const float *g, const float *ref, voi
                                            float mul2, const float *amax_g, float *gb, float *gnw, const float *noise,
                                            int64_t rows, int C, int64_t rows_per_img, int64_t noise_nb, int64_t noise_hw,
                                            float alpha, float scale, float *partials, int accumulate, void *stream) {
-    if (!out1 || !hdr1 || !amax_g || (C & 31) || (out2 && (!hdr2 || mul2 == 0.f)) || scale == 0.f) return RICK_EINVAL;
+    if (!out1 || !hdr1 || !amax_g || (C & 3) || (out2 && (!hdr2 || mul2 == 0.f)) || scale == 0.f) return RICK_EINVAL;
     if (((uintptr_t)out1 | (uintptr_t)(out2 ? out2 : out1) | (uintptr_t)g | (uintptr_t)ref) % 16) return RICK_EINVAL;
     const float slope = fabsf(alpha) > 1.f ? fabsf(alpha) : 1.f;
     const BabSplit sp = {(unsigned char *)out1, (unsigned char *)out2, (cv_split_hdr *)hdr1, (cv_split_hdr *)hdr2, amax_g,
@@ -601,8 +601,7 @@ __global__ __launch_bounds__(256) void add_scale_kernel(const float *__restrict_
 __global__ __launch_bounds__(256) void add_scale_split_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                               float *__restrict__ y, unsigned char *__restrict__ sy,
                                                               cv_split_hdr *__restrict__ hdr, const float *__restrict__ ba,
-                                                              const float *__restrict__ bb, float coef, int64_t n4, int C4,
-                                                              float alpha) {
+                                                              const float *__restrict__ bb, float coef, int64_t n4, float alpha) {
     const cv_split_hdr h = cv_split_header(ba, bb, coef);
     if (blockIdx.x == 0 && threadIdx.x == 0) *hdr = h;
     const float sc = cv_uniform(h.scale);
@@ -613,8 +612,7 @@ __global__ __launch_bounds__(256) void add_scale_split_kernel(const float *__res
         av.x += bv.x; av.y += bv.y; av.z += bv.z; av.w += bv.w;
         const float4 o = make_float4(av.x * alpha, av.y * alpha, av.z * alpha, av.w * alpha);
         reinterpret_cast<float4 *>(y)[i4] = o;
-        const int64_t row = i4 / C4;
-        cv_split_store4(sy + row * C4 * 16, (int)(i4 - row * C4) * 4, o, sc);
+        cv_split_store4(sy + i4 * 16, 0, o, sc);
         am = amax4(am, o);
     }
     cv_sat_check(am, sc);
@@ -622,12 +620,12 @@ __global__ __launch_bounds__(256) void add_scale_split_kernel(const float *__res
 
 extern "C" int rick_add_scale_split_f32(const float *a, const float *b, float *y, void *y_split, float *hdr,
                                         const float *amax_a, const float *amax_b, int64_t rows, int C, float alpha, void *stream) {
-    if (!a || !b || !y || !y_split || !hdr || !amax_a || !amax_b || rows < 0 || C <= 0 || (C & 31) || alpha == 0.f) return RICK_EINVAL;
+    if (!a || !b || !y || !y_split || !hdr || !amax_a || !amax_b || rows < 0 || C <= 0 || (C & 3) || alpha == 0.f) return RICK_EINVAL;
     if (rows == 0) return 0;
     if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)y | (uintptr_t)y_split | (uintptr_t)hdr) % 16 != 0) return RICK_EINVAL;
     const int64_t n4 = rows * (C / 4);
     hipLaunchKernelGGL(add_scale_split_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, a, b, y,
-                       (unsigned char *)y_split, (cv_split_hdr *)hdr, amax_a, amax_b, fabsf(alpha), n4, C / 4, alpha);
+                       (unsigned char *)y_split, (cv_split_hdr *)hdr, amax_a, amax_b, fabsf(alpha), n4, alpha);
     RICK_LAUNCH_STATUS();
 }
 

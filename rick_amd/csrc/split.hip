@@ -12,9 +12,8 @@ __global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, 
         m = amax4(m, reinterpret_cast<const float4 *>(x)[i]);
     if (blockIdx.x == 0)
         for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(word), __float_as_uint(m));
+    __shared__ float red[4];
+    cv_amax_publish(m, word, red);
 }
 
 extern "C" int rick_amax_f32(const float *x, int64_t n, float *amax_word, void *stream) {
@@ -28,40 +27,27 @@ extern "C" int rick_amax_f32(const float *x, int64_t n, float *amax_word, void *
 
 __global__ __launch_bounds__(256) void split_pack_kernel(const float *__restrict__ x, unsigned char *__restrict__ out,
                                                          cv_split_hdr *__restrict__ hdr, const float *__restrict__ a0,
-                                                         const float *__restrict__ a1, float coef, int64_t total8, int C8) {
+                                                         const float *__restrict__ a1, float coef, int64_t n4) {
     const cv_split_hdr h = cv_split_header(a0, a1, coef);
     if (blockIdx.x == 0 && threadIdx.x == 0) *hdr = h;
     const float s = cv_uniform(h.scale);
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
-        const float4 v0 = reinterpret_cast<const float4 *>(x)[2 * i], v1 = reinterpret_cast<const float4 *>(x)[2 * i + 1];
-        uint2 h0, l0, h1, l1;
-        split4s<2>(v0, s, h0, l0);
-        split4s<2>(v1, s, h1, l1);
-        m = amax4(amax4(m, v0), v1);
-        const int64_t pix = i / C8;
-        const int g = (int)(i - pix * C8);                     // 8-channel group of the pixel: chunk g >> 2, granule g & 3
-        unsigned char *dst = out + (pix * C8 + (g >> 2) * 4) * 32 + (g & 3) * 16;
-        *reinterpret_cast<uint4 *>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-        *reinterpret_cast<uint4 *>(dst + 64) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        cv_split_store4(out + i * 16, 0, v, s);
+        m = amax4(m, v);
     }
-    // a value above the bound means the caller's bound was no bound: counted, never silent (rick_split_saturation_count)
+    // a value above the bound means the caller's bound was no bound: counted, never silent (rick_saturation_count)
     cv_sat_check(m, s);
 }
 
 __global__ __launch_bounds__(256) void split_unpack_kernel(const unsigned char *__restrict__ pk, const cv_split_hdr *__restrict__ hdr,
-                                                           float *__restrict__ out, int64_t total8, int C8) {
+                                                           float *__restrict__ out, int64_t n4) {
     const float u = hdr->unscale;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
-        const int64_t pix = i / C8;
-        const int g = (int)(i - pix * C8);
-        const unsigned char *src = pk + (pix * C8 + (g >> 2) * 4) * 32 + (g & 3) * 16;
-        const f16x8 hi = *reinterpret_cast<const f16x8 *>(src), lo = *reinterpret_cast<const f16x8 *>(src + 64);
-        float r[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) r[k] = ((float)hi[k] + (float)lo[k]) * u;
-        reinterpret_cast<float4 *>(out)[2 * i] = make_float4(r[0], r[1], r[2], r[3]);
-        reinterpret_cast<float4 *>(out)[2 * i + 1] = make_float4(r[4], r[5], r[6], r[7]);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f16x8 q = *reinterpret_cast<const f16x8 *>(pk + i * 16);
+        reinterpret_cast<float4 *>(out)[i] = make_float4(((float)q[0] + (float)q[4]) * u, ((float)q[1] + (float)q[5]) * u,
+                                                          ((float)q[2] + (float)q[6]) * u, ((float)q[3] + (float)q[7]) * u);
     }
 }
 
@@ -79,25 +65,25 @@ extern "C" int rick_saturation_count(unsigned *count, int reset) {
 
 extern "C" int rick_split_pack_f32(const float *x, void *out, float *hdr, const float *amax0, const float *amax1, float coef,
                                    int64_t npix, int C, void *stream) {
-    if (!x || !out || !hdr || !amax0 || npix < 0 || C <= 0 || (C & 31) || !(coef > 0.f)) return RICK_EINVAL;
+    if (!x || !out || !hdr || !amax0 || npix < 0 || C <= 0 || (C & 3) || !(coef > 0.f)) return RICK_EINVAL;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)hdr) % 16) return RICK_EINVAL;
     if (npix == 0) return 0;
-    const int64_t total8 = npix * (C / 8);
-    int64_t nb = cdiv64(total8, 256 * 4);
+    const int64_t n4 = npix * (C / 4);
+    int64_t nb = cdiv64(n4, 256 * 8);
     nb = nb < 1 ? 1 : (nb > 8192 ? 8192 : nb);
     hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, (unsigned char *)out,
-                       (cv_split_hdr *)hdr, amax0, amax1, coef, total8, C / 8);
+                       (cv_split_hdr *)hdr, amax0, amax1, coef, n4);
     RICK_LAUNCH_STATUS();
 }
 
 extern "C" int rick_split_unpack_f32(const void *pk, const float *hdr, float *out, int64_t npix, int C, void *stream) {
-    if (!pk || !hdr || !out || npix < 0 || C <= 0 || (C & 31)) return RICK_EINVAL;
+    if (!pk || !hdr || !out || npix < 0 || C <= 0 || (C & 3)) return RICK_EINVAL;
     if (((uintptr_t)pk | (uintptr_t)out | (uintptr_t)hdr) % 16) return RICK_EINVAL;
     if (npix == 0) return 0;
-    const int64_t total8 = npix * (C / 8);
-    int64_t nb = cdiv64(total8, 256 * 4);
+    const int64_t n4 = npix * (C / 4);
+    int64_t nb = cdiv64(n4, 256 * 8);
     nb = nb < 1 ? 1 : (nb > 8192 ? 8192 : nb);
     hipLaunchKernelGGL(split_unpack_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const unsigned char *)pk,
-                       (const cv_split_hdr *)hdr, out, total8, C / 8);
+                       (const cv_split_hdr *)hdr, out, n4);
     RICK_LAUNCH_STATUS();
 }

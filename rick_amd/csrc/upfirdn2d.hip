@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_kernel(const float *__rest
         ufd_store<XO>(out + po * p.minor + c0 + c4 * 4, (unsigned char *)xo.split_out + po * p.minor * 4, c0 + c4 * 4, v, xo, sscale, am);
     }
     if (XO) {
-        if (xo.amax) cv_amax_publish(am, xo.amax);
+        if (xo.amax) cv_amax_publish(am, xo.amax, smem);
         if (xo.split_out) cv_sat_check(am, sscale);
     }
 }
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
         }
     }
     if (XO) {
-        if (xo.amax) cv_amax_publish(am, xo.amax);
+        if (xo.amax) cv_amax_publish(am, xo.amax, reinterpret_cast<float *>(sx));
         if (xo.split_out) cv_sat_check(am, sscale);
     }
 }

@@ -48,9 +48,9 @@ __device__ __forceinline__ int wg_pswz(int kg, int pix, int kb) { return kg ^ ((
 // kernel is bound by the ISSUE of exactly these instructions (one wave per SIMD, 2-3 of them per MFMA, and an MFMA
 // leaves room for ~2), not by the matrix pipe: measured +20...27 % (280 -> 330-345 TFLOP/s on the 64^2...256^2 layers).
 // PK (FAST == 1 only): bit 0 = gy is a split image, bit 1 = x is a split image (conv_common.h; `ascale` / `bscale` then point
-// at the image's header instead of a scale table).  A split image has the fp32 tensor's pixel pitch and 16-byte granules of 8
-// channels, so the staging items keep their addresses; an item is copied to LDS as it is (one ds_write_b128, no conversion)
-// and the operand's exponent comes from the header.
+// at the image's header instead of a scale table).  A split image stores the fp16 hi / lo halves of 4 channels in the 16 bytes
+// the fp32 tensor uses for them, so the staging items keep their addresses and their LDS slots; an item is copied to LDS as it
+// is (two ds_write_b64, no conversion) and the operand's exponent comes from the header.
 template <int NT, int SPLIT, bool VEC, int PMAX, bool PIPE, int FAST = 0, int PK = 0>   // FAST: 1 = no per-channel scales, 2 = with
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                          float *__restrict__ ws, const float *__restrict__ ascale,
@@ -148,8 +148,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         g_rel[k] = ((nbi * g.OH + py * g.os) * g.OW + px * g.os) * g.Co;
         g_pyx[k] = (gco < g.Co && nbi < t.nbe) ? (((unsigned)nbi << 20) | ((unsigned)py << 10) | (unsigned)px) : 0xffffffffu;
         g_lds[k] = r * 256 + ((gc4 * 8) ^ (wg_key(r) * 32));
-        if constexpr ((PK & 1) != 0)     // granule gc4 of the pixel's 512 bytes: chunk gc4 >> 3, hi / lo plane bit 2, 8 channels each
-            g_lds[k] = ((gc4 >> 2) & 1) * WG_GY_BYTES + r * 256 + ((((gc4 >> 3) * 32 + (gc4 & 3) * 8) * 2) ^ (wg_key(r) * 32));
     }
 #pragma unroll
     for (int k = 0; k < PMAX; k++) {
@@ -157,8 +155,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         p_rel[k] = 0;
         p_pyx[k] = 0xffffffffu;
         p_lds[k] = (pix < t.NPP ? pix : t.NPP) * 64 + wg_pswz(pc4 >> 1, pix, t.pkb) * 16 + (pc4 & 1) * 8;
-        if constexpr ((PK & 2) != 0)     // granule pc4 of the chunk's 128 bytes: hi / lo plane bit 2, k-group pc4 & 3
-            p_lds[k] = (pc4 >> 2) * (t.NPP + 1) * 64 + (pix < t.NPP ? pix : t.NPP) * 64 + wg_pswz(pc4 & 3, pix, t.pkb) * 16;
         if (pix < t.NPP) {
             const unsigned e = ptab[pix];
             p_rel[k] = (((int)(e >> 20) * g.IH + (int)((e >> 10) & 1023)) * g.IW + (int)(e & 1023)) * g.Ci;
@@ -407,10 +403,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             const bool ok = (mask_cv >> K) & 1u;
             if constexpr (FAST) {
                 uint2 hi, lo;
-                if constexpr (K < 8 && (PK & 1) != 0) {
-                    *reinterpret_cast<float4 *>(buf + g_lds[K]) = gq[K];
+                if constexpr (K < 8 && (PK & 1) != 0) {            // split image: the item already IS {hi x 4 | lo x 4}
+                    const float4 v = gq[K];
+                    *reinterpret_cast<float2 *>(buf + g_lds[K]) = make_float2(v.x, v.y);
+                    *reinterpret_cast<float2 *>(buf + WG_GY_BYTES + g_lds[K]) = make_float2(v.z, v.w);
                 } else if constexpr (K >= 8 && (PK & 2) != 0) {
-                    *reinterpret_cast<float4 *>(buf + 2 * WG_GY_BYTES + p_lds[K - 8]) = pq[K - 8];
+                    const float4 v = pq[K - 8];
+                    *reinterpret_cast<float2 *>(buf + 2 * WG_GY_BYTES + p_lds[K - 8]) = make_float2(v.x, v.y);
+                    *reinterpret_cast<float2 *>(buf + 2 * WG_GY_BYTES + (t.NPP + 1) * 64 + p_lds[K - 8]) = make_float2(v.z, v.w);
                 } else if constexpr (K < 8) {
                     const float4 v = gq[K];
                     if constexpr (FAST == 2) {     // modulated layers (G) carry per-(image, channel) scales (x block exponent)

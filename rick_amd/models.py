@@ -12,6 +12,7 @@ Differences that do not change results (documented in DESIGN.md):
     `feat` tensors (the reference computes them twice, model_probe_tune.py:740-744).
 """
 import math
+import os
 import random
 
 import torch
@@ -24,7 +25,8 @@ from .op.fused_act import FusedLeakyReLU, fused_leaky_relu, fused_noise_bias_act
 from .op.upfirdn2d import upfirdn2d
 
 CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512}
-_USE_DBLOCK = True      # tests / tools switch the one-node split-image ResBlock (op/dblock.py) off to compare with the per-layer path
+# tests / tools switch the one-node split-image ResBlock (op/dblock.py) off to compare with the per-layer path
+_USE_DBLOCK = not os.environ.get('RICK_NO_DBLOCK')
 
 
 def _channels(res, channel_multiplier):

@@ -41,7 +41,7 @@ def _fir_ex(x, taps, up, down, pad4, out=None, split_bound=None, bound1=None, co
     img = None
     if split_bound is not None:
         data = torch.empty((n, c, oh, ow), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
-        img = sp.SplitImage(data, sp.new_words(4, x.device))
+        img = sp.SplitImage(data, sp.new_words(4, x.device), (split_bound, bound1, float(coef)))
         ex.split_out, ex.split_hdr, ex.bound0, ex.bound1, ex.bound_coef = ptr(data), ptr(img.hdr), ptr(split_bound), ptr(bound1), float(coef)
     ex.amax, ex.accumulate, ex.no_f32 = ptr(amax), int(accumulate), int(no_f32)
     if out is None and not no_f32:
@@ -55,8 +55,8 @@ def _act_adjoint_split(g, y, slope, scale, amax_g, mul2=None, want_b=False, sink
     """The activation adjoint as split images: (image of g * act'(y) * scale, image of g * mul2 or None, gb or None)."""
     n, c, h, w = g.shape
     rows = n * h * w
-    out1 = sp.SplitImage(torch.empty_like(g), sp.new_words(4, g.device))
-    out2 = sp.SplitImage(torch.empty_like(g), sp.new_words(4, g.device)) if mul2 is not None else None
+    out1 = sp.SplitImage(torch.empty_like(g), sp.new_words(4, g.device), (amax_g, None, abs(scale) * max(1.0, abs(slope))))
+    out2 = sp.SplitImage(torch.empty_like(g), sp.new_words(4, g.device), (amax_g, None, abs(mul2))) if mul2 is not None else None
     gb = part = None
     sunk = want_b and sink_b is not None
     if want_b:
@@ -121,17 +121,18 @@ class _DResBlock(Function):
         if xpk is None:
             xpk = sp.split_pack(xc)                     # block input from a producer that is not fused (the first block)
         dev = x.device
-        A1, A2, A3 = sp.new_words(1, dev), sp.new_words(1, dev), sp.new_words(1, dev)
+        A1, A2, A3 = sp.new_amax(dev), sp.new_amax(dev), sp.new_amax(dev)
         b1c, b2c = b1.contiguous(), b2.contiguous()
         t1 = _conv_launch(None, _pack(w1, sc1, (k1, 'w/conv')), C, 3, 3, 1, 1, epi=_amax_epilogue(A1, b1c, slope, gain, True), x_split=xpk)
         # blur(t1): only conv2 and its weight gradient read it -> split image only; |blur| <= max |t1| (taps >= 0, sum 1)
         _, b1pk = _fir_ex(t1, taps, 1, 1, (pad2[0], pad2[1], pad2[0], pad2[1]), split_bound=A1, no_f32=True)
         t2 = _conv_launch(None, _pack(w2, sc2, (k2, 'w/conv')), O, 3, 3, 2, 0, epi=_amax_epilogue(A2, b2c, slope, gain, True), x_split=b1pk)
         # skip path: the FIR evaluated at the even positions only (models.ResBlock._skip), bound = the input image's own
-        _, xspk = _fir_ex(xc, taps, 1, 2, (pads[0], pads[1], pads[0], pads[1]), split_bound=xpk.hdr[2:3], no_f32=True)
+        xb = xpk.bound
+        _, xspk = _fir_ex(xc, taps, 1, 2, (pads[0], pads[1], pads[0], pads[1]), split_bound=xb[0], bound1=xb[1], coef=xb[2], no_f32=True)
         sk = _conv_launch(None, _pack(ws, scs, (ks, 'w/conv')), O, 1, 1, 1, 0, epi=_amax_epilogue(A3), x_split=xspk)
         out = torch.empty_like(t2)
-        opk = sp.SplitImage(torch.empty_like(t2), sp.new_words(4, dev))
+        opk = sp.SplitImage(torch.empty_like(t2), sp.new_words(4, dev), (A2, A3, _SQ))
         check(lib.rick_add_scale_split_f32(ptr(t2), ptr(sk), ptr(out), ptr(opk.data), ptr(opk.hdr), ptr(A2), ptr(A3),
                                            t2.numel() // O, O, _SQ, stream_ptr()), 'rick_add_scale_split_f32')
         out._rick_split = opk
@@ -183,7 +184,7 @@ class _DResBlock(Function):
         upstream = need_x or need[1] or need[2]
         if upstream:
             g_b1 = _convT_launch(None, _pack(w2.transpose(0, 1), sc2, (k2, 'w/T/convT')), C, 3, 3, 2, 0, (H + 1, W + 1), x_split=gz2)
-            A1g = sp.new_words(1, dev)
+            A1g = sp.new_amax(dev)
             kh = taps.shape[0]
             adj2 = (kh - pad2[0] - 1, W - (W + 1) + pad2[0], kh - pad2[0] - 1, H - (H + 1) + pad2[0])   # op/upfirdn2d.py:111-114
             g_t1b, _ = _fir_ex(g_b1, flip, 1, 1, adj2, amax=A1g)
@@ -202,7 +203,7 @@ class _DResBlock(Function):
             # adjoint of the decimating FIR = zero-insertion upsampling with the flipped taps, ADDED into the main path's gradient
             kh = taps.shape[0]
             adjs = (kh - pads[0] - 1, W - (W // 2) * 2 + pads[0], kh - pads[0] - 1, H - (H // 2) * 2 + pads[0])
-            Agx = sp.new_words(1, dev)
+            Agx = sp.new_amax(dev)
             gx, _ = _fir_ex(g_xs, flip, 2, 1, adjs, out=gx, amax=Agx, accumulate=True)
             gx._rick_amax = Agx
         return gx, gw1, gb1, gw2, gb2, gws, None, None

@@ -1,5 +1,5 @@
-"""Split images: activations / gradients stored pre-split (fp16 hi | lo per 32-channel chunk, one power-of-two exponent
-per tensor) for the MFMA convolution kernels — see rick_amd/csrc/conv_common.h and include/rick_hip.h.
+"""Split images: activations / gradients stored pre-split (fp16 {hi x 4 | lo x 4} in the 16 bytes of every 4 channels, one
+power-of-two exponent per tensor) for the MFMA convolution kernels — see rick_amd/csrc/conv_common.h and include/rick_hip.h.
 
 A producer that is handed a guaranteed bound on |v| writes the image in its epilogue (next to, or instead of, the fp32
 tensor); consumers (igemm, convt2, wgrad) copy 16-byte granules into LDS with no conversion work.  The reference has no
@@ -12,7 +12,7 @@ from .._lib import check, lib, ptr, stream_ptr
 
 
 class _Arena(threading.local):
-    """Zero-initialised device words handed out one at a time (running maxima, headers): one fill launch per 1024 words
+    """Zero-initialised device words handed out in slices (running maxima, headers): one fill launch per 128 KB
     instead of one per tensor.  A chunk is never shared between eager issue and a hipGraph capture — the words a captured
     launch accumulates into must be re-zeroed by a fill that is part of the same graph."""
 
@@ -23,13 +23,14 @@ class _Arena(threading.local):
         cap = torch.cuda.is_current_stream_capturing()
         n4 = (n + 3) // 4 * 4                      # 16-byte aligned slices
         if self.chunk is None or self.pos + n4 > self.chunk.numel() or cap != self.cap or self.chunk.device != device:
-            self.chunk, self.pos, self.cap = torch.zeros(4096, device=device, dtype=torch.float32), 0, cap
+            self.chunk, self.pos, self.cap = torch.zeros(32768, device=device, dtype=torch.float32), 0, cap
         out = self.chunk[self.pos:self.pos + n]
         self.pos += n4
         return out
 
 
 _arena = _Arena()
+AMAX_FLOATS = 512        # RICK_AMAX_FLOATS: 16 slots, one per 128-byte line (include/rick_hip.h)
 
 
 def new_words(n, device):
@@ -37,13 +38,24 @@ def new_words(n, device):
     return _arena.take(n, torch.device(device))
 
 
+def new_amax(device):
+    """A zeroed running-maximum word (its value is the maximum over its slots: `amax_value`)."""
+    return _arena.take(AMAX_FLOATS, torch.device(device))
+
+
+def amax_value(word):
+    return word.max()
+
+
 class SplitImage:
     """data: the image (a float32 channels-last tensor of the activation's shape used as a byte container),
-    hdr: float32[4] on the device = {2^e, 2^-e, bound, 0}."""
-    __slots__ = ('data', 'hdr')
+    hdr: float32[4] on the device = {2^e, 2^-e, bound, 0},
+    bound: (amax word, amax word or None, coef) the producer derived its exponent from — |v| <= coef * (a0 + a1); a kernel
+    whose result is bounded by this tensor's values (a FIR with non-negative taps of sum 1) reuses it."""
+    __slots__ = ('data', 'hdr', 'bound')
 
-    def __init__(self, data, hdr):
-        self.data, self.hdr = data, hdr
+    def __init__(self, data, hdr, bound=None):
+        self.data, self.hdr, self.bound = data, hdr, bound
 
     @property
     def shape(self):
@@ -53,21 +65,21 @@ class SplitImage:
 def amax(x, word=None):
     """max |x| folded into a device word (atomic max; a fresh zeroed word by default)."""
     if word is None:
-        word = new_words(1, x.device)
+        word = new_amax(x.device)
     xc = x if x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last) else x.contiguous()
     check(lib.rick_amax_f32(ptr(xc), xc.numel(), ptr(word), stream_ptr()), 'rick_amax_f32')
     return word
 
 
 def supported(x):
-    return x.dim() == 4 and x.shape[1] % 32 == 0 and x.dtype == torch.float32 and x.is_cuda
+    return x.dim() == 4 and x.shape[1] % 4 == 0 and x.dtype == torch.float32 and x.is_cuda
 
 
 def split_pack(x, amax0=None, amax1=None, coef=1.0):
     """Stand-alone fp32 -> split image pass (layers whose producer is not fused; tests).  Without `amax0` the exact maximum
     is measured first (one extra read of x)."""
     if not supported(x):
-        raise RuntimeError('split_pack: needs a CUDA float32 [N, C, H, W] tensor with C % 32 == 0')
+        raise RuntimeError('split_pack: needs a CUDA float32 [N, C, H, W] tensor with C % 4 == 0')
     x = x.contiguous(memory_format=torch.channels_last)
     if amax0 is None:
         amax0 = amax(x)
@@ -76,7 +88,7 @@ def split_pack(x, amax0=None, amax1=None, coef=1.0):
     hdr = new_words(4, x.device)
     check(lib.rick_split_pack_f32(ptr(x), ptr(data), ptr(hdr), ptr(amax0), ptr(amax1), float(coef), n * h * w, c, stream_ptr()),
           'rick_split_pack_f32')
-    return SplitImage(data, hdr)
+    return SplitImage(data, hdr, (amax0, amax1, float(coef)))
 
 
 def split_unpack(si):

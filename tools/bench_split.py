@@ -40,7 +40,7 @@ if 'wgrad' in which:
         t0 = timeit(lambda: cv._wgrad_launch(gy, x, 3, 3, s, p))
         t1 = timeit(lambda: cv._wgrad_launch(gy, x, 3, 3, s, p, a_split=gs))
         t2 = timeit(lambda: cv._wgrad_launch(gy, x, 3, 3, s, p, a_split=gs, b_split=xs))
-        tp = timeit(lambda: sp.split_pack(x, xs.hdr[2:3]))
+        tp = timeit(lambda: sp.split_pack(x, xs.bound[0]))
         print(f'wgrad s{s} {ci:4d}x{co:4d} @{r:3d} N{B}: fp32 {t0*1e6:7.1f} us {flops/t0/1e12:6.1f} TF | gy split {t1*1e6:7.1f} us {flops/t1/1e12:6.1f} TF | '
               f'both {t2*1e6:7.1f} us {flops/t2/1e12:6.1f} TF ({t0/t2:.2f}x) | pack(x) pass {tp*1e6:6.1f} us')
 
