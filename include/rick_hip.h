@@ -226,7 +226,10 @@ typedef struct {
     int accumulate;         /* add the result to what the fp32 output holds (a second gradient arriving at a branch point) */
     int no_f32;             /* do not write the fp32 result (the output pointer may be NULL) */
 } rick_split_out;
-/* values that exceeded their producer's bound since the last reset (0 unless a caller passed a wrong bound); host-synchronous */
+/* Saturation events since the last reset, host-synchronous: values that exceeded a split-image producer's bound (a caller's
+ * mistake) and waves of the igemm / convt2 / wgrad kernels that clamped an fp32 -> fp16 conversion of an on-the-fly split
+ * (an operand ~8 000 x above the sampled block maximum: the hardware's sticky OVERFLOW status, read once per wave).  Every
+ * event means a finite but wrong product somewhere: 0 in every test and in tools/stability.py. */
 int rick_saturation_count(unsigned *count, int reset);
 /* Producers.  rick_upfirdn2d_f32 / rick_upfirdn2d_act_f32 (tail may be NULL) with the extended result handling, channels-last
  * only; `out` may be NULL with ex->no_f32.  The activation adjoint (rick_bias_act_bwd_f32) leaving as split images:

@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
         packed[base + off] = h;
         packed[base + CV_WTILE_BYTES / 2 + off] = l;
     }
+    cv_overflow_check();
 }
 
 extern "C" int rick_conv_pack_weight(const float *w, int64_t s_co, int64_t s_ci, int64_t s_t, int Co, int Ci,
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const rick_pack_
         dst[(int64_t)sl * (CV_WSTEP_BYTES / 2)] = h;
         dst[(int64_t)sl * (CV_WSTEP_BYTES / 2) + CV_WTILE_BYTES / 2] = l;
     }
+    cv_overflow_check();
 }
 
 extern "C" int rick_conv_pack_blocks(int Co, int Ci) { return cdiv(Co, CV_BM) * cdiv(Ci, CV_CK) * (CV_BM * CV_CK / 256); }
@@ -787,6 +789,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     else if (oscale) epilogue(std::true_type{}, std::false_type{});
     else if (has_ep) epilogue(std::false_type{}, std::true_type{});
     else epilogue(std::false_type{}, std::false_type{});
+    cv_overflow_check();
     if (epi.amax && t.nsplit == 1) cv_amax_publish(out_amax, epi.amax, reinterpret_cast<float *>(smem));     // (split-K: the second stage measures)
 }
 
@@ -1134,3 +1137,5 @@ extern "C" int rick_conv_igemm_multi_f32(const float *x, const void *packed_w, f
         if (m.t[c].nsplit > 1) launch_splitk_reduce(ws + m.ws_off[c], out, oscale, &geoms[c], m.t[c].nsplit, st);
     RICK_LAUNCH_STATUS();
 }
+
+CV_DEFINE_SAT_ACCESSOR(rick_sat_conv)

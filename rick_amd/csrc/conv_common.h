@@ -35,8 +35,9 @@ __host__ __device__ __forceinline__ int cv_swz(int kg, int row) { return kg ^ ((
 //     second-order bias gradients 3e-3 off); nearest rounding makes the dropped term sign-random;
 //   * smaller values: lo becomes an fp16 subnormal (the MFMA does not flush them - measured), absolute error
 //     <= 2^-25 / 2^T = 2^-27 of the sampled maximum;
-//   * overflow needs a value 2^(15 - T) = 8192x above the sampled maximum of >= 4096 samples per block; such a value
-//     becomes infinity and the outputs it touches inf / nan (loud, never silently wrong).
+//   * overflow needs a value 2^(13 - T) ~ 8 000 x above the sampled maximum of >= 4096 samples per block; such a value
+//     saturates at +-65504 (MODE.FP16_OVFL, below: finite, wrong by its excess) and is COUNTED (cv_overflow_check):
+//     rick_saturation_count() > 0 — tools/stability.py and the GPU tests fail on it.
 #define CV_EXP_TARGET 2
 
 __device__ __forceinline__ unsigned pack_f16_rne(float a, float b) {   // v_cvt_pk_f16_f32
@@ -240,6 +241,15 @@ __device__ __forceinline__ void cv_split_store4(unsigned char *pixel, int c, con
 static __device__ unsigned g_cv_sat;
 __device__ __forceinline__ void cv_sat_check(float thread_amax, float scale) {
     if (thread_amax * scale >= 65504.f) atomicAdd(&g_cv_sat, 1u);
+}
+// The kernels that split fp32 operands on the fly take their exponent from a SAMPLE of the block's data and run with
+// MODE.FP16_OVFL = 1 (cv_fp16_saturate): a value more than ~8 000 x the largest sample clamps to +-65504 — finite and wrong.
+// The hardware still records the event: TRAPSTS.EXCP is sticky per wave and accumulates IEEE exceptions whether or not traps are
+// enabled, and a clamped fp32 -> fp16 conversion raises OVERFLOW (bit 3).  One s_getreg at the end of the kernel, no VALU in
+// the loops; a wave that saw an overflow bumps the translation unit's counter (rick_saturation_count sums them).
+__device__ __forceinline__ void cv_overflow_check() {
+    const unsigned ovf = __builtin_amdgcn_s_getreg((0 << 11) | (3 << 6) | 3);     // hwreg(HW_REG_TRAPSTS, offset 3, size 1)
+    if (ovf && (threadIdx.x & 63) == 0) atomicAdd(&g_cv_sat, 1u);
 }
 // running maximum of a thread -> wave -> one atomic max on the float's bits (values are >= 0)
 // The thread first reads the slot (device-scope load: from the L2, where the atomics act) and only issues the atomic when it

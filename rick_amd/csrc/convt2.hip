@@ -326,6 +326,7 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     // ---- epilogue: class (py, px), position (gy, gx) -> output pixel (2*gy + py, 2*gx + px)
     const int GHc = P.IH + 1 - py, GWc = P.IW + 1 - px;
     const int64_t osz = (int64_t)P.N * P.OH * P.OW * P.Co;
+    cv_overflow_check();
     const float oalpha = P.alpha * unscale;                   // exact: the exponents are powers of two
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
@@ -601,3 +602,5 @@ extern "C" int rick_convt2_posmap(int N, int IH, int IW, int Ci, int Co, int OH,
     *pitch = p.PW;
     return 0;
 }
+
+CV_DEFINE_SAT_ACCESSOR(rick_sat_convt2)

@@ -54,12 +54,17 @@ __global__ __launch_bounds__(256) void split_unpack_kernel(const unsigned char *
 CV_DEFINE_SAT_ACCESSOR(rick_sat_split)
 extern "C" int rick_sat_upfirdn2d(unsigned *, int);
 extern "C" int rick_sat_elementwise(unsigned *, int);
+extern "C" int rick_sat_conv(unsigned *, int);
+extern "C" int rick_sat_wgrad(unsigned *, int);
+extern "C" int rick_sat_convt2(unsigned *, int);
 
 extern "C" int rick_saturation_count(unsigned *count, int reset) {
     if (!count) return RICK_EINVAL;
-    unsigned a = 0, b = 0, c = 0;
-    if (rick_sat_split(&a, reset) || rick_sat_upfirdn2d(&b, reset) || rick_sat_elementwise(&c, reset)) return 1;
-    *count = a + b + c;
+    unsigned a = 0, b = 0, c = 0, d = 0, e = 0, f = 0;
+    if (rick_sat_split(&a, reset) || rick_sat_upfirdn2d(&b, reset) || rick_sat_elementwise(&c, reset) || rick_sat_conv(&d, reset) ||
+        rick_sat_wgrad(&e, reset) || rick_sat_convt2(&f, reset))
+        return 1;
+    *count = a + b + c + d + e + f;
     return 0;
 }
 

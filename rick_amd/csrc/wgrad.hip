@@ -542,6 +542,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         else run(std::false_type{});
     }
 
+    cv_overflow_check();
     // ---- partial tile -> workspace [split][cot][chunk][tap][32 ci][128 co]: a lane's 4 accumulator
     // registers are 4 consecutive co of one ci, so the [ci][co] order makes every store a float4
     float *wsb = ws + (((int64_t)split * t.ncot + cot) * t.nchunks + chunk) * g.ntaps * (CV_BM * CV_CK);
@@ -800,3 +801,5 @@ static int wgrad_run(const float *x, const float *gy, float *gw, int64_t s_co, i
                        t.ncot, t.nchunks, g->ntaps, nsplit, g->alpha, accumulate, *g);
     RICK_LAUNCH_STATUS();
 }
+
+CV_DEFINE_SAT_ACCESSOR(rick_sat_wgrad)

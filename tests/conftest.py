@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'saturates: the test provokes fp16 saturation on purpose (the counter may be non-zero)')
 
 
 @pytest.fixture(scope='session')
@@ -25,3 +26,24 @@ def golden():
             cache[name] = np.load(os.path.join(GOLDEN, name + '.npz'))
         return cache[name]
     return load
+
+
+@pytest.fixture(autouse=True)
+def _no_silent_saturation(request):
+    """Every GPU test must leave the library's saturation counter at zero (include/rick_hip.h: rick_saturation_count): an
+    operand far above its block's sampled maximum, or a value above a split-image producer's bound, yields finite but wrong
+    products — never silently.  Tests that provoke the event on purpose carry @pytest.mark.saturates."""
+    if request.node.get_closest_marker('gpu') is None:
+        yield
+        return
+    import ctypes
+
+    import torch
+    from rick_amd._lib import check, lib
+    c = ctypes.c_uint(0)
+    check(lib.rick_saturation_count(ctypes.byref(c), 1), 'rick_saturation_count')
+    yield
+    if request.node.get_closest_marker('saturates') is None:
+        torch.cuda.synchronize()
+        check(lib.rick_saturation_count(ctypes.byref(c), 1), 'rick_saturation_count')
+        assert c.value == 0, f'{c.value} saturation events during {request.node.name}'

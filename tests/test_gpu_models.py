@@ -688,6 +688,57 @@ def test_fisher_sweep_256_16_samples(golden):
     assert (view[0, tr.idx_freeze_g['convs.0.conv.weight']] & 1).all()
 
 
+def test_fisher_sweep_256_64_samples_as_four_shards(golden):
+    """BASELINE config 5 at its own size (num_fisher_img = 64, 256 px) on one GPU, and its 4-way sharding: the 64-sample
+    sweep (10 shipped _noise latents + 54 seeded, train_dynamic_update_prune.py:214-269) against the four 16-sample shards a
+    4-rank run would compute (rank r takes samples j % 4 == r, bench.py / dist.py):
+      * the accumulators equal the sum of the shards' (grad^2 accumulation is linear; fp32 summation order only),
+      * the per-filter statistics summed over the shards — what all_reduce_vectors hands every rank — give exactly the index
+        sets of the unsharded sweep, which equal the oracle's decision code (:277-393) on the device Fisher tensors."""
+    from oracle.train_ref import d_decisions_ref, g_decisions_ref
+    from rick_amd.train import RickTrainer, TrainConfig, d_filter_fim, decide_d, decide_g, g_filter_fim
+    lat = golden('noise_latents')
+    size, n, world = 256, 64, 4
+    g, d = build(size)
+    g_ema, d_ema = build(size)
+    cfg = TrainConfig(size=size, batch=4, warmup_iter=0, num_fisher_img=n, fisher_quantile=40.0, prune_quantile=0.1)
+    tr = RickTrainer(cfg, g, d, g_ema, d_ema)
+    zs = [torch.from_numpy(lat[f'noise_{j:04d}']).to(DEV) for j in range(10)] + [synth_latents(1, seed=500 + j).to(DEV) for j in range(10, n)]
+    reals = [synth_reals(2, size=size, seed=256)[0:1].to(DEV)] + [synth_reals(1, size=size, seed=600 + j).to(DEV) for j in range(1, n)]
+    tr.enable_graphs(True)
+    sum_g = sum_d = None
+    vec = None
+    for r in range(world):
+        mine = [j for j in range(n) if j % world == r]
+        acc_g, acc_d = tr.fisher_sweep([zs[j] for j in mine], [reals[j] for j in mine], first=True, fixed_noise=True)
+        cg = {k: v.double().clone() for k, v in acc_g.acc.items()}
+        cd = {k: v.double().clone() for k, v in acc_d.acc.items()}
+        sum_g = cg if sum_g is None else {k: sum_g[k] + cg[k] for k in cg}
+        sum_d = cd if sum_d is None else {k: sum_d[k] + cd[k] for k in cd}
+        conv, fc = g_filter_fim(acc_g.acc)
+        dfim = d_filter_fim(acc_d.acc)
+        parts = [{k: v.clone() for k, v in t.items()} for t in (conv, fc, dfim)]
+        vec = parts if vec is None else [{k: a[k] + b[k] for k in a} for a, b in zip(vec, parts)]     # all_reduce_vectors: fp32 sum
+    acc_g, acc_d = tr.fisher_sweep(zs, reals, first=True, fixed_noise=True)
+    for k, v in acc_g.acc.items():
+        assert l2rel(v, sum_g[k]) < 2e-6, k
+    for k, v in acc_d.acc.items():
+        assert l2rel(v, sum_d[k]) < 2e-6, k
+    to_np = lambda t: {k: v.detach().cpu().numpy() for k, v in t.items()}   # noqa: E731
+    fz_g, _, pr_g = decide_g(to_np(vec[0]), to_np(vec[1]), cfg.fisher_quantile, cfg.prune_quantile)
+    fz_d, _, pr_d = decide_d(to_np(vec[2]), cfg.fisher_quantile, cfg.prune_quantile)
+    og, _, opg = g_decisions_ref({k: v.cpu().numpy() for k, v in acc_g.acc.items()}, cfg.fisher_quantile, cfg.prune_quantile,
+                                 n_blocks=len(g.convs))
+    od, _, opd = d_decisions_ref({k: v.cpu().numpy() for k, v in acc_d.acc.items()}, cfg.fisher_quantile, cfg.prune_quantile,
+                                 blocks=range(1, len(d.convs)))
+    for name, got, shard, want in (('freeze_g', tr.idx_freeze_g, fz_g, og), ('prune_g', tr.zero_idx_g, pr_g, opg),
+                                   ('freeze_d', tr.idx_freeze_d, fz_d, od), ('prune_d', tr.zero_idx_d, pr_d, opd)):
+        assert set(got) == set(want) == set(shard), name
+        for k in want:
+            assert np.array_equal(np.sort(got[k]), np.sort(want[k])), (name, k)
+            assert np.array_equal(np.sort(shard[k]), np.sort(want[k])), (name, k, 'sharded')
+
+
 def test_generator_forward_options_vs_oracle():
     """Generator.forward's remaining arguments (model_probe_tune.py:509-592): two-style mixing at an explicit inject_index,
     truncation < 1 towards a truncation_latent, return_feats (the 2 * (log2(size) - 2) + 1 StyledConv outputs),

@@ -53,6 +53,7 @@ def test_amax_and_pack_roundtrip():
     assert _sat() == 0
 
 
+@pytest.mark.saturates
 def test_wrong_bound_is_counted_not_silent():
     """A producer whose values exceed the bound it was given (a caller's mistake: bounds are guaranteed, not sampled) is
     counted AND loud: the producers do not set MODE.FP16_OVFL, so the value becomes inf / NaN instead of a finite wrong one."""
@@ -237,3 +238,39 @@ def test_discriminator_chain_passes_images_and_maxima():
             assert calls == {'pack': 1, 'amax': 2}, calls
     for a, b in zip(res[True], res[False]):
         assert float((a - b).abs().max() / b.abs().max()) < 3e-5
+
+
+@pytest.mark.saturates
+def test_on_the_fly_split_counts_what_its_sampled_exponent_misses():
+    """The kernels that split fp32 operands themselves take the exponent from a sample of the block's data (MODE.FP16_OVFL on:
+    a value ~8 000 x above every sample clamps to 65504, finite and wrong).  The clamp is counted through the hardware's
+    sticky overflow status: a spike 10^5 x above the rest at a position the sample does not visit makes
+    rick_saturation_count() non-zero, in the forward, data-gradient and weight-gradient kernels alike; the same launches on
+    well-scaled data leave it at zero (and so does every other GPU test: tests/conftest.py)."""
+    from rick_amd.op import conv as cv
+    torch.manual_seed(0)
+    N, C, H = 4, 256, 64
+    w = torch.randn(C, C, 3, 3, device=DEV)
+    wp, wpT = cv._pack(w, 1.0), cv._pack(w.transpose(0, 1), 1.0)
+    x = _cl(torch.randn(N, C, H, H, device=DEV))
+    g = _cl(torch.randn(N, C, H, H, device=DEV))
+    assert _sat(reset=True) == 0
+    cv._conv_launch(x, wp, C, 3, 3, 1, 1)
+    cv._convT_launch(g, wpT, C, 3, 3, 1, 1, (H, H))
+    cv._wgrad_launch(g, x, 3, 3, 1, 1)
+    torch.cuda.synchronize()
+    assert _sat() == 0
+    hits = 0
+    for trial in range(8):                       # the sampled positions are fixed per block; one of a few spike positions is missed
+        xs = x.clone()
+        xs[trial % N, 100 + 7 * trial, 17 + trial, 29 - trial] = 1e5
+        _sat(reset=True)
+        y = cv._conv_launch(xs, wp, C, 3, 3, 1, 1)
+        gw = cv._wgrad_launch(g, xs, 3, 3, 1, 1)
+        torch.cuda.synchronize()
+        n = _sat()
+        if n:
+            hits += 1
+            assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(gw).all())      # clamped, not inf: hence the counter
+    assert hits > 0
+    _sat(reset=True)

@@ -253,3 +253,99 @@ def test_bench_self_launch_propagates_failure():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0
+
+
+# ------------------------------------------------------------------- world_size-4 gloo
+def _dp4_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from rick_amd.dist import DataParallelGrads, init_from_env
+    init_from_env('gloo')
+    # integer-valued data: every gradient and every partial sum is exact in fp32, so the result cannot depend on the order
+    # in which a ring sums the four ranks — bucketed and blocking exchange must agree BIT FOR BIT
+    gen = torch.Generator().manual_seed(11)
+    def ints(*shape, k=2):
+        return torch.randint(-k, k + 1, shape, generator=gen).float()
+    import copy
+    nets, flats, twins = [], [], []
+    for widths in ((48, 160, 96, 96, 8), (40, 200, 120, 64, 64, 4)):     # "G": 3 buckets, "D": 4 buckets at 16 KiB
+        # INDEPENDENT layers (each reads the input's first columns): gradients are sums of a few small integers
+        lin = torch.nn.ModuleList([torch.nn.Linear(a, b) for a, b in zip(widths[:-1], widths[1:])])
+        with torch.no_grad():
+            for p in lin.parameters():
+                p.copy_(ints(*p.shape))
+        nets.append(lin)
+        flats.append(FlatParams(list(lin.named_parameters())))
+        twin = copy.deepcopy(lin)                                  # same parameters, no hooks: the blocking reference
+        twins.append((twin, FlatParams(list(twin.named_parameters()))))
+    dp = DataParallelGrads(bucket_bytes=16 * 1024)
+    dp.attach(*flats)
+    nb = [len(dp._state[id(f)]['buckets']) for f in flats]
+    xs = [ints(16, 256, k=3), ints(16, 256, k=3)]
+    out = {'nb': nb}
+    for name, lin, flat, x in zip('gd', nets, flats, xs):
+        flat.zero_grad()
+        dp.prepare(flat)
+        xr = x[rank * 4:(rank + 1) * 4]
+        sum(((rank + 1) * m(xr[:, :m.in_features])).sum() for m in lin).backward()   # buckets leave from the hooks during backward
+        dp.all_reduce(flat)
+        twin, tflat = twins['gd'.index(name)]
+        tflat.zero_grad()
+        sum(((rank + 1) * m(xr[:, :m.in_features])).sum() for m in twin).backward()
+        blocking = tflat.grad.clone()
+        dist.all_reduce(blocking, op=dist.ReduceOp.SUM)
+        blocking /= world
+        out[name] = (flat.grad.clone().numpy(), blocking.numpy())
+    # Fisher sweep with fewer samples than ranks' worth: 5 samples over 4 ranks (2 / 1 / 1 / 1), then 3 samples (rank 3 has
+    # none: its loop body never runs and its accumulators stay zero, train.py fisher_sweep) — the per-filter vectors are summed
+    # across ranks and every rank must take identical decisions
+    from rick_amd.train import decide_d
+    for nsamp in (5, 3):
+        rs = np.random.RandomState(100 + nsamp)
+        per_sample = [{f'convs.{b}.{nm}': rs.rand(64).astype(np.float32) ** 3 for b in range(1, 7)
+                       for nm in ('conv1.0.weight', 'conv2.1.weight', 'skip.1.weight')} for _ in range(nsamp)]
+        mine = [j for j in range(nsamp) if j % world == rank]
+        keys = sorted(per_sample[0])
+        vecs = [torch.zeros(64) for _ in keys]
+        for j in mine:
+            for v, k in zip(vecs, keys):
+                v += torch.from_numpy(per_sample[j][k])
+        dp.all_reduce_vectors(vecs)
+        fim = {k: v.numpy() / nsamp for k, v in zip(keys, vecs)}
+        fr, ft, pr = decide_d(fim, 75, 0.1)
+        out[f'fisher{nsamp}'] = (len(mine), {k: fim[k].copy() for k in keys}, {k: np.asarray(v) for k, v in fr.items()},
+                                 {k: np.asarray(v) for k, v in pr.items()})
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_world4_buckets_and_uneven_fisher_shards():
+    """Four ranks (gloo, CPU): 3 + 4 buckets, bucketed == blocking all-reduce bit for bit (integer-valued gradients), equal on
+    every rank; Fisher shards of 2/1/1/1 and 1/1/1/0 samples give every rank the same per-filter statistics and decisions."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp4_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert outs[0]['nb'] == [3, 4], outs[0]['nb']
+    for name in 'gd':
+        for r in range(4):
+            got, blocking = outs[r][name]
+            assert np.array_equal(got, blocking), (name, r)
+            assert np.array_equal(got, outs[0][name][0])
+        assert float(np.abs(outs[0][name][0]).max()) > 0
+    for nsamp, counts in ((5, [2, 1, 1, 1]), (3, [1, 1, 1, 0])):
+        assert [outs[r][f'fisher{nsamp}'][0] for r in range(4)] == counts
+        ref = outs[0][f'fisher{nsamp}']
+        for r in range(1, 4):
+            o = outs[r][f'fisher{nsamp}']
+            for k in ref[1]:
+                assert np.array_equal(o[1][k], ref[1][k])
+            assert o[2].keys() == ref[2].keys() and all(np.array_equal(o[2][k], ref[2][k]) for k in ref[2])
+            assert o[3].keys() == ref[3].keys() and all(np.array_equal(o[3][k], ref[3][k]) for k in ref[3])

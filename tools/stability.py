@@ -34,3 +34,9 @@ for blk in range(int(os.environ.get('BLOCKS', 5))):
           f'mpl={float(tr.mean_path_length):.4f} mem={torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB', flush=True)
 assert all(bool(torch.isfinite(p).all()) for p in g.parameters())
 print('finite ok')
+import ctypes
+from rick_amd._lib import lib
+c = ctypes.c_uint(0)
+assert lib.rick_saturation_count(ctypes.byref(c), 0) == 0
+assert c.value == 0, f'{c.value} fp16 saturation events: some operand sat far above its block\'s sampled maximum (finite, wrong products)'
+print('no saturation events')
