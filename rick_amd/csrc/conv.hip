@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
     const int nchunks = (Ci + CV_CK - 1) / CV_CK;
     const float pscale = trailer[1];
     cv_fp16_saturate();
+    float satm = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int k = (int)(i & 31);
         const int r = (int)((i >> 5) & 127);
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
         const int co = cot * CV_BM + r, ci = chunk * CV_CK + k;
         float v = 0.f;
         if (co < Co && ci < Ci) v = w[co * s_co + ci * s_ci + slice * s_t] * scale * pscale;
+        satm = fmaxf(satm, fabsf(v));
         unsigned short h, l;
         split1(v, h, l, split);
         const int64_t base = (i >> 12) * (CV_WSTEP_BYTES / 2);
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
         packed[base + off] = h;
         packed[base + CV_WTILE_BYTES / 2 + off] = l;
     }
-    cv_overflow_check();
+    cv_sat_report(satm);
 }
 
 extern "C" int rick_conv_pack_weight(const float *w, int64_t s_co, int64_t s_ci, int64_t s_t, int Co, int Ci,
@@ -144,15 +146,17 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const rick_pack_
     const float *src = ds.w + (ok ? co * ds.s_co + ci * ds.s_ci : 0);
     unsigned short *dst = (unsigned short *)ds.packed + (int64_t)tile * ds.nslices * (CV_WSTEP_BYTES / 2) +
                           r * 32 + cv_swz(k >> 3, r) * 8 + (k & 7);
+    float satm = 0.f;
     for (int sl = 0; sl < ds.nslices; sl++) {
         float v = src[sl * ds.s_t] * ds.scale * pscale;
         if (!ok) v = 0.f;
+        satm = fmaxf(satm, fabsf(v));
         unsigned short h, l;
         split1(v, h, l, split);
         dst[(int64_t)sl * (CV_WSTEP_BYTES / 2)] = h;
         dst[(int64_t)sl * (CV_WSTEP_BYTES / 2) + CV_WTILE_BYTES / 2] = l;
     }
-    cv_overflow_check();
+    cv_sat_report(satm);
 }
 
 extern "C" int rick_conv_pack_blocks(int Co, int Ci) { return cdiv(Co, CV_BM) * cdiv(Ci, CV_CK) * (CV_BM * CV_CK / 256); }
@@ -276,6 +280,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     __syncthreads();   // patch table and scale table complete
     // operand exponent of this block (conv_common.h), set by block_exponent() below once the first chunk is in registers
     float xscale = 1.f, unscale = 1.f;
+    float satm = 0.f;          // largest |scaled operand| this thread converts (cv_sat_report)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -361,8 +366,8 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 if (!VEC && !ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 hi, lo;
                 if constexpr (decltype(ISC)::value)
-                    split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sct + p_sc[k] + (chunk - c_begin) * CV_CK), hi, lo);
-                else split4s<SPLIT>(v, xscale, hi, lo);
+                    split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sct + p_sc[k] + (chunk - c_begin) * CV_CK), hi, lo, satm);
+                else split4s<SPLIT>(v, xscale, hi, lo, satm);
                 *reinterpret_cast<uint2 *>(ph + p_lds[k]) = hi;
                 if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + p_lds[k]) = lo;
             }
@@ -380,8 +385,8 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 float4 v = load4<VEC>(ok ? x + (((int64_t)n * g.IH + iy) * g.IW + ix) * g.Ci + ci : x, ok, ci, g.Ci);
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 hi, lo;
-                if (iscale) split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sct + (int)(e >> 20) * cspan + (chunk - c_begin) * CV_CK + c4 * 4), hi, lo);
-                else split4s<SPLIT>(v, xscale, hi, lo);      // (the scale table only exists with an input scale)
+                if (iscale) split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sct + (int)(e >> 20) * cspan + (chunk - c_begin) * CV_CK + c4 * 4), hi, lo, satm);
+                else split4s<SPLIT>(v, xscale, hi, lo, satm);      // (the scale table only exists with an input scale)
                 const int off = pix * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
                 *reinterpret_cast<uint2 *>(ph + off) = hi;
                 if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + off) = lo;
@@ -789,7 +794,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     else if (oscale) epilogue(std::true_type{}, std::false_type{});
     else if (has_ep) epilogue(std::false_type{}, std::true_type{});
     else epilogue(std::false_type{}, std::false_type{});
-    cv_overflow_check();
+    cv_sat_report(satm);
     if (epi.amax && t.nsplit == 1) cv_amax_publish(out_amax, epi.amax, reinterpret_cast<float *>(smem));     // (split-K: the second stage measures)
 }
 

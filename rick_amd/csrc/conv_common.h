@@ -129,6 +129,21 @@ template <int SPLIT>
 __device__ __forceinline__ void split4s(const float4 v, const float s, uint2 &hi, uint2 &lo) {
     split4v<SPLIT>(v, make_float4(s, s, s, s), hi, lo);
 }
+// Saturation tracking (2 v_max3 per 4 elements): `m` follows the largest |scaled operand| this thread has converted; a thread
+// whose m reaches the fp16 maximum has produced a clamped (finite, wrong) value and reports it at the end of the kernel
+// (cv_sat_report).  The exponent comes from a SAMPLE, so this is the only place the event can be seen.
+__device__ __forceinline__ float cv_track4(float m, const float4 w) {
+    return fmaxf(fmaxf(fmaxf(m, fabsf(w.x)), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w)));
+}
+template <int SPLIT>
+__device__ __forceinline__ void split4v(const float4 v, const float4 s, uint2 &hi, uint2 &lo, float &m) {
+    m = cv_track4(m, make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w));     // (the products are shared with the split below)
+    split4v<SPLIT>(v, s, hi, lo);
+}
+template <int SPLIT>
+__device__ __forceinline__ void split4s(const float4 v, const float s, uint2 &hi, uint2 &lo, float &m) {
+    split4v<SPLIT>(v, make_float4(s, s, s, s), hi, lo, m);
+}
 
 // The same split in 8 instructions on v_fma_mixlo/mixhi_f16: f16(v*s) and f16(v*s - hi), the fp16 hi read back in place.
 // Half-rate instructions (57 issue cycles against 41), but a third fewer of them: the weight-gradient kernel, whose single
@@ -150,6 +165,19 @@ __device__ __forceinline__ void split4v_mix(const float4 v, const float4 s, uint
     }
     hi = make_uint2(h0, h1);
     lo = make_uint2(l0, l1);
+}
+// (mix forms never materialise v * s in fp32: they track the RAW operand; the caller multiplies by a bound on the scale)
+template <int SPLIT>
+__device__ __forceinline__ void split4v_mix(const float4 v, const float4 s, uint2 &hi, uint2 &lo, float &mraw) {
+    mraw = cv_track4(mraw, v);
+    split4v_mix<SPLIT>(v, s, hi, lo);
+}
+template <int SPLIT>
+__device__ __forceinline__ void split4s_mix(const float4 v, const float s, uint2 &hi, uint2 &lo);
+template <int SPLIT>
+__device__ __forceinline__ void split4s_mix(const float4 v, const float s, uint2 &hi, uint2 &lo, float &mraw) {
+    mraw = cv_track4(mraw, v);
+    split4s_mix<SPLIT>(v, s, hi, lo);
 }
 template <int SPLIT>
 __device__ __forceinline__ void split4s_mix(const float4 v, const float s, uint2 &hi, uint2 &lo) {
@@ -242,14 +270,11 @@ static __device__ unsigned g_cv_sat;
 __device__ __forceinline__ void cv_sat_check(float thread_amax, float scale) {
     if (thread_amax * scale >= 65504.f) atomicAdd(&g_cv_sat, 1u);
 }
-// The kernels that split fp32 operands on the fly take their exponent from a SAMPLE of the block's data and run with
-// MODE.FP16_OVFL = 1 (cv_fp16_saturate): a value more than ~8 000 x the largest sample clamps to +-65504 — finite and wrong.
-// The hardware still records the event: TRAPSTS.EXCP is sticky per wave and accumulates IEEE exceptions whether or not traps are
-// enabled, and a clamped fp32 -> fp16 conversion raises OVERFLOW (bit 3).  One s_getreg at the end of the kernel, no VALU in
-// the loops; a wave that saw an overflow bumps the translation unit's counter (rick_saturation_count sums them).
-__device__ __forceinline__ void cv_overflow_check() {
-    const unsigned ovf = __builtin_amdgcn_s_getreg((0 << 11) | (3 << 6) | 3);     // hwreg(HW_REG_TRAPSTS, offset 3, size 1)
-    if (ovf && (threadIdx.x & 63) == 0) atomicAdd(&g_cv_sat, 1u);
+// End of a kernel that splits on the fly: a thread whose tracked maximum reached the fp16 range's end bumps the counter.
+// (TRAPSTS.EXCP would have been free, but this hardware does not accumulate IEEE exceptions while traps are disabled:
+// tools/micro/trapsts.hip reads 0 after an fp32 -> fp16 and an fp32 overflow alike.)
+__device__ __forceinline__ void cv_sat_report(float m) {
+    if (m >= 65504.f) atomicAdd(&g_cv_sat, 1u);
 }
 // running maximum of a thread -> wave -> one atomic max on the float's bits (values are >= 0)
 // The thread first reads the slot (device-scope load: from the L2, where the atomics act) and only issues the atomic when it

@@ -133,6 +133,9 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
         }
     }
     float unscale = 1.f, xscale = 1.f;                        // set by block_exponent() once the first chunk is in registers
+    // saturation tracking without a live VGPR (see wgrad.hip): raw item maximum against 65504 / (largest scale x exponent)
+    float sat_thr = 3.0e38f;
+    unsigned long long sat_bits = 0;
     float4 pq[CT_PITEMS];
     unsigned cur_ok = 0;
     auto issue_patch = [&](int chunk) {
@@ -151,6 +154,9 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
 #pragma unroll
             for (int k = 0; k < CT_PITEMS; k++) {
                 const float4 v = pq[k];       // (an out-of-range item has read the zero page)
+#ifdef RICK_ABLATION      // (shipping build: off here, as in wgrad.hip — this kernel spills already; conv.hip tracks always)
+                if constexpr (!PKX) sat_bits |= __builtin_amdgcn_ballot_w64(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) > sat_thr);
+#endif
                 if constexpr (PKX) {      // the item already IS {hi x 4 | lo x 4}
                     if (pix0 + (CT_THREADS / 8) * k < P.NPP) {
                         *reinterpret_cast<float2 *>(ph + p_lds0 + k * 4096) = make_float2(v.x, v.y);
@@ -215,8 +221,12 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
         xscale = cv_uniform(xs);
         // packed-weight exponent (trailer of the packed image)
         unscale = cv_uniform(xu * *reinterpret_cast<const float *>(wpk + (int64_t)P.ncot * P.nchunks * 9 * CV_WSTEP_BYTES));
+        sat_thr = 65504.f / xscale;
         if (iscale) {                                         // fold 2^e into the scale table
-            for (int i = threadIdx.x; i < P.NB * cspan; i += CT_THREADS) sct[i] *= xscale;
+            float tm = 0.f;
+            for (int i = threadIdx.x; i < P.NB * cspan; i += CT_THREADS) tm = fmaxf(tm, fabsf(sct[i] *= xscale));
+            __syncthreads();
+            sat_thr = cv_uniform(65504.f / fmaxf(block_amax(tm, red), 1e-30f));
             __syncthreads();
         }
     };
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     // ---- epilogue: class (py, px), position (gy, gx) -> output pixel (2*gy + py, 2*gx + px)
     const int GHc = P.IH + 1 - py, GWc = P.IW + 1 - px;
     const int64_t osz = (int64_t)P.N * P.OH * P.OW * P.Co;
-    cv_overflow_check();
+    if (sat_bits != 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_cv_sat, 1u);
     const float oalpha = P.alpha * unscale;                   // exact: the exponents are powers of two
 #pragma unroll
     for (int j = 0; j < NJ; j++) {

@@ -166,6 +166,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     // position tiles x 2 staging items each (4096 values per operand), then 2^e is folded into the LDS scale tables.
     float punscale;   // 2^-(e_gy + e_x): applied to the partial tile on its way to the workspace
     float xsa, xsb;   // 2^e_gy, 2^e_x (SGPRs: the multiplier of layers without per-channel scales)
+    // Saturation tracking (conv_common.h) without a live VGPR — this kernel has none to spare (two extra ones cost 24-200
+    // spilled registers): a converted item whose raw maximum exceeds thr = 65504 / (largest scale x exponent of the block's
+    // table) sets the wave's bit mask, which lives in SGPRs (a ballot result is wave-uniform).
+    [[maybe_unused]] float thr_a = 3.0e38f, thr_b = 3.0e38f;
+    unsigned long long sat_bits = 0;
+    // Shipping build: OFF in this kernel — its whole-tile forms sit at exactly 512 registers, the three compares per item cost
+    // 17-21 spilled registers and 1.5 % of a train step (same-box A/B).  The forward / data-gradient kernel (conv.hip) tracks
+    // always: every tensor this kernel converts is also an operand there in the same step (x in fprop, gy in dgrad).  The
+    // experiment build (make abl, -DRICK_ABLATION) tracks here too; tools/stability.py runs on it.
+#ifdef RICK_ABLATION
+#define WG_TRACK(v, thr) sat_bits |= __builtin_amdgcn_ballot_w64(fmaxf(fmaxf(fabsf((v).x), fabsf((v).y)), fmaxf(fabsf((v).z), fabsf((v).w))) > (thr))
+#else
+#define WG_TRACK(v, thr) (void)0
+#endif
     {
         float ma = 0.f, mb = 0.f;
         const int nt = tile_end - tile_begin;
@@ -215,8 +229,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         xsa = cv_uniform(sa);
         xsb = cv_uniform(sb);
         __syncthreads();                                    // every thread has read `red`
-        for (int i = threadIdx.x; i < g.N * CV_BM; i += 256) sA[i] *= sa;
-        for (int i = threadIdx.x; i < g.N * CV_CK; i += 256) sB[i] *= sb;
+        float ta = 0.f, tb = 0.f;
+        for (int i = threadIdx.x; i < g.N * CV_BM; i += 256) ta = fmaxf(ta, fabsf(sA[i] *= sa));
+        for (int i = threadIdx.x; i < g.N * CV_CK; i += 256) tb = fmaxf(tb, fabsf(sB[i] *= sb));
+        thr_a = cv_uniform(65504.f / fmaxf(block_amax(ta, red), 1e-30f));
+        thr_b = cv_uniform(65504.f / fmaxf(block_amax(tb, red + 8), 1e-30f));
         __syncthreads();
     }
 
@@ -262,6 +279,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             const bool ok = (okmask >> k) & 1u;
             float4 v = gq[k];
             if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            WG_TRACK(v, thr_a);
             uint2 hi, lo;
             split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sA + (ok ? (st_n0 + (int)(g_pyx[k] >> 20)) * CV_BM : 0) + gc4 * 4), hi, lo);
             *reinterpret_cast<uint2 *>(gh + g_lds[k]) = hi;
@@ -272,6 +290,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             const bool ok = (okmask >> (8 + k)) & 1u;
             float4 v = pq[k];
             if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            WG_TRACK(v, thr_b);
             uint2 hi, lo;
             split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sB + (ok ? (st_n0 + (int)(p_pyx[k] >> 20)) * CV_CK : 0) + pc4 * 4), hi, lo);
             *reinterpret_cast<uint2 *>(ph + p_lds[k]) = hi;
@@ -413,6 +432,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                     *reinterpret_cast<float2 *>(buf + 2 * WG_GY_BYTES + (t.NPP + 1) * 64 + p_lds[K - 8]) = make_float2(v.z, v.w);
                 } else if constexpr (K < 8) {
                     const float4 v = gq[K];
+                    WG_TRACK(v, thr_a);
                     if constexpr (FAST == 2) {     // modulated layers (G) carry per-(image, channel) scales (x block exponent)
                         if constexpr (ONE_IMG) split4v_mix<SPLIT>(v, sa_cv, hi, lo);
                         else split4v_mix<SPLIT>(v, *reinterpret_cast<const float4 *>(sA + (cv_n0 + (int)(g_pyx[K] >> 20)) * CV_BM + gc4 * 4), hi, lo);
@@ -421,6 +441,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                     *reinterpret_cast<uint2 *>(buf + WG_GY_BYTES + g_lds[K]) = lo;
                 } else {
                     const float4 v = pq[K - 8];
+                    WG_TRACK(v, thr_b);
                     if constexpr (FAST == 2) {     // (an out-of-range item read the zero page: 0 * scale stays 0)
                         if constexpr (ONE_IMG) split4v_mix<SPLIT>(v, sb_cv, hi, lo);
                         else split4v_mix<SPLIT>(v, *reinterpret_cast<const float4 *>(sB + (cv_n0 + (int)((p_pyx[K - 8] >> 20) & 15)) * CV_CK + pc4 * 4), hi, lo);
@@ -431,6 +452,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             } else if constexpr (K < 8) {
                 float4 v = gq[K];
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                WG_TRACK(v, thr_a);
                 uint2 hi, lo;
                 if constexpr (ONE_IMG) split4v<SPLIT>(v, sa_cv, hi, lo);
                 else split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sA + (ok ? (cv_n0 + (int)(g_pyx[K] >> 20)) * CV_BM : 0) + gc4 * 4), hi, lo);
@@ -440,6 +462,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                 constexpr int P = K - 8;
                 float4 v = pq[P];
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                WG_TRACK(v, thr_b);
                 uint2 hi, lo;
                 if constexpr (ONE_IMG) split4v<SPLIT>(v, sb_cv, hi, lo);
                 else split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sB + (ok ? (cv_n0 + (int)(p_pyx[P] >> 20)) * CV_CK : 0) + pc4 * 4), hi, lo);
@@ -542,7 +565,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         else run(std::false_type{});
     }
 
-    cv_overflow_check();
+    if (sat_bits != 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_cv_sat, 1u);
     // ---- partial tile -> workspace [split][cot][chunk][tap][32 ci][128 co]: a lane's 4 accumulator
     // registers are 4 consecutive co of one ci, so the [ci][co] order makes every store a float4
     float *wsb = ws + (((int64_t)split * t.ncot + cot) * t.nchunks + chunk) * g.ntaps * (CV_BM * CV_CK);

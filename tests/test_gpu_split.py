@@ -236,17 +236,24 @@ def test_discriminator_chain_passes_images_and_maxima():
         if mode:
             # one stand-alone pack (+ its maximum) for the chain's input, one maximum for the gradient entering the chain
             assert calls == {'pack': 1, 'amax': 2}, calls
-    for a, b in zip(res[True], res[False]):
-        assert float((a - b).abs().max() / b.abs().max()) < 3e-5
+    # (two blocks deep a ~0 pre-activation may take the other LeakyReLU branch in the two fp32 evaluations: L2, and the share of
+    # entries that moved)
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        e = float((a - b).norm() / b.norm())
+        moved = float(((a - b).abs() > 1e-4 * b.abs().max()).float().mean())
+        assert e < 1e-3 and moved < 2e-3, (i, e, moved)
 
 
 @pytest.mark.saturates
 def test_on_the_fly_split_counts_what_its_sampled_exponent_misses():
     """The kernels that split fp32 operands themselves take the exponent from a sample of the block's data (MODE.FP16_OVFL on:
     a value ~8 000 x above every sample clamps to 65504, finite and wrong).  The clamp is counted through the hardware's
-    sticky overflow status: a spike 10^5 x above the rest at a position the sample does not visit makes
-    rick_saturation_count() non-zero, in the forward, data-gradient and weight-gradient kernels alike; the same launches on
-    well-scaled data leave it at zero (and so does every other GPU test: tests/conftest.py)."""
+    tracked operand maximum: a spike 10^5 x above the rest at a position the sample does not visit makes
+    rick_saturation_count() non-zero (the forward / data-gradient kernel tracks in the shipping library; the weight-gradient
+    and transposed kernels, which have no register to spare, only in the experiment build: csrc/wgrad.hip); the same launches on
+    well-scaled data leave it at zero (and so does every other GPU test: tests/conftest.py).  (The counter is fed by two
+    v_max3 per four converted elements; the hardware's sticky overflow status would have been free but stays 0 with traps
+    disabled on this chip — tools/micro/trapsts.hip.)"""
     from rick_amd.op import conv as cv
     torch.manual_seed(0)
     N, C, H = 4, 256, 64
