@@ -245,6 +245,10 @@ int rick_bias_act_bwd_split_f32(const float *g, const float *ref, void *out1, fl
                                 float mul2, const float *amax_g, float *gb, float *gnw, const float *noise,
                                 int64_t rows, int C, int64_t rows_per_img, int64_t noise_nb, int64_t noise_hw,
                                 float alpha, float scale, float *partials, int accumulate, void *stream);
+/* The discriminator's input layer (model_probe_tune.py:679: 1x1 conv of the planar image t [N, J, P] with W [J, C], then
+ * FusedLeakyReLU) in one pass: x[n,p,c] = gain * lrelu(sum_j t[n,j,p] * W[j,c] + bias[c]); ex (may be NULL) adds a split image. */
+int rick_d_input_f32(const float *t, const float *W, const float *bias, float *x, int N, int64_t P, int C, int J,
+                     float slope, float gain, const rick_split_out *ex, void *stream);
 int rick_add_scale_split_f32(const float *a, const float *b, float *y, void *y_split, float *hdr,
                              const float *amax_a, const float *amax_b, int64_t rows, int C, float alpha, void *stream);
 int rick_split_pack_f32(const float *x, void *out, float *hdr, const float *amax0, const float *amax1, float coef,

@@ -67,6 +67,7 @@ SIGNATURES = {
                                                                                  ctypes.POINTER(SplitOut), c_fp]),
     'rick_bias_act_bwd_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_i64,
                                             c_i64, c_i64, c_f, c_f, c_fp, c_int, c_fp]),
+    'rick_d_input_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_int, c_f, c_f, ctypes.POINTER(SplitOut), c_fp]),
     'rick_add_scale_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_f, c_fp]),
     'rick_conv_igemm_split_supported': (c_int, [ctypes.POINTER(ConvGeom)]),
     'rick_conv_igemm_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue),

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     }
     float unscale = 1.f, xscale = 1.f;                        // set by block_exponent() once the first chunk is in registers
     // saturation tracking without a live VGPR (see wgrad.hip): raw item maximum against 65504 / (largest scale x exponent)
-    float sat_thr = 3.0e38f;
+    [[maybe_unused]] float sat_thr = 3.0e38f;
     unsigned long long sat_bits = 0;
     float4 pq[CT_PITEMS];
     unsigned cur_ok = 0;

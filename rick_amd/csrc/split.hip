@@ -57,14 +57,15 @@ extern "C" int rick_sat_elementwise(unsigned *, int);
 extern "C" int rick_sat_conv(unsigned *, int);
 extern "C" int rick_sat_wgrad(unsigned *, int);
 extern "C" int rick_sat_convt2(unsigned *, int);
+extern "C" int rick_sat_thin(unsigned *, int);
 
 extern "C" int rick_saturation_count(unsigned *count, int reset) {
     if (!count) return RICK_EINVAL;
-    unsigned a = 0, b = 0, c = 0, d = 0, e = 0, f = 0;
+    unsigned a = 0, b = 0, c = 0, d = 0, e = 0, f = 0, g = 0;
     if (rick_sat_split(&a, reset) || rick_sat_upfirdn2d(&b, reset) || rick_sat_elementwise(&c, reset) || rick_sat_conv(&d, reset) ||
-        rick_sat_wgrad(&e, reset) || rick_sat_convt2(&f, reset))
+        rick_sat_wgrad(&e, reset) || rick_sat_convt2(&f, reset) || rick_sat_thin(&g, reset))
         return 1;
-    *count = a + b + c + d + e + f;
+    *count = a + b + c + d + e + f + g;
     return 0;
 }
 

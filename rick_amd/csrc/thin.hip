@@ -3,7 +3,7 @@
 // wavefront shuffles, reductions over pixels are two-stage and deterministic.
 //   ToRGB (model_probe_tune.py:351-370):  rgb[n,j,p] = sum_c x[n,p,c] * (scale*w[j,c]*s[n,c]) + ...
 //   D input conv (model_probe_tune.py:679): y[n,p,co] = sum_j img[n,j,p] * (scale*w[co,j])
-#include "common.h"
+#include "conv_common.h"
 
 #define THIN_MAXJ 4
 
@@ -206,6 +206,75 @@ __global__ __launch_bounds__(256) void thin_bwdx_kernel(const float *__restrict_
         xn[i4] = acc;
     }
 }
+
+// The discriminator's input layer in one pass (model_probe_tune.py:679 + its FusedLeakyReLU): x = gain * lrelu(sum_j t_j W[j,c]
+// + b[c]), written as fp32 and — for the first ResBlock's convolutions — as a split image (conv_common.h).  Same operation order
+// as thin_bwdx_kernel followed by bias_act_kernel: bit-identical values, without writing the 128-channel map twice and reading
+// it once in between.
+__global__ __launch_bounds__(256) void d_input_kernel(const float *__restrict__ t, const float *__restrict__ W,
+                                                      const float *__restrict__ bias, float *__restrict__ x, int64_t P, int C,
+                                                      int J, float slope, float gain, rick_split_out xo) {
+    const int n = blockIdx.y;
+    const int C4 = C >> 2;
+    const int64_t total4 = P * C4;
+    const float *tn = t + (int64_t)n * J * P;
+    float4 *xn = reinterpret_cast<float4 *>(x + (int64_t)n * P * C);
+    float sscale = 1.f, am = 0.f;
+    if (xo.split_out) {
+        const cv_split_hdr h = cv_split_header(xo.bound0, xo.bound1, xo.bound_coef);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *reinterpret_cast<cv_split_hdr *>(xo.split_hdr) = h;
+        sscale = cv_uniform(h.scale);
+    }
+    unsigned char *sn = (unsigned char *)xo.split_out + (int64_t)n * P * C * 4;
+    for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * 256) {
+        const int64_t p = i4 / C4;
+        const int c4 = (int)(i4 - p * C4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float tv[THIN_MAXJ];
+        float4 wv[THIN_MAXJ];
+#pragma unroll
+        for (int j = 0; j < THIN_MAXJ; j++) {
+            const int jj = j < J ? j : J - 1;
+            tv[j] = tn[(int64_t)jj * P + p];
+            wv[j] = *reinterpret_cast<const float4 *>(W + (int64_t)jj * C + c4 * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < THIN_MAXJ; j++) {
+            const float tj = j < J ? tv[j] : 0.f;
+            acc.x += tj * wv[j].x; acc.y += tj * wv[j].y; acc.z += tj * wv[j].z; acc.w += tj * wv[j].w;
+        }
+        const float4 bv = *reinterpret_cast<const float4 *>(bias + c4 * 4);
+        acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
+        float4 y;
+        y.x = (acc.x > 0.f ? acc.x : acc.x * slope) * gain;
+        y.y = (acc.y > 0.f ? acc.y : acc.y * slope) * gain;
+        y.z = (acc.z > 0.f ? acc.z : acc.z * slope) * gain;
+        y.w = (acc.w > 0.f ? acc.w : acc.w * slope) * gain;
+        xn[i4] = y;
+        if (xo.split_out) {
+            cv_split_store4(sn + i4 * 16, 0, y, sscale);
+            am = amax4(am, y);
+        }
+    }
+    if (xo.split_out) cv_sat_check(am, sscale);
+}
+
+extern "C" int rick_d_input_f32(const float *t, const float *W, const float *bias, float *x, int N, int64_t P, int C, int J,
+                                float slope, float gain, const rick_split_out *ex, void *stream) {
+    if (!x || !W || !t || !bias || N <= 0 || P <= 0 || C <= 0 || C % 4 || J < 1 || J > THIN_MAXJ || N > 65535) return RICK_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)W | (uintptr_t)bias) % 16) return RICK_EINVAL;
+    rick_split_out xo = {nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, 0, 0};
+    if (ex) {
+        xo = *ex;
+        if (xo.split_out && (!xo.split_hdr || !xo.bound0 || !(xo.bound_coef > 0.f) || ((uintptr_t)xo.split_out % 16))) return RICK_EINVAL;
+    }
+    int64_t nb = cdiv64(P * (C / 4), 256 * 2);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(d_input_kernel, dim3((unsigned)nb, N), dim3(256), 0, (hipStream_t)stream, t, W, bias, x, P, C, J, slope, gain, xo);
+    RICK_LAUNCH_STATUS();
+}
+
+CV_DEFINE_SAT_ACCESSOR(rick_sat_thin)
 
 static int thin_bwdx_launch(const float *t, const float *W, int64_t w_bstride, float *x, int N, int64_t P, int C, int J, ThinMod m,
                             void *stream) {

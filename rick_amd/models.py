@@ -466,6 +466,17 @@ class ConvLayer(nn.Sequential):
     def forward(self, x):
         # conv -> bias + LeakyReLU as ONE launch (tail in the MFMA kernel's epilogue) when only first derivatives are
         # needed; the child modules (and their state_dict keys) stay exactly the reference's
+        if (_USE_DBLOCK and not self._fusable and len(self) == 2 and isinstance(self[1], FusedLeakyReLU) and x.is_cuda
+                and x.dtype == torch.float32 and not op.second_order_enabled() and op.get_precision() == 'fp16x3'):
+            conv, act = self[0], self[1]
+            O, I, k, _ = conv.weight.shape
+            if I <= 4 and k == 1 and conv.stride == 1 and conv.bias is None and O % 4 == 0:
+                # image -> features (the discriminator's input layer): one launch, fp32 + the split image the first ResBlock reads
+                from .op import dblock
+                return dblock.d_input(x, conv.weight, act.bias, conv.scale, act.negative_slope, act.scale,
+                                      lambda x_, w_, b_: fused_leaky_relu(
+                                          op.thin_bwdx(x_.contiguous(), (w_.view(O, I) * conv.scale).t().unsqueeze(0)), b_,
+                                          act.negative_slope, act.scale))
         if not self._fusable or op.second_order_enabled():
             return super().forward(x)
         mods = list(self)

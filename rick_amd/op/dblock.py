@@ -211,3 +211,60 @@ class _DResBlock(Function):
 
 def d_resblock(x, w1, b1, w2, b2, ws, taps, cfg):
     return _DResBlock.apply(x, w1, b1, w2, b2, ws, taps, cfg)
+
+
+class _DInput(Function):
+    """The discriminator's input layer (model_probe_tune.py:679-680: 1x1 EqualConv2d 3 -> C without bias, FusedLeakyReLU) as one
+    launch that writes the activation as fp32 and as the split image the first ResBlock's convolutions read — bit-identical to
+    thin_bwdx -> fused_leaky_relu, without the 3 extra passes over the 128-channel map (and the stand-alone maximum + pack passes
+    the first block would otherwise need).  Bound of the image: gain * (J * max |W| * max |img| + max |b|)."""
+
+    @staticmethod
+    def forward(ctx, img, weight, bias, wscale, slope, gain, compose):
+        O, J = weight.shape[0], weight.shape[1]
+        n, _, h, w = img.shape
+        t = img.contiguous()
+        W = (weight.view(O, J) * wscale).t().contiguous()           # [J, C], the per-layer path's own expression
+        bc = bias.contiguous()
+        x = torch.empty((n, O, h, w), device=img.device, dtype=torch.float32, memory_format=torch.channels_last)
+        pk = sp.SplitImage(torch.empty_like(x), sp.new_words(4, img.device))
+        a_img = sp.amax(t)
+        # (a tensor of its own: an in-place write into an arena slice would bump the version counter every saved header shares)
+        bound = torch.nn.functional.pad((gain * (J * W.abs().max() * sp.amax_value(a_img) + bc.abs().max())).reshape(1),
+                                        (0, sp.AMAX_FLOATS - 1))
+        pk.bound = (bound, None, 1.0)
+        ex = SplitOut()
+        ex.split_out, ex.split_hdr, ex.bound0, ex.bound1, ex.bound_coef = ptr(pk.data), ptr(pk.hdr), ptr(bound), None, 1.0
+        check(lib.rick_d_input_f32(ptr(t), ptr(W), ptr(bc), ptr(x), n, h * w, O, J, float(slope), float(gain), ctypes.byref(ex),
+                                   stream_ptr()), 'rick_d_input_f32')
+        x._rick_split = pk
+        ctx.save_for_backward(img, weight, bias, x, W)
+        ctx.cfg = (wscale, slope, gain, compose)
+        ctx.sink = grad_sink_enabled()
+        ctx.plike = (False, param_like(weight), param_like(bias))
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        from .fused_act import _ActAdjoint
+        from .misc import _ThinFwd, _ThinWgrad
+        img, weight, bias, x, W = ctx.saved_tensors
+        wscale, slope, gain, compose = ctx.cfg
+        if torch.is_grad_enabled():
+            from ._twice import second_order_backward
+            res = second_order_backward(compose, (img, weight, bias), ctx.needs_input_grad[:3], g, ctx.plike)
+            return (*res, None, None, None, None)
+        O, J = weight.shape[0], weight.shape[1]
+        need_w = ctx.needs_input_grad[1] and not skip_param_grad(ctx.plike[1])
+        need_b = ctx.needs_input_grad[2] and not skip_param_grad(ctx.plike[2])
+        gz, gb, _ = _ActAdjoint.apply(g, x, None, slope, gain, need_b, False, param_sink(bias, O, ctx.sink and need_b))
+        gimg = gw = None
+        if ctx.needs_input_grad[0]:
+            gimg = _ThinFwd.apply(gz, W.unsqueeze(0))
+        if need_w:
+            gw = (_ThinWgrad.apply(img, gz).sum(0).t() * wscale).reshape(weight.shape)
+        return gimg, gw, gb, None, None, None, None
+
+
+def d_input(img, weight, bias, wscale, slope, gain, compose):
+    return _DInput.apply(img, weight, bias, float(wscale), float(slope), float(gain), compose)

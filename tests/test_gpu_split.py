@@ -281,3 +281,32 @@ def test_on_the_fly_split_counts_what_its_sampled_exponent_misses():
             assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(gw).all())      # clamped, not inf: hence the counter
     assert hits > 0
     _sat(reset=True)
+
+
+def test_discriminator_input_layer_one_launch_equals_two_op_path():
+    """thin product + FusedLeakyReLU of the discriminator's first layer in one launch: values bit-identical to the two-op path,
+    the split image it emits equals the stand-alone pass's under the same bound, gradients equal."""
+    from rick_amd import models
+    from rick_amd.op import split as sp
+    torch.manual_seed(2)
+    layer = models.ConvLayer(3, 128, 1).to(DEV)
+    with torch.no_grad():
+        layer[1].bias.normal_(0, 0.2)
+    img0 = torch.randn(4, 3, 64, 64, device=DEV)
+    res = {}
+    for mode in (True, False):
+        models._USE_DBLOCK = mode
+        try:
+            img = img0.clone().requires_grad_(True)
+            y = layer(img)
+            g = torch.autograd.grad((y * y).sum(), [img, layer[0].weight, layer[1].bias])
+            res[mode] = [y.detach()] + [t.detach() for t in g]
+            if mode:
+                pk = y._rick_split
+                assert float(pk.hdr[2]) >= float(y.abs().max())
+                assert torch.equal(pk.data, sp.split_pack(y.detach(), *pk.bound).data)
+        finally:
+            models._USE_DBLOCK = True
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-6
