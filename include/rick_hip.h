@@ -145,8 +145,16 @@ typedef struct {
     int noise_nb;           /* 1 (shared map) or N */
     int act;                /* 0: none, 1: LeakyReLU(slope) * gain */
     float slope, gain;
-    float *amax;            /* NULL, or a device word: max |out| is folded into it with an atomic max (the exact bound the
-                             * producer of the next split image needs; see "Split images" below) */
+    float *amax;            /* NULL, or an amax word: max |out| is folded into it (the exact bound the producer of the next
+                             * split image needs; see "Split images" below) */
+    /* also write out * split_scale[n, co] as a split image (the next modulated convolution's operand: its style scale
+     * folded in; split_scale may be NULL), bounded by split_coef * (*split_bound) * ... — the caller's bound covers the scale.
+     * Launches without split-K only (rick_conv_igemm_workspace_bytes(g) == 0). */
+    void *split_out;
+    float *split_hdr;
+    const float *split_bound;   /* amax word */
+    float split_coef;
+    const float *split_scale;   /* [N, Co] or NULL */
 } rick_conv_epilogue;
 int rick_conv_igemm_f32(const float *x, const void *packed_w, float *out,
                         const float *iscale, const float *oscale,
@@ -225,6 +233,8 @@ typedef struct {
     float *amax;            /* NULL, or: fold max |result| (after accumulation) into this word */
     int accumulate;         /* add the result to what the fp32 output holds (a second gradient arriving at a branch point) */
     int no_f32;             /* do not write the fp32 result (the output pointer may be NULL) */
+    const float *chan_scale;/* NULL, or [N, C]: the split image holds result * chan_scale[n, c] (a modulated convolution's
+                             * style / demodulation scale folded in; the bound must cover it) */
 } rick_split_out;
 /* Saturation events since the last reset, host-synchronous: values that exceeded a split-image producer's bound (a caller's
  * mistake) and waves of the igemm / convt2 / wgrad kernels that clamped an fp32 -> fp16 conversion of an on-the-fly split
@@ -249,6 +259,20 @@ int rick_bias_act_bwd_split_f32(const float *g, const float *ref, void *out1, fl
  * FusedLeakyReLU) in one pass: x[n,p,c] = gain * lrelu(sum_j t[n,j,p] * W[j,c] + bias[c]); ex (may be NULL) adds a split image. */
 int rick_d_input_f32(const float *t, const float *W, const float *bias, float *x, int N, int64_t P, int C, int J,
                      float slope, float gain, const rick_split_out *ex, void *stream);
+/* Bound of an activation tail for the producers above, evaluated on the device (one tiny launch, no host sync):
+ *   out[slot 0] = max|mul| * gain * (c0 * amax(w0) + max|nw| * amax(w_noise) + max|bias|)
+ * — |gain * lrelu(v + nw * noise + bias) * mul[n,c]| for |v| <= c0 * amax(w0).  Any of nw / w_noise, bias, mul may be NULL
+ * (term dropped / factor 1).  out is an amax word (the other slots are zeroed). */
+int rick_bound_tail_f32(float *out_word, const float *w0, float c0, const float *nw, const float *w_noise,
+                        const float *bias, int nbias, float gain, const float *mul, int nmul, void *stream);
+/* rick_bias_act_bwd_split_f32 for modulated layers: image 1 = adjoint * chan_scale[n, c] (chan_scale [rows / rows_per_img, C]),
+ * bounded by the amax word bound1 alone (|scale| * max |chan_scale| * max |g|, combined by rick_bound_tail_f32); out_f32
+ * (may be NULL) also receives the unscaled adjoint. */
+int rick_bias_act_bwd_split2_f32(const float *g, const float *ref, void *out1, float *hdr1, void *out2, float *hdr2,
+                                 float mul2, const float *amax_g, const float *chan_scale, const float *bound1,
+                                 float *out_f32, float *gb, float *gnw, const float *noise,
+                                 int64_t rows, int C, int64_t rows_per_img, int64_t noise_nb, int64_t noise_hw,
+                                 float alpha, float scale, float *partials, int accumulate, void *stream);
 int rick_add_scale_split_f32(const float *a, const float *b, float *y, void *y_split, float *hdr,
                              const float *amax_a, const float *amax_b, int64_t rows, int C, float alpha, void *stream);
 int rick_split_pack_f32(const float *x, void *out, float *hdr, const float *amax0, const float *amax1, float coef,
@@ -267,7 +291,8 @@ int rick_conv_igemm_split_f32(const void *x_split, const float *x_hdr, const voi
                               const float *oscale, const rick_conv_geom *g, const rick_conv_epilogue *epilogue,
                               void *workspace, void *stream);
 int rick_convt2_split_f32(const void *x_split, const float *x_hdr, const void *packed_w, float *out, const float *oscale,
-                          int N, int IH, int IW, int Ci, int Co, int OH, int OW, float alpha, void *workspace, void *stream);
+                          int N, int IH, int IW, int Ci, int Co, int OH, int OW, float alpha, float *amax /* word or NULL */,
+                          void *workspace, void *stream);
 int rick_conv_wgrad_split_f32(const void *x, const float *x_hdr, const void *gy, const float *gy_hdr, float *gw,
                               int64_t s_co, int64_t s_ci, int64_t s_t, const rick_conv_geom *g, int accumulate,
                               void *workspace, void *stream);

@@ -37,13 +37,14 @@ class ConvGeom(ctypes.Structure):
 class ConvEpilogue(ctypes.Structure):
     """rick_conv_epilogue (include/rick_hip.h)."""
     _fields_ = [('bias', c_fp), ('noise', c_fp), ('noise_w', c_fp), ('noise_nb', c_int), ('act', c_int),
-                ('slope', c_f), ('gain', c_f), ('amax', c_fp)]
+                ('slope', c_f), ('gain', c_f), ('amax', c_fp), ('split_out', c_fp), ('split_hdr', c_fp), ('split_bound', c_fp),
+                ('split_coef', c_f), ('split_scale', c_fp)]
 
 
 class SplitOut(ctypes.Structure):
     """rick_split_out (include/rick_hip.h)."""
     _fields_ = [('split_out', c_fp), ('split_hdr', c_fp), ('bound0', c_fp), ('bound1', c_fp), ('bound_coef', c_f),
-                ('amax', c_fp), ('accumulate', c_int), ('no_f32', c_int)]
+                ('amax', c_fp), ('accumulate', c_int), ('no_f32', c_int), ('chan_scale', c_fp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/rick_hip.h
@@ -72,7 +73,10 @@ SIGNATURES = {
     'rick_conv_igemm_split_supported': (c_int, [ctypes.POINTER(ConvGeom)]),
     'rick_conv_igemm_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue),
                                           c_fp, c_fp]),
-    'rick_convt2_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp] + [c_int] * 7 + [c_f, c_fp, c_fp]),
+    'rick_convt2_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp] + [c_int] * 7 + [c_f, c_fp, c_fp, c_fp]),
+    'rick_bound_tail_f32': (c_int, [c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_int, c_f, c_fp, c_int, c_fp]),
+    'rick_bias_act_bwd_split2_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64,
+                                             c_int, c_i64, c_i64, c_i64, c_f, c_f, c_fp, c_int, c_fp]),
     'rick_conv_packed_bytes': (c_i64, [c_int, c_int, c_int]),
     'rick_conv_pack_weight': (c_int, [c_fp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_f, c_int, c_fp, c_fp]),
     'rick_conv_pack_blocks': (c_int, [c_int, c_int]),

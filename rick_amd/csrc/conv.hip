@@ -699,6 +699,13 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     const float oalpha = g.alpha * unscale;   // exact: the exponents are powers of two
     const float nwv = epi.noise ? epi.noise_w[0] : 0.f;
     float out_amax = 0.f;      // running max |out| of this thread's stores (epi.amax)
+    // split image of the output (the next modulated convolution's operand, its style folded in): epi.split_out
+    float so_scale = 1.f, so_amax = 0.f;
+    if (epi.split_out) {
+        const cv_split_hdr h = cv_split_header(epi.split_bound, nullptr, epi.split_coef);
+        if (bid == 0 && threadIdx.x == 0) *reinterpret_cast<cv_split_hdr *>(epi.split_hdr) = h;
+        so_scale = cv_uniform(h.scale);
+    }
     auto epilogue = [&](auto HAS_OS, auto HAS_EP) {
         constexpr bool OS = decltype(HAS_OS)::value;
         constexpr bool EP = decltype(HAS_EP)::value;   // fused bias (+ noise) + LeakyReLU tail (rick_conv_epilogue)
@@ -765,6 +772,14 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                         }
                         *reinterpret_cast<float4 *>(orow + co) = v;
                         out_amax = amax4(out_amax, v);
+                        if (epi.split_out) {
+                            if (epi.split_scale) {
+                                const float4 cs = *reinterpret_cast<const float4 *>(epi.split_scale + (int64_t)n * g.Co + co);
+                                v = make_float4(v.x * cs.x, v.y * cs.y, v.z * cs.z, v.w * cs.w);
+                            }
+                            so_amax = amax4(so_amax, v);
+                            cv_split_store4(reinterpret_cast<unsigned char *>(epi.split_out) + opix * g.Co * 4, co, v, so_scale);
+                        }
                     }
                 }
                 continue;
@@ -795,6 +810,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     else if (has_ep) epilogue(std::false_type{}, std::true_type{});
     else epilogue(std::false_type{}, std::false_type{});
     cv_sat_report(satm);
+    if (epi.split_out) cv_sat_check(so_amax, so_scale);
     if (epi.amax && t.nsplit == 1) cv_amax_publish(out_amax, epi.amax, reinterpret_cast<float *>(smem));     // (split-K: the second stage measures)
 }
 
@@ -836,7 +852,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_multi_kernel(const float *_
         }
     // every parity class of a transposed conv has a patch of <= 160 pixels (tile + at most one halo row/col)
     // (the host only uses this kernel when every class qualifies for the two-ahead prefetch)
-    const rick_conv_epilogue none = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f, nullptr};
+    const rick_conv_epilogue none = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr};
     igemm_body<SPLIT, VEC, true, 4, 0>(x, wpk, out, iscale, oscale, ws + m.ws_off[c], m.g[c], m.t[c], (int)blockIdx.x - start,
                                        m.blk_end[c] - start, none);
 }
@@ -908,7 +924,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float *_
     }
 }
 
-static const rick_conv_epilogue kNoEpilogue = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f, nullptr};
+static const rick_conv_epilogue kNoEpilogue = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr};
 
 static void launch_splitk_reduce(const float *ws, float *out, const float *oscale, const rick_conv_geom *g, int nsplit,
                                  hipStream_t st, const rick_conv_epilogue &epi = kNoEpilogue) {
@@ -1031,6 +1047,9 @@ static int igemm_run(const float *x, const void *packed_w, float *out, const flo
         if (epi.noise && (!epi.noise_w || (epi.noise_nb != 1 && epi.noise_nb != g->N))) return RICK_EINVAL;
         // the tail is applied on float4 channel groups: Co % 4 == 0, 16-byte aligned bias
         if ((epi.bias || epi.noise || epi.act) && ((g->Co & 3) || ((uintptr_t)(epi.bias ? epi.bias : x) % 16))) return RICK_EINVAL;
+        if (epi.split_out && ((g->Co & 3) || !epi.split_hdr || !epi.split_bound || !(epi.split_coef > 0.f) ||
+                              (((uintptr_t)epi.split_out | (uintptr_t)(epi.split_scale ? epi.split_scale : x)) % 16)))
+            return RICK_EINVAL;
     }
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed_w | (uintptr_t)(iscale ? iscale : x) | (uintptr_t)(oscale ? oscale : x)) % 16)
         return RICK_EINVAL;
@@ -1038,6 +1057,7 @@ static int igemm_run(const float *x, const void *packed_w, float *out, const flo
     if (make_tiling(g, igemm_tile_positions(g), &t)) return RICK_EINVAL;
     igemm_plan_split(&t, g->ntaps);
     if (t.nsplit > 1 && (!workspace || ((uintptr_t)workspace % 16))) return RICK_EINVAL;
+    if (t.nsplit > 1 && epi.split_out) return RICK_EINVAL;          // (the split-K second stage writes no image)
     const size_t lds = igemm_lds_bytes(t, iscale != nullptr);
     if (lds > 160 * 1024 || t.PH > 1023 || t.PW > 1023) return RICK_EINVAL;
     const int64_t nwg = (int64_t)t.ntx * t.nty * t.ntn * t.ncot * t.nsplit;

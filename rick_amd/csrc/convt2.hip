@@ -49,6 +49,7 @@ struct Ct2Plan {
     // lane slot (j * 16 + l15) -> tile position (bit 7: slot unused), 4 slots per word; a permutation that makes every
     // ds_read_b128 of the patch conflict-free (ct2_position_map)
     unsigned posw[32];
+    float *amax;                    // NULL, or an amax word: max |out| is folded into it (conv_common.h)
 };
 
 // PKX: x is a split image (conv_common.h), `iscale` its header; staging copies 16-byte granules (see conv.hip).
@@ -338,6 +339,7 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
     const int64_t osz = (int64_t)P.N * P.OH * P.OW * P.Co;
     if (sat_bits != 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_cv_sat, 1u);
     const float oalpha = P.alpha * unscale;                   // exact: the exponents are powers of two
+    float out_amax = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
         const unsigned ent = (slotpos[j >> 2] >> (8 * (j & 3))) & 255u;
@@ -373,17 +375,22 @@ __global__ __launch_bounds__(CT_THREADS) void convt2_kernel(const float *__restr
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int co = cot * CV_BM + h * 64 + i * 16 + kg * 4;
-            if (co < P.Co)
-                *reinterpret_cast<float4 *>(orow + co) = make_float4(acc[i][j][0] * sc[i].x, acc[i][j][1] * sc[i].y,
-                                                                     acc[i][j][2] * sc[i].z, acc[i][j][3] * sc[i].w);
+            if (co < P.Co) {
+                const float4 o = make_float4(acc[i][j][0] * sc[i].x, acc[i][j][1] * sc[i].y, acc[i][j][2] * sc[i].z, acc[i][j][3] * sc[i].w);
+                *reinterpret_cast<float4 *>(orow + co) = o;
+                if constexpr (PKX) out_amax = amax4(out_amax, o);        // (only the split-image entry takes an amax word)
+            }
         }
     }
+    if constexpr (PKX)
+        if (P.amax && P.nsplit == 1) cv_amax_publish(out_amax, P.amax, reinterpret_cast<float *>(smem));
 }
 
 // out[i] = alpha * oscale[n, co] * sum_s ws[s][i]   (ws in output layout; Co % 4 == 0)
 __global__ __launch_bounds__(256) void convt2_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
                                                             const float *__restrict__ oscale, int64_t n4, int64_t per_img4,
-                                                            int co4, int nsplit, float alpha) {
+                                                            int co4, int nsplit, float alpha, float *__restrict__ amax) {
+    float am = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 *src = reinterpret_cast<const float4 *>(ws) + i;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -399,7 +406,13 @@ __global__ __launch_bounds__(256) void convt2_reduce_kernel(const float *__restr
             s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha;
             sc = o;
         }
-        reinterpret_cast<float4 *>(out)[i] = make_float4(s.x * sc.x, s.y * sc.y, s.z * sc.z, s.w * sc.w);
+        const float4 o = make_float4(s.x * sc.x, s.y * sc.y, s.z * sc.z, s.w * sc.w);
+        reinterpret_cast<float4 *>(out)[i] = o;
+        am = amax4(am, o);
+    }
+    if (amax) {
+        __shared__ float red[4];
+        cv_amax_publish(am, amax, red);
     }
 }
 
@@ -532,7 +545,7 @@ extern "C" int64_t rick_convt2_workspace_bytes(int N, int IH, int IW, int Ci, in
 
 static int convt2_run(const float *x, const void *packed_w, float *out, const float *iscale, const float *oscale,
                       int N, int IH, int IW, int Ci, int Co, int OH, int OW, int split, float alpha,
-                      void *workspace, void *stream, bool pkx);
+                      void *workspace, void *stream, bool pkx, float *amax = nullptr);
 
 extern "C" int rick_convt2_f32(const float *x, const void *packed_w, float *out, const float *iscale, const float *oscale,
                                int N, int IH, int IW, int Ci, int Co, int OH, int OW, int split, float alpha,
@@ -542,19 +555,20 @@ extern "C" int rick_convt2_f32(const float *x, const void *packed_w, float *out,
 
 extern "C" int rick_convt2_split_f32(const void *x_split, const float *x_hdr, const void *packed_w, float *out,
                                      const float *oscale, int N, int IH, int IW, int Ci, int Co, int OH, int OW, float alpha,
-                                     void *workspace, void *stream) {
+                                     float *amax, void *workspace, void *stream) {
     if (!x_hdr || (Ci & 31)) return RICK_EINVAL;
-    return convt2_run((const float *)x_split, packed_w, out, x_hdr, oscale, N, IH, IW, Ci, Co, OH, OW, 2, alpha, workspace, stream, true);
+    return convt2_run((const float *)x_split, packed_w, out, x_hdr, oscale, N, IH, IW, Ci, Co, OH, OW, 2, alpha, workspace, stream, true, amax);
 }
 
 static int convt2_run(const float *x, const void *packed_w, float *out, const float *iscale, const float *oscale,
                       int N, int IH, int IW, int Ci, int Co, int OH, int OW, int split, float alpha,
-                      void *workspace, void *stream, bool pkx) {
+                      void *workspace, void *stream, bool pkx, float *amax) {
     if (!x || !packed_w || !out || (split != 1 && split != 2)) return RICK_EINVAL;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed_w | (uintptr_t)(iscale ? iscale : x) | (uintptr_t)(oscale ? oscale : x)) % 16)
         return RICK_EINVAL;
     Ct2Plan p;
     if (ct2_plan(N, IH, IW, Ci, Co, OH, OW, alpha, &p)) return RICK_EINVAL;
+    p.amax = amax;
     if (p.nsplit > 1 && (!workspace || ((uintptr_t)workspace % 16))) return RICK_EINVAL;
     const size_t lds = ct2_lds_bytes(p);
     if (lds > 160 * 1024) return RICK_EINVAL;
@@ -587,7 +601,7 @@ static int convt2_run(const float *x, const void *packed_w, float *out, const fl
         int64_t nb = cdiv64(n4, 256);
         if (nb > 8192) nb = 8192;
         hipLaunchKernelGGL(convt2_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float *)workspace, out, oscale, n4,
-                           (int64_t)OH * OW * Co / 4, Co / 4, p.nsplit, alpha);
+                           (int64_t)OH * OW * Co / 4, Co / 4, p.nsplit, alpha, amax);
     }
     RICK_LAUNCH_STATUS();
 }

@@ -113,6 +113,10 @@ struct BabSplit {
     cv_split_hdr *h1, *h2;
     const float *bound;          // max |g| (exact or an upper bound)
     float coef1, coef2, mul2;
+    const float *cs1;            // NULL, or [images, C]: image 1 holds adjoint * cs1[n, c] (a demodulation scale folded in)
+    int64_t rows_per_img;
+    float *f32;                  // NULL, or: also write the (unscaled) adjoint as fp32
+    const float *bound1;         // NULL, or the amax word that bounds image 1 by itself (then coef1 = 1)
 };
 
 template <bool VEC4, bool SPL = false>
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restri
     extern __shared__ float lds[];   // [256 * (VEC4 ? 4 : 1)] column partials + 4 for block_sum
     float sc1 = 1.f, sc2 = 1.f, am1 = 0.f, am2 = 0.f;
     if (SPL) {
-        const cv_split_hdr h1 = cv_split_header(sp.bound, nullptr, sp.coef1);
+        const cv_split_hdr h1 = cv_split_header(sp.bound1 ? sp.bound1 : sp.bound, nullptr, sp.coef1);
         sc1 = cv_uniform(h1.scale);
         if (blockIdx.x == 0 && threadIdx.x == 0) *sp.h1 = h1;
         if (sp.s2) {
@@ -138,8 +142,14 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restri
             *reinterpret_cast<float4 *>(op) = o;
             return;
         }
-        cv_split_store4(sp.s1 + row * C * 4, c, o, sc1);
-        am1 = amax4(am1, o);
+        if (sp.f32) *reinterpret_cast<float4 *>(sp.f32 + row * C + c) = o;
+        float4 o1 = o;
+        if (sp.cs1) {
+            const float4 cs = *reinterpret_cast<const float4 *>(sp.cs1 + (row / sp.rows_per_img) * C + c);
+            o1 = make_float4(o.x * cs.x, o.y * cs.y, o.z * cs.z, o.w * cs.w);
+        }
+        cv_split_store4(sp.s1 + row * C * 4, c, o1, sc1);
+        am1 = amax4(am1, o1);
         if (sp.s2) {
             const float4 g2 = make_float4(gv.x * sp.mul2, gv.y * sp.mul2, gv.z * sp.mul2, gv.w * sp.mul2);
             cv_split_store4(sp.s2 + row * C * 4, c, g2, sc2);
@@ -342,17 +352,38 @@ extern "C" int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx
                             accumulate, stream, nullptr);
 }
 
+extern "C" int rick_bias_act_bwd_split2_f32(const float *g, const float *ref, void *out1, float *hdr1, void *out2, float *hdr2,
+                                            float mul2, const float *amax_g, const float *chan_scale, const float *bound1,
+                                            float *out_f32, float *gb, float *gnw, const float *noise,
+                                            int64_t rows, int C, int64_t rows_per_img, int64_t noise_nb, int64_t noise_hw,
+                                            float alpha, float scale, float *partials, int accumulate, void *stream);
+
 // The activation adjoint written as split images: out1 = g * (ref > 0 ? 1 : alpha) * scale (bound |scale| * *amax_g) and,
 // when out2 != NULL, out2 = g * mul2 (bound |mul2| * *amax_g).  C % 32 == 0; gb / gnw as in rick_bias_act_bwd_f32.
 extern "C" int rick_bias_act_bwd_split_f32(const float *g, const float *ref, void *out1, float *hdr1, void *out2, float *hdr2,
                                            float mul2, const float *amax_g, float *gb, float *gnw, const float *noise,
                                            int64_t rows, int C, int64_t rows_per_img, int64_t noise_nb, int64_t noise_hw,
                                            float alpha, float scale, float *partials, int accumulate, void *stream) {
-    if (!out1 || !hdr1 || !amax_g || (C & 3) || (out2 && (!hdr2 || mul2 == 0.f)) || scale == 0.f) return RICK_EINVAL;
-    if (((uintptr_t)out1 | (uintptr_t)(out2 ? out2 : out1) | (uintptr_t)g | (uintptr_t)ref) % 16) return RICK_EINVAL;
+    return rick_bias_act_bwd_split2_f32(g, ref, out1, hdr1, out2, hdr2, mul2, amax_g, nullptr, nullptr, nullptr, gb, gnw, noise, rows,
+                                        C, rows_per_img, noise_nb, noise_hw, alpha, scale, partials, accumulate, stream);
+}
+
+// ... with image 1 scaled per (image, channel) by chan_scale[n, c] — then bounded by the amax word `bound1` alone (the caller
+// combines |scale| * max |chan_scale| * max |g| on the device: rick_bound_tail_f32) — and the unscaled adjoint optionally
+// written as fp32 too (out_f32): the generator's layers, whose demodulation gradient still reads the fp32 adjoint.
+extern "C" int rick_bias_act_bwd_split2_f32(const float *g, const float *ref, void *out1, float *hdr1, void *out2, float *hdr2,
+                                            float mul2, const float *amax_g, const float *chan_scale, const float *bound1,
+                                            float *out_f32, float *gb, float *gnw, const float *noise,
+                                            int64_t rows, int C, int64_t rows_per_img, int64_t noise_nb, int64_t noise_hw,
+                                            float alpha, float scale, float *partials, int accumulate, void *stream) {
+    if (!out1 || !hdr1 || (!amax_g && !bound1) || (C & 3) || (out2 && (!hdr2 || mul2 == 0.f || !amax_g)) || scale == 0.f) return RICK_EINVAL;
+    if (((uintptr_t)out1 | (uintptr_t)(out2 ? out2 : out1) | (uintptr_t)g | (uintptr_t)ref | (uintptr_t)(out_f32 ? out_f32 : (float *)out1)) % 16)
+        return RICK_EINVAL;
+    if (chan_scale && (!bound1 || rows_per_img <= 0 || ((uintptr_t)chan_scale % 16))) return RICK_EINVAL;
     const float slope = fabsf(alpha) > 1.f ? fabsf(alpha) : 1.f;
     const BabSplit sp = {(unsigned char *)out1, (unsigned char *)out2, (cv_split_hdr *)hdr1, (cv_split_hdr *)hdr2, amax_g,
-                         fabsf(scale) * slope, fabsf(mul2), mul2};
+                         bound1 ? 1.f : fabsf(scale) * slope, fabsf(mul2), mul2, chan_scale,
+                         rows_per_img > 0 ? rows_per_img : 1, out_f32, bound1};
     return bias_act_bwd_run(g, ref, (float *)out1, gb, gnw, noise, rows, C, rows_per_img, noise_nb, noise_hw, alpha, scale,
                             partials, accumulate, stream, &sp);
 }
@@ -369,7 +400,7 @@ static int bias_act_bwd_run(const float *g, const float *ref, float *gx, float *
     const bool vec = (C % 4 == 0) && (((uintptr_t)g | (uintptr_t)ref | (uintptr_t)gx) % 16 == 0);
     const size_t lds = (256 * 4 + 8) * sizeof(float);
     const float *nz = gnw ? noise : nullptr;
-    const BabSplit none = {nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f, 1.f};
+    const BabSplit none = {nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f, 1.f, nullptr, 1, nullptr, nullptr};
     if (sp && vec)
         hipLaunchKernelGGL((bias_act_bwd_kernel<true, true>), dim3(nb), dim3(256), lds, st, g, ref, gx, nz, partials, rows, C,
                            rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0, *sp);

@@ -93,3 +93,31 @@ extern "C" int rick_split_unpack_f32(const void *pk, const float *hdr, float *ou
                        (const cv_split_hdr *)hdr, out, n4);
     RICK_LAUNCH_STATUS();
 }
+
+// out = max|mul| * gain * (c0 * amax(w0) + max|nw| * amax(w_noise) + max|bias|)   (rick_hip.h: rick_bound_tail_f32)
+__global__ __launch_bounds__(256) void bound_tail_kernel(float *__restrict__ out, const float *__restrict__ w0, float c0,
+                                                         const float *__restrict__ nw, const float *__restrict__ w_noise,
+                                                         const float *__restrict__ bias, int nbias, float gain,
+                                                         const float *__restrict__ mul, int nmul) {
+    __shared__ float red[8];
+    float mb = 0.f, mm = 0.f;
+    for (int i = threadIdx.x; i < nbias; i += 256) mb = fmaxf(mb, fabsf(bias[i]));
+    for (int i = threadIdx.x; i < nmul; i += 256) mm = fmaxf(mm, fabsf(mul[i]));
+    mb = block_amax(mb, red);
+    mm = block_amax(mm, red + 4);
+    for (int i = threadIdx.x; i < CV_AMAX_SLOTS * CV_AMAX_STRIDE; i += 256) out[i] = 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v = c0 * cv_amax_read(w0) + mb;
+        if (nw && w_noise) v += fabsf(nw[0]) * cv_amax_read(w_noise);
+        out[0] = (mul ? mm : 1.f) * gain * v;
+    }
+}
+
+extern "C" int rick_bound_tail_f32(float *out_word, const float *w0, float c0, const float *nw, const float *w_noise,
+                                   const float *bias, int nbias, float gain, const float *mul, int nmul, void *stream) {
+    if (!out_word || !w0 || !(c0 > 0.f) || !(gain > 0.f) || nbias < 0 || nmul < 0) return RICK_EINVAL;
+    hipLaunchKernelGGL(bound_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out_word, w0, c0, nw, w_noise,
+                       bias, bias ? nbias : 0, gain, mul, mul ? nmul : 0);
+    RICK_LAUNCH_STATUS();
+}

@@ -74,11 +74,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_planar_kernel(const float *__re
 // ------------------------------------------------------------------------------- NHWC
 // blockIdx.x: pixel tile, blockIdx.y: 64-channel slab, blockIdx.z: image.
 // XO: extended result handling (rick_split_out): add into `out`, fold max |result| into a word, write a split image.
-static const rick_split_out kNoSplitOut = {nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, 0, 0};
+static const rick_split_out kNoSplitOut = {nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, 0, 0, nullptr};
 
 template <bool XO>
 __device__ __forceinline__ void ufd_store(float *dst, unsigned char *spix, int c, float4 v, const rick_split_out &xo, float sscale,
-                                          float &am) {
+                                          float &am, float &ams, int64_t n = 0, int C = 0) {
     if (!XO) {
         *reinterpret_cast<float4 *>(dst) = v;
         return;
@@ -89,7 +89,14 @@ __device__ __forceinline__ void ufd_store(float *dst, unsigned char *spix, int c
     }
     am = amax4(am, v);
     if (!xo.no_f32) *reinterpret_cast<float4 *>(dst) = v;
-    if (xo.split_out) cv_split_store4(spix, c, v, sscale);
+    if (xo.split_out) {
+        if (xo.chan_scale) {
+            const float4 cs = *reinterpret_cast<const float4 *>(xo.chan_scale + n * C + c);
+            v = make_float4(v.x * cs.x, v.y * cs.y, v.z * cs.z, v.w * cs.w);
+        }
+        ams = amax4(ams, v);
+        cv_split_store4(spix, c, v, sscale);
+    }
 }
 
 template <bool XO>
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_kernel(const float *__rest
                                                              const float *__restrict__ kern,
                                                              float *__restrict__ out, UfdParams p, int cb4, rick_split_out xo) {
     extern __shared__ float smem[];
-    float sscale = 1.f, am = 0.f;
+    float sscale = 1.f, am = 0.f, ams = 0.f;
     if (XO && xo.split_out) {
         const cv_split_hdr h = cv_split_header(xo.bound0, xo.bound1, xo.bound_coef);
         if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *reinterpret_cast<cv_split_hdr *>(xo.split_hdr) = h;
@@ -155,11 +162,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_kernel(const float *__rest
             xr += p.tiw * cb4;
         }
         const int64_t po = n * (int64_t)p.out_h * p.out_w + (int64_t)oy * p.out_w + ox;
-        ufd_store<XO>(out + po * p.minor + c0 + c4 * 4, (unsigned char *)xo.split_out + po * p.minor * 4, c0 + c4 * 4, v, xo, sscale, am);
+        ufd_store<XO>(out + po * p.minor + c0 + c4 * 4, (unsigned char *)xo.split_out + po * p.minor * 4, c0 + c4 * 4, v, xo, sscale, am, ams, n, p.minor);
     }
     if (XO) {
         if (xo.amax) cv_amax_publish(am, xo.amax, smem);
-        if (xo.split_out) cv_sat_check(am, sscale);
+        if (xo.split_out) cv_sat_check(ams, sscale);
     }
 }
 
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
                                                                 rick_conv_epilogue tail, rick_split_out xo) {
     constexpr int TIH = (TOH - 1) * DOWN + 4, TIW = (TOW - 1) * DOWN + 4, CB4 = 16;
     __shared__ float4 sx[TIH * TIW * CB4];
-    float sscale = 1.f, am = 0.f;
+    float sscale = 1.f, am = 0.f, ams = 0.f;
     if (XO && xo.split_out) {
         const cv_split_hdr h = cv_split_header(xo.bound0, xo.bound1, xo.bound_coef);
         if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *reinterpret_cast<cv_split_hdr *>(xo.split_hdr) = h;
@@ -252,12 +259,12 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
                 }
             }
             const int64_t po = n * (int64_t)p.out_h * p.out_w + (int64_t)oy * p.out_w + ox;
-            ufd_store<XO>(out + po * p.minor + c0 + c4 * 4, (unsigned char *)xo.split_out + po * p.minor * 4, c0 + c4 * 4, v, xo, sscale, am);
+            ufd_store<XO>(out + po * p.minor + c0 + c4 * 4, (unsigned char *)xo.split_out + po * p.minor * 4, c0 + c4 * 4, v, xo, sscale, am, ams, n, p.minor);
         }
     }
     if (XO) {
         if (xo.amax) cv_amax_publish(am, xo.amax, reinterpret_cast<float *>(sx));
-        if (xo.split_out) cv_sat_check(am, sscale);
+        if (xo.split_out) cv_sat_check(ams, sscale);
     }
 }
 
@@ -319,7 +326,7 @@ static int upfirdn2d_impl(const float *input, const float *kernel, float *out, i
     hipStream_t st = (hipStream_t)stream;
     if (minor % 64 == 0 && kh == 4 && kw == 4 && up_x == 1 && up_y == 1 && down_x == down_y && (down_x == 1 || down_x == 2) &&
         major <= 65535 && minor / 64 <= 65535 && (((uintptr_t)input | (uintptr_t)out) % 16 == 0)) {
-        const rick_conv_epilogue none = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f, nullptr};
+        const rick_conv_epilogue none = {nullptr, nullptr, nullptr, 1, 0, 0.f, 1.f, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr};
         if (tail) {
             if (tail->noise && (!tail->noise_w || (tail->noise_nb != 1 && tail->noise_nb != major))) return RICK_EINVAL;
             if (tail->bias && ((uintptr_t)tail->bias % 16)) return RICK_EINVAL;

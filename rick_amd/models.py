@@ -155,7 +155,7 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
 
-    def forward(self, x, style, tail=None, s=None, d=None, rgb_tail=None):
+    def forward(self, x, style, tail=None, s=None, d=None, rgb_tail=None, next_s=None):
         """tail = (bias, noise, noise_weight, negative_slope, gain): apply StyledConv's NoiseInjection + FusedLeakyReLU
         as part of this layer (fused into the blur launch of the upsampling variant; first-order mode only).
         s = modulation(style) (and d, the demodulation coefficients) when the Generator has already evaluated them for
@@ -191,10 +191,12 @@ class ModulatedConv2d(nn.Module):
                 y = self.blur(y)
             return op.chan_scale(y, d) if d is not None else y
         if tail is not None and not self.upsample and self.out_channel % 4 == 0:
-            return _mc.modulated_conv_fused(x, w, s, d, self.scale, False, key, tail)     # tail in the conv epilogue
+            return _mc.modulated_conv_fused(x, w, s, d, self.scale, False, key, tail, next_s=next_s)     # tail in the conv epilogue
         y = _mc.modulated_conv_fused(x, w, s, d, self.scale, self.upsample, key)
         if tail is not None and self.upsample:
-            return op.upfirdn2d_noise_bias_act(y, self.blur.kernel, self.blur.pad, *tail)  # tail in the blur launch
+            # tail in the blur launch; next_s / d: split-image hand-over to the next layer's forward and to this layer's backward
+            return op.upfirdn2d_noise_bias_act(y, self.blur.kernel, self.blur.pad, *tail, next_s=next_s,
+                                               bwd_scale=d if _mc._USE_SPLIT else None)
         y = self.blur(y) if self.upsample else y
         return y if tail is None else fused_noise_bias_act(y, *tail)
 
@@ -231,14 +233,14 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, x, style, noise=None, s=None, d=None):
+    def forward(self, x, style, noise=None, s=None, d=None, next_s=None):
         if noise is None:
             r = x.shape[2] * 2 if self.conv.upsample else x.shape[2]
             noise = torch.empty(x.shape[0], 1, r, r * x.shape[3] // x.shape[2], device=x.device, dtype=x.dtype).normal_()
         tail = (self.activate.bias, noise, self.noise.weight, self.activate.negative_slope, self.activate.scale)
         if op.second_order_enabled():
             return fused_noise_bias_act(self.conv(x, style, s=s, d=d), *tail)
-        return self.conv(x, style, tail, s=s)
+        return self.conv(x, style, tail, s=s, next_s=next_s)
 
 
 class ToRGB(nn.Module):
@@ -413,14 +415,19 @@ class Generator(nn.Module, _FisherMixin):
             sb = self._modulation_bank()(latent)
         elif latent.is_cuda and op.second_order_enabled() and latent.ndim == 3 and latent.shape[1] == self.n_latent:
             sb, db = self._styles_batched(latent)
-        out = self.conv1(self.input(latent), lat[0], noise=noise[0], s=sb[0], d=db[0])
+        # (next_s: the style scales of the following modulated convolution — a layer folds them into the split image it writes
+        # for that convolution, op/modconv.py; first-order steps only, sb is None-filled otherwise)
+        nblk = len(self.to_rgbs)
+        out = self.conv1(self.input(latent), lat[0], noise=noise[0], s=sb[0], d=db[0], next_s=sb[2] if nblk else None)
         feats.append(out)
         skip = self.to_rgb1(out, lat[1], s=sb[1])
         i = 1
         for blk, to_rgb in enumerate(self.to_rgbs):
-            out = self.convs[2 * blk](out, lat[i], noise=noise[2 * blk + 1], s=sb[2 + 3 * blk], d=db[2 + 3 * blk])
+            out = self.convs[2 * blk](out, lat[i], noise=noise[2 * blk + 1], s=sb[2 + 3 * blk], d=db[2 + 3 * blk],
+                                      next_s=sb[3 + 3 * blk])
             feats.append(out)
-            out = self.convs[2 * blk + 1](out, lat[i + 1], noise=noise[2 * blk + 2], s=sb[3 + 3 * blk], d=db[3 + 3 * blk])
+            out = self.convs[2 * blk + 1](out, lat[i + 1], noise=noise[2 * blk + 2], s=sb[3 + 3 * blk], d=db[3 + 3 * blk],
+                                          next_s=sb[5 + 3 * blk] if blk + 1 < nblk else None)
             feats.append(out)
             skip = to_rgb(out, lat[i + 2], skip, s=sb[4 + 3 * blk])
             i += 2

@@ -332,7 +332,7 @@ def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0, ep
 _USE_CT2 = True     # tools/bench_conv.py switches the dedicated stride-2 kernel off to time the generic multi-class launch
 
 
-def _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha, x_split=None):
+def _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha, x_split=None, amax=None):
     """3x3 stride-2 padding-0 transposed convolution on the single-staging kernel (csrc/convt2.hip)."""
     N, I, IH, IW = x.shape
     OH, OW = out_hw
@@ -356,14 +356,14 @@ def _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha, x_split=None):
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     if x_split is not None:
         check(_launch('igemm', flops, lib.rick_convt2_split_f32, ptr(x), ptr(x_split.hdr), ptr(wp), ptr(y), ptr(oscale), N, IH, IW,
-                      I, O, OH, OW, alpha, ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_convt2_split_f32')
+                      I, O, OH, OW, alpha, ptr(amax), ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_convt2_split_f32')
         return y
     check(_launch('igemm', flops, lib.rick_convt2_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), N, IH, IW, I, O,
                   OH, OW, _SPLIT, alpha, ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_convt2_f32')
     return y
 
 
-def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alpha=1.0, x_split=None):
+def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alpha=1.0, x_split=None, amax=None):
     """y[q] += w[k] x[pos], q = pos*s + k - p: the output parity classes (s*s of them) run as one launch.
     `x_split`: the input as a split image (stride 1, or the 3x3 stride-2 single-staging kernel)."""
     x = _nhwc(x) if x_split is None else x_split.data
@@ -371,7 +371,7 @@ def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alph
     OH, OW = out_hw
     if (_USE_CT2 and kh == 3 and kw == 3 and s == 2 and p == 0 and I % 4 == 0 and O % 4 == 0
             and OH in (2 * IH, 2 * IH + 1) and OW in (2 * IW, 2 * IW + 1)):
-        y = _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha, x_split=x_split)
+        y = _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha, x_split=x_split, amax=amax)
         if y is not None:            # (None: the single-staging kernel has no plan for this size -> generic launch below)
             return y
     if x_split is not None and s != 1:

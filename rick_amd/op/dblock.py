@@ -31,7 +31,8 @@ from .upfirdn2d import _flipped
 _SQ = 1.0 / math.sqrt(2.0)
 
 
-def _fir_ex(x, taps, up, down, pad4, out=None, split_bound=None, bound1=None, coef=1.0, amax=None, accumulate=False, no_f32=False):
+def _fir_ex(x, taps, up, down, pad4, out=None, split_bound=None, bound1=None, coef=1.0, amax=None, accumulate=False, no_f32=False,
+            chan_scale=None):
     """upfirdn2d (channels-last) with the extended result handling -> (fp32 tensor or None, SplitImage or None)."""
     n, c, h, w = x.shape
     kh, kw = taps.shape
@@ -43,7 +44,7 @@ def _fir_ex(x, taps, up, down, pad4, out=None, split_bound=None, bound1=None, co
         data = torch.empty((n, c, oh, ow), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         img = sp.SplitImage(data, sp.new_words(4, x.device), (split_bound, bound1, float(coef)))
         ex.split_out, ex.split_hdr, ex.bound0, ex.bound1, ex.bound_coef = ptr(data), ptr(img.hdr), ptr(split_bound), ptr(bound1), float(coef)
-    ex.amax, ex.accumulate, ex.no_f32 = ptr(amax), int(accumulate), int(no_f32)
+    ex.amax, ex.accumulate, ex.no_f32, ex.chan_scale = ptr(amax), int(accumulate), int(no_f32), ptr(chan_scale)
     if out is None and not no_f32:
         out = torch.empty((n, c, oh, ow), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     check(lib.rick_upfirdn2d_ex_f32(ptr(x), ptr(taps), ptr(out), n, h, w, c, kh, kw, up, up, down, down, pad4[0], pad4[1], pad4[2],

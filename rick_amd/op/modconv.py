@@ -14,6 +14,7 @@ Two implementations with identical values:
                               family, differentiable to any order (used under op.second_order()).
 """
 import ctypes
+import math
 
 import numpy as np
 import torch
@@ -23,6 +24,76 @@ from .._lib import check, lib, ptr, require_cuda_f32, stream_ptr
 from .conv import (_conv_launch, _convT_launch, _epilogue, _pack, _sink_target, _wgrad_launch, conv2d, conv_transpose2d,
                    grad_sink_enabled, param_like)
 from .misc import _chan_scale_raw, _hw_dot_raw, chan_scale
+
+
+# Split-image hand-over between the generator's fused layers: built, parity-tested (tests/test_gpu_split.py) and OFF by default.
+# Unlike the discriminator's blocks (op/dblock.py), where the images REPLACE fp32 tensors nobody else reads and the exact maxima
+# fall out of the conv epilogues, every generator activation is also read as fp32 (ToRGB, style and demodulation gradients), so
+# the images are extra writes, the gradient maxima need stand-alone passes and each bound a tiny launch: same-box A/B 153.3 vs
+# 154.5 images/s (-0.8 %): the MFMA kernels gained 6.4 ms over 30 iterations (7-9 % on the launches that moved, not the 11-26 %
+# of the micro-benchmark on random data), the producers / maxima / bound launches cost 13.5 ms.  RICK_GSPLIT=1 switches it on.
+_USE_SPLIT = bool(__import__('os').environ.get('RICK_GSPLIT'))
+
+
+stats = {'fprop': 0, 'dgrad': 0, 'wgrad': 0, 'produced': 0}     # launches that consumed / produced a split image (tests)
+
+
+def _bound_tail(w0, c0, gain, nw=None, w_noise=None, bias=None, mul=None):
+    """amax word  max|mul| * gain * (c0 * amax(w0) + |nw| * amax(w_noise) + max|bias|)  evaluated on the device."""
+    from . import split as sp
+    out = sp.new_amax(w0.device)
+    check(lib.rick_bound_tail_f32(ptr(out), ptr(w0), float(c0), ptr(nw), ptr(w_noise), ptr(bias), bias.numel() if bias is not None else 0,
+                                  float(gain), ptr(mul), mul.numel() if mul is not None else 0, stream_ptr()), 'rick_bound_tail_f32')
+    return out
+
+
+def _tensor_amax(t):
+    """The running-maximum word of a tensor: the one its producer measured (attribute), else a stand-alone pass."""
+    from . import split as sp
+    a = getattr(t, '_rick_amax', None)
+    return a if a is not None else sp.amax(t)
+
+
+def _same_tensor(a, b):
+    return a is b or (a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.shape == b.shape
+                      and a._version == b._version)
+
+
+def _input_image(x, s):
+    """The split image of s * x its producer attached to x, if it was made for THIS scale tensor."""
+    img = getattr(x, '_rick_split', None)
+    return img if (img is not None and _same_tensor(getattr(img, 'scale_of', None), s)) else None
+
+
+_sup_cache = {}
+
+
+def _split_geoms_supported(kind, N, I, IH, IW, O, kh):
+    """Do the MFMA launches of a modulated layer have split-image forms?  kind 'plain': conv s1 + its dgrad + wgrad;
+    'up': convT2 fprop + conv s2 dgrad + wgrad.  -> dict(fprop, dgrad, wgrad)"""
+    key = (kind, N, I, IH, IW, O, kh)
+    r = _sup_cache.get(key)
+    if r is None:
+        from .conv import _geom
+        p = kh // 2
+        if kind == 'plain':
+            t3 = [(ky - p, kx - p, ky * kh + kx) for ky in range(kh) for kx in range(kh)]
+            t3T = [(p - ky, p - kx, ky * kh + kx) for ky in range(kh) for kx in range(kh)]
+            gf = _geom(N, IH, IW, I, IH, IW, O, IH, IW, 1, 1, 0, 0, t3, kh * kh)
+            gd = _geom(N, IH, IW, O, IH, IW, I, IH, IW, 1, 1, 0, 0, t3T, kh * kh)
+            r = dict(fprop=bool(lib.rick_conv_igemm_split_supported(ctypes.byref(gf))) and I % 32 == 0,
+                     dgrad=bool(lib.rick_conv_igemm_split_supported(ctypes.byref(gd))) and O % 32 == 0,
+                     wgrad=bool(lib.rick_conv_wgrad_split_supported(ctypes.byref(gf))),
+                     nosplitk=lib.rick_conv_igemm_workspace_bytes(ctypes.byref(gf)) == 0)
+        else:
+            OH, OW = 2 * IH + 1, 2 * IW + 1
+            t3s = [(ky, kx, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+            gd = _geom(N, OH, OW, O, IH, IW, I, IH, IW, 2, 1, 0, 0, t3s, 9)          # dgrad: stride-2 conv of the output gradient
+            r = dict(fprop=kh == 3 and I % 32 == 0 and lib.rick_convt2_workspace_bytes(N, IH, IW, I, O, OH, OW) >= 0,
+                     dgrad=kh == 3 and bool(lib.rick_conv_igemm_split_supported(ctypes.byref(gd))) and O % 32 == 0,
+                     wgrad=kh == 3 and bool(lib.rick_conv_wgrad_split_supported(ctypes.byref(gd))), nosplitk=True)
+        _sup_cache[key] = r
+    return r
 
 
 def demod_coeff(w, s, wscale, eps=1e-8):
@@ -103,7 +174,8 @@ class _ModConvFused(Function):
     for the demodulation gradient from the saved activation (rick_hw_dot_act_f32)."""
 
     @staticmethod
-    def forward(ctx, x, w, s, d, wscale, upsample, key, bias, noise, nw, slope, gain):
+    def forward(ctx, x, w, s, d, wscale, upsample, key, bias, noise, nw, slope, gain, next_s=None):
+        from . import split as sp
         O, I, kh, kw = w.shape
         s_in, d_in = s, d
         s = s.contiguous()
@@ -112,14 +184,55 @@ class _ModConvFused(Function):
         tail_params = (bias, nw)                  # the Parameters themselves (gradient sink targets)
         ctx.plike = (param_like(w), param_like(bias), param_like(nw))
         wp = _pack(w, wscale, key and (key[0], key[1] + ('/convT' if upsample else '/conv')))
+        N, _, IH, IW = x.shape
+        # Split images (op/split.py): the input's image (its producer folded THIS layer's style in) replaces x and s in every
+        # MFMA launch of the layer that has a split form; the output's image (the next layer's style folded in) is written by
+        # this layer's own epilogue / its blur.  Exponents come from bounds: |d * conv(s x)| <= sqrt(taps * Ci) * max |x|
+        # (Cauchy-Schwarz; the demodulation makes the modulated weight rows unit vectors), then the tail's terms.
+        use = _USE_SPLIT and d is not None and s_in is s and kh == kw and x.is_cuda
+        sup = _split_geoms_supported('up' if upsample else 'plain', N, I, IH, IW, O, kh) if use else None
+        xpk = _input_image(x, s_in) if use else None
+        ctx.xpk = xpk if (xpk is not None and (sup['wgrad'] or sup['fprop'])) else None
+        ctx.sup = sup
+        xin = xpk if (xpk is not None and sup['fprop']) else None
         if upsample:
             if tail:
                 raise RuntimeError('the fused tail of an upsampling layer belongs to its blur (upfirdn2d_noise_bias_act)')
             oh, ow = (x.shape[2] - 1) * 2 + kh, (x.shape[3] - 1) * 2 + kw
-            y = _convT_launch(x, wp, O, kh, kw, 2, 0, (oh, ow), iscale=s, oscale=d)
+            if xin is not None:
+                A = sp.new_amax(x.device)
+                y = _convT_launch(None, wp, O, kh, kw, 2, 0, (oh, ow), oscale=d, x_split=xin, amax=A)
+                y._rick_bound = (A, 1.0)
+                stats['fprop'] += 1
+            else:
+                y = _convT_launch(x, wp, O, kh, kw, 2, 0, (oh, ow), iscale=s, oscale=d)
+                if use:
+                    y._rick_bound = (_tensor_amax(x), math.sqrt(4.0 * I))     # (a stride-2 output pixel sees <= 4 of the 9 taps)
         elif tail:
             bias, noise, nw = bias.contiguous(), noise.contiguous(), nw.contiguous()
-            y = _conv_launch(x, wp, O, kh, kw, 1, kh // 2, iscale=s, oscale=d, epi=_epilogue(bias, noise, nw, slope, gain))
+            epi = _epilogue(bias, noise, nw, slope, gain)
+            if use:
+                A = sp.new_amax(x.device)
+                epi.amax = ptr(A)
+                img = None
+                if next_s is not None and sup['nosplitk'] and O % 4 == 0:
+                    ns = next_s.contiguous()
+                    bound = _bound_tail(_tensor_amax(x), math.sqrt(kh * kw * I), gain, nw, _tensor_amax(noise), bias, ns)
+                    img = sp.SplitImage(torch.empty((N, O, IH, IW), device=x.device, dtype=torch.float32,
+                                                    memory_format=torch.channels_last), sp.new_words(4, x.device), (bound, None, 1.0))
+                    img.scale_of = next_s
+                    epi.split_out, epi.split_hdr, epi.split_bound, epi.split_coef, epi.split_scale = (
+                        ptr(img.data), ptr(img.hdr), ptr(bound), 1.0, ptr(ns))
+            if xin is not None:
+                stats['fprop'] += 1
+                y = _conv_launch(None, wp, O, kh, kw, 1, kh // 2, oscale=d, epi=epi, x_split=xin)
+            else:
+                y = _conv_launch(x, wp, O, kh, kw, 1, kh // 2, iscale=s, oscale=d, epi=epi)
+            if use:
+                y._rick_amax = A
+                if img is not None:
+                    y._rick_split = img
+                    stats['produced'] += 1
         else:
             y = _conv_launch(x, wp, O, kh, kw, 1, kh // 2, iscale=s, oscale=d)
         ctx.save_for_backward(x, w, s, d, y, *((bias, noise, nw) if tail else ()))
@@ -148,21 +261,35 @@ class _ModConvFused(Function):
             gx, gw, gs, gd, gb, gnw = second_order_backward(
                 compose, (x, w, s, d, bias, nw), [ctx.needs_input_grad[i] for i in (0, 1, 2, 3, 7, 9)], g,
                 (False, ctx.plike[0], False, False, ctx.plike[1], ctx.plike[2]))
-            return (gx, gw, gs, gd, None, None, None, gb, None, gnw, None, None)
+            return (gx, gw, gs, gd, None, None, None, gb, None, gnw, None, None, None)
+        g_in = g
         g = g.contiguous(memory_format=torch.channels_last)
         gx = gs = gw = gd = gb = gnw = None
+        sup, xpk = ctx.sup, ctx.xpk
+        gpk = None                                      # split image of d * (gradient of the convolution's output)
         if tail:
             from .fused_act import _ActAdjoint, param_sink
             bias, noise, nw = ctx.saved_tensors[5:]
             want_b, want_w = ctx.needs_input_grad[7], ctx.needs_input_grad[9]
-            g, gb, gnw = _ActAdjoint.apply(g, y, noise, slope, gain, want_b, want_w,
-                                           param_sink(ctx.tail_params[0], O, ctx.sink and want_b),
-                                           param_sink(ctx.tail_params[1], 1, ctx.sink and want_w))
+            sink_b = param_sink(ctx.tail_params[0], O, ctx.sink and want_b)
+            sink_w = param_sink(ctx.tail_params[1], 1, ctx.sink and want_w)
+            if sup is not None and sup['dgrad']:
+                # the adjoint leaves as fp32 (the demodulation gradient reads it) AND as the image of d * adjoint
+                g, gpk, gb, gnw = _adjoint_with_image(g, y, noise, slope, gain, d, want_b, want_w, sink_b, sink_w)
+            else:
+                g, gb, gnw = _ActAdjoint.apply(g, y, noise, slope, gain, want_b, want_w, sink_b, sink_w)
+        elif sup is not None and sup['dgrad']:
+            img = getattr(g_in, '_rick_split', None)    # written by the blur's adjoint (op/upfirdn2d.py) with THIS d folded in
+            if img is not None and _same_tensor(getattr(img, 'scale_of', None), d):
+                gpk = img
         wT = w.transpose(0, 1)
         wpT = _pack(wT, wscale, key and (key[0], key[1] + '/T'))
+        stats['dgrad'] += gpk is not None
         # unscaled data gradient: gx' = W^T (g * d)
         if upsample:
-            gxu = _conv_launch(g, wpT, I, kh, kw, 2, 0, iscale=d)
+            gxu = _conv_launch(None, wpT, I, kh, kw, 2, 0, x_split=gpk) if gpk is not None else _conv_launch(g, wpT, I, kh, kw, 2, 0, iscale=d)
+        elif gpk is not None:
+            gxu = _convT_launch(None, wpT, I, kh, kw, 1, kh // 2, (x.shape[2], x.shape[3]), x_split=gpk)
         else:
             gxu = _convT_launch(g, wpT, I, kh, kw, 1, kh // 2, (x.shape[2], x.shape[3]), iscale=d)
         if ctx.needs_input_grad[2] and ctx.needs_input_grad[0] and I % 4 == 0:
@@ -174,9 +301,16 @@ class _ModConvFused(Function):
                 gx = _chan_scale_raw(gxu, s)
         if ctx.needs_input_grad[1]:
             sink = _sink_target(key, w.shape, ctx.sink)     # op.grad_sink(): add straight into the parameter's .grad
+            both = gpk is not None and xpk is not None and sup['wgrad']       # both operands as images (scales folded in)
+            stats['wgrad'] += both
             if upsample:   # convT: gw[o,i,k] = sum x[pos,i] g[pos*2+k, o]  (a = x, b = g), transposed back
-                gw = _wgrad_launch(x, g, kh, kw, 2, 0, wscale, ascale=s, bscale=d, out=sink, transposed=True)
+                if both:
+                    gw = _wgrad_launch(None, None, kh, kw, 2, 0, wscale, out=sink, transposed=True, a_split=xpk, b_split=gpk)
+                else:
+                    gw = _wgrad_launch(x, g, kh, kw, 2, 0, wscale, ascale=s, bscale=d, out=sink, transposed=True)
                 gw = gw.transpose(0, 1) if gw is not None else None
+            elif both:
+                gw = _wgrad_launch(None, None, kh, kw, 1, kh // 2, wscale, out=sink, a_split=gpk, b_split=xpk)
             else:
                 gw = _wgrad_launch(g, x, kh, kw, 1, kh // 2, wscale, ascale=d, bscale=s, out=sink)
         if d is not None and ctx.needs_input_grad[3]:
@@ -185,7 +319,7 @@ class _ModConvFused(Function):
                 gd = _hw_dot_act_raw(g, y, bias, noise, nw, slope, gain, divisor=d)
             else:
                 gd = _hw_dot_raw(g, y, divisor=d)
-        return (gx, gw, gs, gd, None, None, None, gb, None, gnw, None, None)
+        return (gx, gw, gs, gd, None, None, None, gb, None, gnw, None, None, None)
 
 
 def _hw_dot_scale_raw(a, b, scale):
@@ -210,12 +344,43 @@ def _hw_dot_act_raw(g, y, bias, noise, nw, slope, gain, divisor=None):
     return out
 
 
-def modulated_conv_fused(x, w, s, d, wscale, upsample, key=None, tail=None):
-    """tail = (bias, noise, noise_weight, negative_slope, gain) fuses StyledConv's activation tail (plain layers only)."""
+def _adjoint_with_image(g, y, noise, slope, gain, d, want_b, want_w, sink_b, sink_w):
+    """The activation adjoint gz = g * act'(y) * gain as fp32 AND as the split image of d[n,c] * gz (the operand of the
+    layer's data- and weight-gradient kernels), bias / noise-strength gradients as in _ActAdjoint (sunk into the parameters'
+    .grad when sinks are given).  -> (gz, image, gb, gnw)"""
+    from . import split as sp
+    from .fused_act import _noise_args
+    n, c, h, w = g.shape
+    rows = n * h * w
+    Ag = _tensor_amax(g)
+    bound = _bound_tail(Ag, 1.0, abs(gain) * max(1.0, abs(slope)), mul=d)
+    gz = torch.empty_like(g)
+    img = sp.SplitImage(torch.empty_like(g), sp.new_words(4, g.device), (bound, None, 1.0))
+    img.scale_of = d
+    want_w = want_w and noise is not None
+    nz, nb, nhw = _noise_args(noise, g) if want_w else (None, 1, 1)
+    if (want_b and sink_b is None) or (want_w and sink_w is None):
+        sink_b = sink_w = None                         # one accumulate switch serves both sums (as in _ActAdjoint)
+    sunk = (want_b and sink_b is not None) or (want_w and sink_w is not None)
+    gb = (sink_b if sunk else torch.empty(c, device=g.device, dtype=g.dtype)) if want_b else None
+    gw = (sink_w if sunk else torch.empty(1, device=g.device, dtype=g.dtype)) if want_w else None
+    part = None
+    if want_b or want_w:
+        part = torch.empty(lib.rick_bias_act_bwd_blocks(rows, c) * (c + 1), device=g.device, dtype=g.dtype)
+    check(lib.rick_bias_act_bwd_split2_f32(ptr(g), ptr(y), ptr(img.data), ptr(img.hdr), None, None, 0.0, None, ptr(d), ptr(bound),
+                                           ptr(gz), ptr(gb), ptr(gw), ptr(nz), rows, c, h * w, nb, nhw, float(slope), float(gain),
+                                           ptr(part), int(sunk), stream_ptr()), 'rick_bias_act_bwd_split2_f32')
+    return gz, img, (None if sunk else gb), (None if sunk else gw)
+
+
+def modulated_conv_fused(x, w, s, d, wscale, upsample, key=None, tail=None, next_s=None):
+    """tail = (bias, noise, noise_weight, negative_slope, gain) fuses StyledConv's activation tail (plain layers only).
+    next_s: the style scales [N, Co] of the NEXT modulated convolution — the layer then also writes its output as that
+    convolution's split-image operand (first-order steps)."""
     if tail is None:
-        return _ModConvFused.apply(x, w, s, d, float(wscale), bool(upsample), key, None, None, None, 0.2, 1.0)
+        return _ModConvFused.apply(x, w, s, d, float(wscale), bool(upsample), key, None, None, None, 0.2, 1.0, None)
     bias, noise, nw, slope, gain = tail
-    return _ModConvFused.apply(x, w, s, d, float(wscale), bool(upsample), key, bias, noise, nw, float(slope), float(gain))
+    return _ModConvFused.apply(x, w, s, d, float(wscale), bool(upsample), key, bias, noise, nw, float(slope), float(gain), next_s)
 
 
 # ------------------------------------------------------------------------------------ modulation bank

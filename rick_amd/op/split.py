@@ -52,10 +52,11 @@ class SplitImage:
     hdr: float32[4] on the device = {2^e, 2^-e, bound, 0},
     bound: (amax word, amax word or None, coef) the producer derived its exponent from — |v| <= coef * (a0 + a1); a kernel
     whose result is bounded by this tensor's values (a FIR with non-negative taps of sum 1) reuses it."""
-    __slots__ = ('data', 'hdr', 'bound')
+    __slots__ = ('data', 'hdr', 'bound', 'scale_of')
 
     def __init__(self, data, hdr, bound=None):
         self.data, self.hdr, self.bound = data, hdr, bound
+        self.scale_of = None        # the per-(image, channel) scale tensor a producer folded in (identity-checked by consumers)
 
     @property
     def shape(self):

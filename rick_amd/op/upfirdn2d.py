@@ -43,6 +43,15 @@ def _fir(x, taps, up_xy, down_xy, pad4):
     return y
 
 
+def _abs_sum(taps):
+    """sum |taps| as a host float, cached on the tensor (one sync at the first, eager, use: never under graph capture)."""
+    ent = getattr(taps, '_rick_abs_sum', None)
+    if ent is None or ent[0] != taps._version:
+        ent = (taps._version, float(taps.abs().sum()))
+        taps._rick_abs_sum = ent
+    return ent[1]
+
+
 def _flipped(taps):
     """flip(taps) for the adjoint, cached ON the FIR tensor object (the networks' filters are constant buffers:
     without the cache every blur backward launches a flip and a copy of a 16-element tensor).  The flipped tensor
@@ -96,8 +105,13 @@ class _FirAct(Function):
     differentiates that two-op form (op/_twice.py)."""
 
     @staticmethod
-    def forward(ctx, x, taps, pad4, bias, noise, nw, slope, gain):
+    def forward(ctx, x, taps, pad4, bias, noise, nw, slope, gain, extra=None):
+        """extra = (next_s, bwd_scale) or None.  next_s [N, C]: also write the output as the split-image operand of the next
+        modulated convolution (its style folded in; needs the bound `x._rick_bound` the transposed convolution attached).
+        bwd_scale [N, C]: the demodulation scale of the convolution BEFORE this blur — the backward writes the blur's adjoint
+        as the image of bwd_scale * gradient for that convolution's data / weight gradient kernels."""
         from .conv import _epilogue, grad_sink_enabled
+        from .._lib import SplitOut
         ctx.params = (bias, nw, grad_sink_enabled())      # op.grad_sink(): bias / noise-strength gradients go straight to .grad
         n, c, h, w = x.shape
         kh, kw = taps.shape
@@ -109,8 +123,31 @@ class _FirAct(Function):
         nw = nw.contiguous()
         y = torch.empty((n, c, oh, ow), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
         tail = _epilogue(bias, noise, nw, slope, gain)
-        check(lib.rick_upfirdn2d_act_f32(ptr(x), ptr(taps), ptr(y), n, h, w, c, kh, kw, 1, 1, 1, 1, pad4[0], pad4[1],
-                                         pad4[2], pad4[3], ctypes.byref(tail), stream_ptr()), 'rick_upfirdn2d_act_f32')
+        next_s, ctx.bwd_scale = extra if extra is not None else (None, None)
+        xb = getattr(x_in, '_rick_bound', None)
+        if xb is not None and c % 4 == 0:
+            from . import split as sp
+            from .modconv import _bound_tail, _tensor_amax
+            ex = SplitOut()
+            A = sp.new_amax(x.device)
+            ex.amax = ptr(A)
+            img = None
+            if next_s is not None:
+                ns = next_s.contiguous()
+                # |y * next_s| <= max|next_s| * gain * (sum|taps| * bound(x) + |nw| * max|noise| + max|bias|)
+                bound = _bound_tail(xb[0], xb[1] * _abs_sum(taps), gain, nw, _tensor_amax(noise), bias, ns)
+                img = sp.SplitImage(torch.empty_like(y), sp.new_words(4, x.device), (bound, None, 1.0))
+                img.scale_of = next_s
+                ex.split_out, ex.split_hdr, ex.bound0, ex.bound1, ex.bound_coef, ex.chan_scale = (
+                    ptr(img.data), ptr(img.hdr), ptr(bound), None, 1.0, ptr(ns))
+            check(lib.rick_upfirdn2d_ex_f32(ptr(x), ptr(taps), ptr(y), n, h, w, c, kh, kw, 1, 1, 1, 1, pad4[0], pad4[1], pad4[2],
+                                            pad4[3], ctypes.byref(tail), ctypes.byref(ex), stream_ptr()), 'rick_upfirdn2d_ex_f32')
+            y._rick_amax = A
+            if img is not None:
+                y._rick_split = img
+        else:
+            check(lib.rick_upfirdn2d_act_f32(ptr(x), ptr(taps), ptr(y), n, h, w, c, kh, kw, 1, 1, 1, 1, pad4[0], pad4[1],
+                                             pad4[2], pad4[3], ctypes.byref(tail), stream_ptr()), 'rick_upfirdn2d_act_f32')
         ctx.save_for_backward(y, noise, x_in, taps)       # (x only for the create_graph route; no copy: it is the op's input)
         ctx.pad4 = pad4
         ctx.flipped = _flipped(taps)
@@ -130,20 +167,38 @@ class _FirAct(Function):
             gx, gb, gw = second_order_backward(
                 lambda x_, b_, nw_: fused_noise_bias_act(_UpFirDn.apply(x_, taps, (1, 1), (1, 1), pad4), b_, noise, nw_, slope, gain),
                 (x_in, bias, nw), [ctx.needs_input_grad[i] for i in (0, 3, 5)], g)
-            return (gx, None, None, gb, None, gw, None, None)
+            return (gx, None, None, gb, None, gw, None, None, None)
         want_b, want_w = ctx.needs_input_grad[3], ctx.needs_input_grad[5]
         gz, gb, gw = _ActAdjoint.apply(g, y, noise, slope, gain, want_b, want_w,
                                        param_sink(bias, y.shape[1], sink and want_b), param_sink(nw, 1, sink and want_w))
-        gx = _fir(gz, ctx.flipped, (1, 1), (1, 1), adj) if ctx.needs_input_grad[0] else None
-        return (gx, None, None, gb, None, gw, None, None)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            bs = ctx.bwd_scale
+            if bs is not None and y.shape[1] % 4 == 0:
+                # the blur's adjoint as fp32 and as the image of bwd_scale * gradient (the transposed convolution's backward
+                # operand): |.| <= sum|taps| * gain * max(1, slope) * max|g| * max|bwd_scale|
+                from . import split as sp
+                from .dblock import _fir_ex
+                from .modconv import _bound_tail, _tensor_amax
+                bsc = bs.contiguous()
+                bound = _bound_tail(_tensor_amax(g), _abs_sum(ctx.flipped) * abs(gain) * max(1.0, abs(slope)), 1.0, mul=bsc)
+                gx, img = _fir_ex(gz, ctx.flipped, 1, 1, adj, split_bound=bound, chan_scale=bsc)
+                img.scale_of = bs
+                gx._rick_split = img
+            else:
+                gx = _fir(gz, ctx.flipped, (1, 1), (1, 1), adj)
+        return (gx, None, None, gb, None, gw, None, None, None)
 
 
-def upfirdn2d_noise_bias_act(input, kernel, pad, bias, noise, noise_weight, negative_slope=0.2, gain=2 ** 0.5):
+def upfirdn2d_noise_bias_act(input, kernel, pad, bias, noise, noise_weight, negative_slope=0.2, gain=2 ** 0.5, next_s=None,
+                             bwd_scale=None):
     """gain * lrelu(upfirdn2d(input, kernel, pad=pad) + bias + noise_weight * noise) — one launch when the fused
-    path applies (4x4 taps, C % 64 == 0), the two separate ops otherwise."""
+    path applies (4x4 taps, C % 64 == 0), the two separate ops otherwise.  next_s / bwd_scale: split-image hand-over to the
+    neighbouring modulated convolutions (see _FirAct.forward)."""
     require_cuda_f32(input, kernel, bias, noise, noise_weight)
     if kernel.shape == (4, 4) and input.shape[1] % 64 == 0 and input.shape[0] <= 65535:
+        extra = (next_s, bwd_scale) if (next_s is not None or bwd_scale is not None) else None
         return _FirAct.apply(input, kernel.contiguous(), (pad[0], pad[1], pad[0], pad[1]), bias, noise, noise_weight,
-                             float(negative_slope), float(gain))
+                             float(negative_slope), float(gain), extra)
     from .fused_act import fused_noise_bias_act
     return fused_noise_bias_act(upfirdn2d(input, kernel, pad=pad), bias, noise, noise_weight, negative_slope, gain)

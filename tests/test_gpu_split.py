@@ -310,3 +310,47 @@ def test_discriminator_input_layer_one_launch_equals_two_op_path():
     assert torch.equal(res[True][0], res[False][0])
     for a, b in zip(res[True][1:], res[False][1:]):
         assert float((a - b).abs().max() / b.abs().max()) < 1e-6
+
+
+def test_generator_split_image_path_equals_on_the_fly_path():
+    """The generator's fused layers hand split images from producer to consumer (op/modconv.py: the conv epilogue / the blur
+    write the next layer's operand with its style folded in; the activation adjoint / the blur's adjoint write the backward
+    operands with the demodulation folded in).  Image and every parameter gradient against the same network with the images
+    switched off (the round-3 path, pinned to the reference's goldens)."""
+    from rick_amd.models import Generator
+    from rick_amd.op import modconv
+    from rick_amd.synth import synth_state_dict
+    from tests.shapes import generator_shapes
+    size, B = 128, 4
+    g = Generator(size, 512, 8)
+    g.load_state_dict(synth_state_dict(generator_shapes(size)), strict=False)
+    g = g.to(DEV)
+    for p_ in g.style.parameters():          # as in the train steps (the optimiser owns no mapping parameter): the modulation bank
+        p_.requires_grad_(False)             # evaluates every style up front, which is what lets a layer know the NEXT layer's style
+    torch.manual_seed(5)
+    z = torch.randn(B, 512, device=DEV)
+    noise = [torch.randn(B, 1, n.shape[2], n.shape[3], device=DEV) for n in g.make_noise()]
+    params = [p for n, p in g.named_parameters() if n.startswith('convs.') or n.startswith('conv1.')]
+    res, used = {}, {}
+    for mode in (True, False):
+        modconv._USE_SPLIT = mode
+        for k in modconv.stats:
+            modconv.stats[k] = 0
+        try:
+            img, _ = g([z], noise=noise)
+            loss = (img * torch.linspace(-1, 1, img.numel(), device=DEV).view_as(img)).sum()
+            gr = torch.autograd.grad(loss, params, allow_unused=True)
+            res[mode] = [img.detach()] + [t.detach() if t is not None else None for t in gr]
+            used[mode] = dict(modconv.stats)
+        finally:
+            modconv._USE_SPLIT = False       # (the shipping default: see op/modconv.py)
+    # 128 px: 11 modulated 3x3 layers; the 32^2 ... 128^2 ones (6 layers) run forward, data and weight gradient on images
+    assert used[False] == {'fprop': 0, 'dgrad': 0, 'wgrad': 0, 'produced': 0}
+    assert used[True]['fprop'] >= 5 and used[True]['dgrad'] >= 5 and used[True]['wgrad'] >= 5, used[True]
+    e = float((res[True][0] - res[False][0]).abs().max() / res[False][0].abs().max())
+    assert e < 2e-5, e
+    for (n, _), a, b in zip([(n, p) for n, p in g.named_parameters() if n.startswith('convs.') or n.startswith('conv1.')], res[True][1:], res[False][1:]):
+        assert (a is None) == (b is None), n
+        if a is not None:
+            e = float((a - b).norm() / (b.norm() + 1e-30))
+            assert e < (3e-2 if n.endswith("noise.weight") else 2e-4), (n, e)     # (noise strengths: the reference itself spreads 1e-2)
