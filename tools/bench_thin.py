@@ -1,0 +1,9 @@
+import sys, os, torch
+sys.path.insert(0, '/root/repo')
+from rick_amd.op import misc
+from tools.bench_conv_util import timeit
+for c, r in [(512, 64), (256, 128), (128, 256)]:
+    x = torch.randn(4, c, r, r, device='cuda').contiguous(memory_format=torch.channels_last)
+    W = torch.randn(4, 3, c, device='cuda')
+    t = timeit(lambda: misc.thin_fwd(x, W), reps=30)
+    print(f'NQ={os.environ.get("RICK_THIN_NQ")} C={c} @{r}: {t*1e6:6.1f} us {x.numel()*4/t/1e12:5.2f} TB/s')
