@@ -279,10 +279,11 @@ def main():
                                        'of `value`; the README recipe runs 5 samples every 50 iterations'}
 
     # ---- per-step-type times (untimed extra pass, every rank runs it so collectives stay matched): HIP events on the
-    # launch stream after every step of 16 more iterations = one full R1 period (4 path-length steps, 1 R1 step)
+    # launch stream after every step of 32 more iterations = two full R1 periods (8 path-length steps, 2 R1 steps, 24 iterations
+    # without a regulariser: SURVEY 8d's headline is the median of >= 20 of those)
     if not args.no_step_times:
         tr.step_events = []
-        run(16, i0 + args.warmup + args.steps)
+        run(32, i0 + args.warmup + args.steps)
         torch.cuda.synchronize()
         ev, tr.step_events = tr.step_events, None
         per, iters, cur, t_begin = {}, [], [], None
@@ -304,19 +305,26 @@ def main():
                                    'n': len(nonreg), 'note': 'D step + G step + EMA (SURVEY 8d definition), GPU time of this rank'}
         tot16 = sum(t for t, _ in iters)
         out['amortised16'] = {'ms_per_iteration': tot16 / len(iters), 'images_per_s': cfg.batch * world * len(iters) / (1e-3 * tot16),
-                              'note': '16 consecutive iterations = 16 D + 16 G + 1 R1 + 4 path-length steps'}
+                              'note': f'{len(iters)} consecutive iterations; per 16: 16 D + 16 G + 1 R1 + 4 path-length steps'}
 
     if not args.no_roofline:
         # instrumented repeat of 16 iterations: HIP events around every conv-family launch (eager issue; every rank
         # runs it — the bucketed all-reduces must stay matched — rank 0 reports)
         tr.enable_graphs(False)
         with launch_profiler() as prof:
-            run(16, i0 + args.warmup + args.steps + 16)
+            run(16, i0 + args.warmup + args.steps + 32)
             torch.cuda.synchronize()
         agg = {}
         by_tag = {}
+        hbm = {}
         for kind, flops, e0, e1, tag, abytes in prof:
             dt = e0.elapsed_time(e1) * 1e-3
+            if kind == 'hbm':           # HBM-bound launches (op.conv.hbm_launch): tag = kernel family, abytes = bytes to move once
+                h = hbm.setdefault(tag, [0.0, 0.0, 0])
+                h[0] += abytes
+                h[1] += dt
+                h[2] += 1
+                continue
             a = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += dt
@@ -351,6 +359,43 @@ def main():
             wg = agg['wgrad']
             out['roofline']['wgrad_kernel'] = {'achieved': wg[0] / wg[1] / 1e12, 'launches': wg[2],
                                                'avg_launch_us': 1e6 * wg[1] / max(wg[2], 1)}
+        # one entry per kernel VARIANT of the MFMA family (own algorithmic FLOPs, own event time), the operand form
+        # (split image / fp32 split on the fly) kept apart, so every fraction can be recomputed from profiles/ kernel by kernel
+        import re as _re
+
+        def variant(tag):
+            m = _re.match(r'(conv|convT|wgrad) (\d+)(?:->|x)(\d+) k(\d) s(\d) N(\d+) (?:a)?(\d+)x', tag)
+            if not m:
+                return None
+            op_, k, s_, res = m.group(1), int(m.group(4)), int(m.group(5)), int(m.group(7))
+            form = 'split image' if tag.endswith('[split]') else 'fp32 operands'
+            if op_ == 'wgrad':
+                name = f'conv_wgrad_kernel {k}x{k} stride {s_}'
+            elif k == 3 and s_ == 2 and op_ == 'convT':
+                name = 'convt2_kernel (3x3 stride-2 transposed, one staging)'
+            elif k == 3:
+                name = f'conv_igemm_kernel 3x3 stride {s_}' + (' (dgrad)' if op_ == 'convT' else '')
+            else:
+                name = f'conv_igemm_kernel {k}x{k}'
+            if res < 32 and op_ != 'wgrad':
+                name += ', < 32^2 (split-K / small-patch forms)'
+            return name, form
+        kv = {}
+        for tag, (fl, dt, n) in by_tag.items():
+            v = variant(tag)
+            if v is not None:
+                a = kv.setdefault(v, [0.0, 0.0, 0])
+                a[0] += fl
+                a[1] += dt
+                a[2] += n
+        out['roofline']['kernels'] = [
+            {'kernel': name, 'operands': form, 'achieved': fl / dt / 1e12, 'frac': fl / dt / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
+             'launches': n, 'avg_launch_us': 1e6 * dt / n, 'ms_per_step': 1e3 * dt / 16, 'algorithmic_gflop_per_launch': fl / n / 1e9}
+            for (name, form), (fl, dt, n) in sorted(kv.items(), key=lambda kv_: -kv_[1][1])]
+        out['hbm_kernels'] = [
+            {'kernel': name, 'achieved': by / dt / 1e9, 'unit': 'GB/s', 'peak': 8000.0, 'frac': by / dt / 8e12, 'launches': n,
+             'ms_per_step': 1e3 * dt / 16, 'avg_launch_us': 1e6 * dt / n}
+            for name, (by, dt, n) in sorted(hbm.items(), key=lambda kv_: -kv_[1][1])]
         conv_s = sum(a[1] for a in agg.values()) / 16
         out['roofline']['conv_family_ms_per_step'] = 1e3 * conv_s
     if rank == 0 and not args.no_extras:

@@ -60,6 +60,18 @@ def _launch(kind, flops, fn, *args, tag='', abytes=0.0):
     return rc
 
 
+def hbm_launch(name, nbytes, fn, *args):
+    """An HBM-bound launch under bench.py's launch profiler: `nbytes` = the bytes it has to move once (its inputs + outputs)."""
+    if _prof is None:
+        return fn(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    _prof.append(('hbm', 0.0, e0, e1, name, float(nbytes)))
+    return rc
+
+
 def set_precision(name):
     """'fp16x3' (default; parity-grade, ~2^-22 relative per product) or 'fp16' (single pass, ~3x the MFMA rate,
     ~2^-12 relative)."""
@@ -317,7 +329,7 @@ def _conv_launch(x, wp, O, kh, kw, s, p, iscale=None, oscale=None, alpha=1.0, ep
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     if x_split is not None:
         check(_launch('igemm', flops, lib.rick_conv_igemm_split_f32, ptr(x), ptr(x_split.hdr), ptr(wp), ptr(y), ptr(oscale), gref,
-                      ctypes.byref(epi) if epi is not None else None, ptr(ws), stream_ptr(), tag=tag, abytes=abytes),
+                      ctypes.byref(epi) if epi is not None else None, ptr(ws), stream_ptr(), tag=tag + ' [split]', abytes=abytes),
               'rick_conv_igemm_split_f32')
         return y
     if epi is not None:
@@ -356,7 +368,7 @@ def _convT2_launch(x, wp, O, out_hw, iscale, oscale, alpha, x_split=None, amax=N
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     if x_split is not None:
         check(_launch('igemm', flops, lib.rick_convt2_split_f32, ptr(x), ptr(x_split.hdr), ptr(wp), ptr(y), ptr(oscale), N, IH, IW,
-                      I, O, OH, OW, alpha, ptr(amax), ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_convt2_split_f32')
+                      I, O, OH, OW, alpha, ptr(amax), ptr(ws), stream_ptr(), tag=tag + ' [split]', abytes=abytes), 'rick_convt2_split_f32')
         return y
     check(_launch('igemm', flops, lib.rick_convt2_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale), N, IH, IW, I, O,
                   OH, OW, _SPLIT, alpha, ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_convt2_f32')
@@ -425,7 +437,7 @@ def _convT_launch(x, wp, O, kh, kw, s, p, out_hw, iscale=None, oscale=None, alph
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     if x_split is not None:          # stride 1: one class
         check(_launch('igemm', flops, lib.rick_conv_igemm_split_f32, ptr(x), ptr(x_split.hdr), ptr(wp), ptr(y), ptr(oscale),
-                      ctypes.byref(geoms[0]), None, ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_conv_igemm_split_f32')
+                      ctypes.byref(geoms[0]), None, ptr(ws), stream_ptr(), tag=tag + ' [split]', abytes=abytes), 'rick_conv_igemm_split_f32')
         return y
     check(_launch('igemm', flops, lib.rick_conv_igemm_multi_f32, ptr(x), ptr(wp), ptr(y), ptr(iscale), ptr(oscale),
                   geoms, ngeom, ptr(ws), stream_ptr(), tag=tag, abytes=abytes), 'rick_conv_igemm_multi_f32')
@@ -534,7 +546,7 @@ def _wgrad_launch(a, b, kh, kw, s, p, alpha=1.0, ascale=None, bscale=None, out=N
         check(_launch('wgrad', flops, lib.rick_conv_wgrad_split_f32, ptr(b_split.data if b_split is not None else b),
                       ptr(b_split.hdr) if b_split is not None else None, ptr(a_split.data if a_split is not None else a),
                       ptr(a_split.hdr) if a_split is not None else None, ptr(dst), s_co, s_ci, 1, gref, acc, ptr(ws),
-                      stream_ptr(), tag=tag, abytes=abytes), 'rick_conv_wgrad_split_f32')
+                      stream_ptr(), tag=tag + ' [split]', abytes=abytes), 'rick_conv_wgrad_split_f32')
         return None if out is not None else dst
     if out is not None:
         s_co, s_ci = (K, O * K) if transposed else (I * K, K)

@@ -47,8 +47,10 @@ def _fir_ex(x, taps, up, down, pad4, out=None, split_bound=None, bound1=None, co
     ex.amax, ex.accumulate, ex.no_f32, ex.chan_scale = ptr(amax), int(accumulate), int(no_f32), ptr(chan_scale)
     if out is None and not no_f32:
         out = torch.empty((n, c, oh, ow), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
-    check(lib.rick_upfirdn2d_ex_f32(ptr(x), ptr(taps), ptr(out), n, h, w, c, kh, kw, up, up, down, down, pad4[0], pad4[1], pad4[2],
-                                    pad4[3], None, ctypes.byref(ex), stream_ptr()), 'rick_upfirdn2d_ex_f32')
+    from .conv import hbm_launch
+    nbytes = 4 * (x.numel() + n * c * oh * ow * ((0 if no_f32 else 1) + (1 if accumulate else 0) + (1 if img is not None else 0)))
+    check(hbm_launch('upfirdn2d', nbytes, lib.rick_upfirdn2d_ex_f32, ptr(x), ptr(taps), ptr(out), n, h, w, c, kh, kw, up, up, down, down,
+                     pad4[0], pad4[1], pad4[2], pad4[3], None, ctypes.byref(ex), stream_ptr()), 'rick_upfirdn2d_ex_f32')
     return out, img
 
 
@@ -63,9 +65,11 @@ def _act_adjoint_split(g, y, slope, scale, amax_g, mul2=None, want_b=False, sink
     if want_b:
         gb = sink_b if sunk else torch.empty(c, device=g.device, dtype=g.dtype)
         part = torch.empty(lib.rick_bias_act_bwd_blocks(rows, c) * (c + 1), device=g.device, dtype=g.dtype)
-    check(lib.rick_bias_act_bwd_split_f32(ptr(g), ptr(y), ptr(out1.data), ptr(out1.hdr), ptr(out2.data) if out2 else None,
-                                          ptr(out2.hdr) if out2 else None, float(mul2 or 0.0), ptr(amax_g), ptr(gb), None, None,
-                                          rows, c, h * w, 1, 1, float(slope), float(scale), ptr(part), int(sunk), stream_ptr()),
+    from .conv import hbm_launch
+    check(hbm_launch('bias_act_bwd', 4 * g.numel() * (3 if out2 is None else 4), lib.rick_bias_act_bwd_split_f32,
+                     ptr(g), ptr(y), ptr(out1.data), ptr(out1.hdr), ptr(out2.data) if out2 else None,
+                     ptr(out2.hdr) if out2 else None, float(mul2 or 0.0), ptr(amax_g), ptr(gb), None, None,
+                     rows, c, h * w, 1, 1, float(slope), float(scale), ptr(part), int(sunk), stream_ptr()),
           'rick_bias_act_bwd_split_f32')
     return out1, out2, (None if sunk else gb)
 

@@ -62,8 +62,9 @@ def _pointwise(x, bias, ref, grad_mode, slope, scale, noise, nw):
     if ref is not None:
         refr, _, _, _ = _as_rows(ref)
     nz, nb, nhw = _noise_args(noise, x) if noise is not None else (None, 1, 1)
-    check(lib.rick_bias_act_f32(ptr(xr), ptr(bias), ptr(refr), ptr(out), xr.numel(), 1, c, 3, grad_mode,
-                                slope, scale, ptr(nz), ptr(nw), hw * c, c, nb, nhw, stream_ptr()),
+    from .conv import hbm_launch
+    check(hbm_launch('bias_act', 4 * xr.numel() * (2 if refr is None else 3), lib.rick_bias_act_f32, ptr(xr), ptr(bias), ptr(refr),
+                     ptr(out), xr.numel(), 1, c, 3, grad_mode, slope, scale, ptr(nz), ptr(nw), hw * c, c, nb, nhw, stream_ptr()),
           'rick_bias_act_f32')
     return out
 
@@ -99,8 +100,9 @@ class _ActAdjoint(Function):
         if want_b or want_w:
             nblk = lib.rick_bias_act_bwd_blocks(rows, c)
             part = torch.empty(nblk * (c + 1), device=g.device, dtype=g.dtype)
-        check(lib.rick_bias_act_bwd_f32(ptr(gr), ptr(yr), ptr(gx), ptr(gb), ptr(gw), ptr(nz), rows, c, hw, nb, nhw,
-                                        slope, scale, ptr(part), int(sunk), stream_ptr()), 'rick_bias_act_bwd_f32')
+        from .conv import hbm_launch
+        check(hbm_launch('bias_act_bwd', 12 * gr.numel(), lib.rick_bias_act_bwd_f32, ptr(gr), ptr(yr), ptr(gx), ptr(gb), ptr(gw), ptr(nz),
+                         rows, c, hw, nb, nhw, slope, scale, ptr(part), int(sunk), stream_ptr()), 'rick_bias_act_bwd_f32')
         ctx.save_for_backward(y, noise)
         ctx.cfg = (slope, scale)
         if sunk:

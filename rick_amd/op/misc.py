@@ -132,8 +132,9 @@ class _ThinFwd(Function):
         n, c, h, w = _thin_shapes(x, W.shape[1])
         Wc, bs = _wb(W, n)
         t = torch.empty((n, W.shape[1], h, w), device=x.device, dtype=x.dtype)
-        check(lib.rick_thin_fwd_f32(ptr(x), ptr(Wc), bs, None, ptr(t), n, h * w, c, W.shape[1], stream_ptr()),
-              'rick_thin_fwd_f32')
+        from .conv import hbm_launch
+        check(hbm_launch('thin', 4 * (x.numel() + t.numel()), lib.rick_thin_fwd_f32, ptr(x), ptr(Wc), bs, None, ptr(t), n, h * w, c,
+                         W.shape[1], stream_ptr()), 'rick_thin_fwd_f32')
         return t
 
     @staticmethod
@@ -160,7 +161,9 @@ class _ThinBwdX(Function):
         Wc, bs = _wb(W, n)
         x = torch.empty((n, c, h, w), device=t.device, dtype=t.dtype, memory_format=torch.channels_last)
         _thin_shapes(x, J)
-        check(lib.rick_thin_bwdx_f32(ptr(t), ptr(Wc), bs, ptr(x), n, h * w, c, J, stream_ptr()), 'rick_thin_bwdx_f32')
+        from .conv import hbm_launch
+        check(hbm_launch('thin', 4 * (x.numel() + t.numel()), lib.rick_thin_bwdx_f32, ptr(t), ptr(Wc), bs, ptr(x), n, h * w, c, J,
+                         stream_ptr()), 'rick_thin_bwdx_f32')
         return x
 
     @staticmethod
@@ -217,8 +220,9 @@ class _ToRGB(Function):
         if sc.shape != (n, c) or wc.shape != (J, c) or (ac is not None and ac.shape != (n, J, h, wd)):
             raise RuntimeError('torgb: shape mismatch')
         t = torch.empty((n, J, h, wd), device=x.device, dtype=x.dtype)
-        check(lib.rick_torgb_fwd_f32(ptr(xc), ptr(wc), ptr(sc), wscale, ptr(bc), ptr(ac), ptr(t), n, h * wd, c, J, stream_ptr()),
-              'rick_torgb_fwd_f32')
+        from .conv import hbm_launch
+        check(hbm_launch('thin', 4 * (xc.numel() + t.numel() * (2 if ac is not None else 1)), lib.rick_torgb_fwd_f32, ptr(xc), ptr(wc),
+                         ptr(sc), wscale, ptr(bc), ptr(ac), ptr(t), n, h * wd, c, J, stream_ptr()), 'rick_torgb_fwd_f32')
         ctx.save_for_backward(x, w, s)
         ctx.wscale, ctx.bias_shape = wscale, (bias.shape if bias is not None else None)
         ctx.bias_add = (bias, add)      # (only used by the create_graph route; bias is a Parameter, add the upsampled skip)
@@ -245,8 +249,9 @@ class _ToRGB(Function):
         gx = gw = gs = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty((n, c, h, wd), device=g.device, dtype=g.dtype, memory_format=torch.channels_last)
-            check(lib.rick_torgb_bwdx_f32(ptr(g), ptr(w.contiguous()), ptr(s.contiguous()), ctx.wscale, ptr(gx), n, h * wd, c, J,
-                                          stream_ptr()), 'rick_torgb_bwdx_f32')
+            from .conv import hbm_launch
+            check(hbm_launch('thin', 4 * (gx.numel() + g.numel()), lib.rick_torgb_bwdx_f32, ptr(g), ptr(w.contiguous()),
+                             ptr(s.contiguous()), ctx.wscale, ptr(gx), n, h * wd, c, J, stream_ptr()), 'rick_torgb_bwdx_f32')
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             G = _ThinWgrad.apply(g, x)                                  # [n, J, c] = d loss / d W[n]
             if ctx.needs_input_grad[1]:

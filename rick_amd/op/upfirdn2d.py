@@ -36,9 +36,9 @@ def _fir(x, taps, up_xy, down_xy, pad4):
         x = x.contiguous()
         y = torch.empty((n, c, oh, ow), device=x.device, dtype=x.dtype)
         major, minor = n * c, 1
-    check(lib.rick_upfirdn2d_f32(ptr(x), ptr(taps), ptr(y), major, h, w, minor, kh, kw,
-                                 up_xy[0], up_xy[1], down_xy[0], down_xy[1],
-                                 pad4[0], pad4[1], pad4[2], pad4[3], stream_ptr()),
+    from .conv import hbm_launch
+    check(hbm_launch('upfirdn2d', 4 * (x.numel() + y.numel()), lib.rick_upfirdn2d_f32, ptr(x), ptr(taps), ptr(y), major, h, w, minor,
+                     kh, kw, up_xy[0], up_xy[1], down_xy[0], down_xy[1], pad4[0], pad4[1], pad4[2], pad4[3], stream_ptr()),
           'rick_upfirdn2d_f32')
     return y
 
@@ -146,8 +146,10 @@ class _FirAct(Function):
             if img is not None:
                 y._rick_split = img
         else:
-            check(lib.rick_upfirdn2d_act_f32(ptr(x), ptr(taps), ptr(y), n, h, w, c, kh, kw, 1, 1, 1, 1, pad4[0], pad4[1],
-                                             pad4[2], pad4[3], ctypes.byref(tail), stream_ptr()), 'rick_upfirdn2d_act_f32')
+            from .conv import hbm_launch
+            check(hbm_launch('upfirdn2d', 4 * (x.numel() + y.numel()), lib.rick_upfirdn2d_act_f32, ptr(x), ptr(taps), ptr(y), n, h, w,
+                             c, kh, kw, 1, 1, 1, 1, pad4[0], pad4[1], pad4[2], pad4[3], ctypes.byref(tail), stream_ptr()),
+                  'rick_upfirdn2d_act_f32')
         ctx.save_for_backward(y, noise, x_in, taps)       # (x only for the create_graph route; no copy: it is the op's input)
         ctx.pad4 = pad4
         ctx.flipped = _flipped(taps)

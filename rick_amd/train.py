@@ -177,9 +177,10 @@ class MaskedFlatAdam:
             bc = self.bc[len(runs)]
             check(lib.rick_adam_prepare_f32(ptr(self.steps_dev), i, idx[kk] - i + 1, b1, b2, ptr(bc), stream_ptr()),
                   'rick_adam_prepare_f32')
-            check(lib.rick_masked_adam_dev_f32(ptr(fp.flat[lo:hi]), ptr(fp.grad[lo:hi]), ptr(self.m[lo:hi]),
-                                               ptr(self.v[lo:hi]), ptr(mk), hi - lo, self.lr, b1, b2, self.eps, ptr(bc),
-                                               stream_ptr()), 'rick_masked_adam_dev_f32')
+            from .op.conv import hbm_launch
+            check(hbm_launch('masked_adam', (28 + (1 if mk is not None else 0)) * (hi - lo), lib.rick_masked_adam_dev_f32,
+                             ptr(fp.flat[lo:hi]), ptr(fp.grad[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]), ptr(mk), hi - lo,
+                             self.lr, b1, b2, self.eps, ptr(bc), stream_ptr()), 'rick_masked_adam_dev_f32')
             runs.append((i, idx[kk]))
             k = kk + 1
         self.last_runs = runs
