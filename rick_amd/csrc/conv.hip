@@ -979,7 +979,10 @@ static int launch_igemm(unsigned nwg, size_t lds, hipStream_t st, const float *x
     if constexpr (SPLIT == 2 && VEC) {
         if (pkx) {   // split-image input (`iscale` = its header): the three forms that carry the FLOPs
             if (u9s2) launch_igemm_k<2, true, false, 2, 9, 2, true>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
-            else if (igemm_tile_positions(g) == 64) return RICK_EINVAL;
+            else if (igemm_tile_positions(g) == 64) {          // stride-2 launches with short K per block (split-K): generic tap loop
+                if (t.NPP > 32 * IG_PMAX) return RICK_EINVAL;
+                launch_igemm_k<2, true, false, 2, 0, 0, true>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
+            }
             else if (u9 && lds + CV_WSTEP_BYTES <= 80 * 1024) launch_igemm_k<2, true, false, 4, 9, 3, true>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
             else if (t.NPP <= IG_DEEP_NPP) launch_igemm_k<2, true, true, 4, 0, 0, true>(nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi);
             else return RICK_EINVAL;
@@ -1033,7 +1036,7 @@ extern "C" int rick_conv_igemm_split_supported(const rick_conv_geom *g) {
     const size_t lds = igemm_lds_bytes(t, false);
     if (lds > 160 * 1024 || t.PH > 1023 || t.PW > 1023) return 0;
     const bool fullk = t.nsplit == 1 || t.cps >= 4;
-    if (igemm_tile_positions(g) == 64) return g->ntaps == 9 && t.NPP <= 32 * IG_PMAX && fullk && t.cps >= 4;
+    if (igemm_tile_positions(g) == 64) return t.NPP <= 32 * IG_PMAX;
     if (g->ntaps == 9 && t.NPP <= IG_DEEP_NPP && fullk && t.cps >= 4 && lds + CV_WSTEP_BYTES <= 80 * 1024) return 1;
     return t.NPP <= IG_DEEP_NPP;
 }
