@@ -235,6 +235,13 @@ typedef struct {
     int no_f32;             /* do not write the fp32 result (the output pointer may be NULL) */
     const float *chan_scale;/* NULL, or [N, C]: the split image holds result * chan_scale[n, c] (a modulated convolution's
                              * style / demodulation scale folded in; the bound must cover it) */
+    /* activation adjoint fused behind the FIR (4x4 up = 1 form only): result <- result * (adj_ref > 0 ? 1 : adj_slope) * adj_gain
+     * with adj_ref the activation's saved OUTPUT (same shape as the result), and the per-channel sums of that (the bias
+     * gradient) reduced per block into adj_partials [blocks per channel slab = images * tiles][C]
+     * (rick_upfirdn2d_adjoint_rows() rows; the caller column-sums them: rick_colsum_f32). */
+    const float *adj_ref;
+    float adj_slope, adj_gain;
+    float *adj_partials;
 } rick_split_out;
 /* Saturation events since the last reset, host-synchronous: values that exceeded a split-image producer's bound (a caller's
  * mistake) and waves of the igemm / convt2 / wgrad kernels that clamped an fp32 -> fp16 conversion of an on-the-fly split
@@ -251,6 +258,10 @@ int rick_upfirdn2d_ex_f32(const float *input, const float *kernel, float *out,
                           int up_x, int up_y, int down_x, int down_y,
                           int pad_x0, int pad_x1, int pad_y0, int pad_y1,
                           const rick_conv_epilogue *tail, const rick_split_out *ex, void *stream);
+/* rows of adj_partials for an output of out_h x out_w pixels and `major` images (4x4 up = 1 down = 1 form: 8 x 8 tiles) */
+int64_t rick_upfirdn2d_adjoint_rows(int64_t major, int out_h, int out_w);
+/* out[c] (+)= sum_r partials[r * stride + c], c < ncols: the deterministic second stage of the per-block channel sums */
+int rick_colsum_f32(const float *partials, float *out, int64_t rows, int stride, int ncols, int accumulate, void *stream);
 int rick_bias_act_bwd_split_f32(const float *g, const float *ref, void *out1, float *hdr1, void *out2, float *hdr2,
                                 float mul2, const float *amax_g, float *gb, float *gnw, const float *noise,
                                 int64_t rows, int C, int64_t rows_per_img, int64_t noise_nb, int64_t noise_hw,

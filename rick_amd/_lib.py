@@ -44,7 +44,8 @@ class ConvEpilogue(ctypes.Structure):
 class SplitOut(ctypes.Structure):
     """rick_split_out (include/rick_hip.h)."""
     _fields_ = [('split_out', c_fp), ('split_hdr', c_fp), ('bound0', c_fp), ('bound1', c_fp), ('bound_coef', c_f),
-                ('amax', c_fp), ('accumulate', c_int), ('no_f32', c_int), ('chan_scale', c_fp)]
+                ('amax', c_fp), ('accumulate', c_int), ('no_f32', c_int), ('chan_scale', c_fp), ('adj_ref', c_fp),
+                ('adj_slope', c_f), ('adj_gain', c_f), ('adj_partials', c_fp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/rick_hip.h
@@ -74,6 +75,8 @@ SIGNATURES = {
     'rick_conv_igemm_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue),
                                           c_fp, c_fp]),
     'rick_convt2_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp] + [c_int] * 7 + [c_f, c_fp, c_fp, c_fp]),
+    'rick_upfirdn2d_adjoint_rows': (c_i64, [c_i64, c_int, c_int]),
+    'rick_colsum_f32': (c_int, [c_fp, c_fp, c_i64, c_int, c_int, c_int, c_fp]),
     'rick_bound_tail_f32': (c_int, [c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_int, c_f, c_fp, c_int, c_fp]),
     'rick_bias_act_bwd_split2_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64,
                                              c_int, c_i64, c_i64, c_i64, c_f, c_f, c_fp, c_int, c_fp]),

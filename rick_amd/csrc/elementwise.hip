@@ -344,6 +344,12 @@ static int bias_act_bwd_run(const float *g, const float *ref, float *gx, float *
                             int64_t noise_nb, int64_t noise_hw, float alpha, float scale,
                             float *partials, int accumulate, void *stream, const BabSplit *sp);
 
+extern "C" int rick_colsum_f32(const float *partials, float *out, int64_t rows, int stride, int ncols, int accumulate, void *stream) {
+    if (!partials || !out || rows < 1 || rows > 0x7fffffff || stride < ncols || ncols < 1) return RICK_EINVAL;
+    launch_colsum(partials, out, (int)rows, stride, ncols, 0, (hipStream_t)stream, nullptr, accumulate);
+    RICK_LAUNCH_STATUS();
+}
+
 extern "C" int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx, float *gb, float *gnw,
                                      const float *noise, int64_t rows, int C, int64_t rows_per_img,
                                      int64_t noise_nb, int64_t noise_hw, float alpha, float scale,

@@ -266,7 +266,7 @@ extern "C" int rick_d_input_f32(const float *t, const float *W, const float *bia
                                 float slope, float gain, const rick_split_out *ex, void *stream) {
     if (!x || !W || !t || !bias || N <= 0 || P <= 0 || C <= 0 || C % 4 || J < 1 || J > THIN_MAXJ || N > 65535) return RICK_EINVAL;
     if (((uintptr_t)x | (uintptr_t)W | (uintptr_t)bias) % 16) return RICK_EINVAL;
-    rick_split_out xo = {nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, 0, 0, nullptr};
+    rick_split_out xo = {nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, 0, 0, nullptr, nullptr, 0.f, 1.f, nullptr};
     if (ex) {
         xo = *ex;
         if (xo.split_out && (!xo.split_hdr || !xo.bound0 || !(xo.bound_coef > 0.f) || ((uintptr_t)xo.split_out % 16))) return RICK_EINVAL;

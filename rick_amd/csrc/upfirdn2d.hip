@@ -74,14 +74,22 @@ __global__ __launch_bounds__(256) void upfirdn2d_planar_kernel(const float *__re
 // ------------------------------------------------------------------------------- NHWC
 // blockIdx.x: pixel tile, blockIdx.y: 64-channel slab, blockIdx.z: image.
 // XO: extended result handling (rick_split_out): add into `out`, fold max |result| into a word, write a split image.
-static const rick_split_out kNoSplitOut = {nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, 0, 0, nullptr};
+static const rick_split_out kNoSplitOut = {nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, 0, 0, nullptr, nullptr, 0.f, 1.f, nullptr};
 
 template <bool XO>
 __device__ __forceinline__ void ufd_store(float *dst, unsigned char *spix, int c, float4 v, const rick_split_out &xo, float sscale,
-                                          float &am, float &ams, int64_t n = 0, int C = 0) {
+                                          float &am, float &ams, int64_t n = 0, int C = 0, int64_t eoff = 0, float4 *bsum = nullptr) {
     if (!XO) {
         *reinterpret_cast<float4 *>(dst) = v;
         return;
+    }
+    if (xo.adj_ref) {          // fused activation adjoint (same expression as bias_act_bwd_kernel: g * (ref > 0 ? 1 : slope) * gain)
+        const float4 r = *reinterpret_cast<const float4 *>(xo.adj_ref + eoff);
+        v.x = v.x * (r.x > 0.f ? 1.f : xo.adj_slope) * xo.adj_gain;
+        v.y = v.y * (r.y > 0.f ? 1.f : xo.adj_slope) * xo.adj_gain;
+        v.z = v.z * (r.z > 0.f ? 1.f : xo.adj_slope) * xo.adj_gain;
+        v.w = v.w * (r.w > 0.f ? 1.f : xo.adj_slope) * xo.adj_gain;
+        if (bsum) { bsum->x += v.x; bsum->y += v.y; bsum->z += v.z; bsum->w += v.w; }
     }
     if (xo.accumulate) {
         const float4 o = *reinterpret_cast<const float4 *>(dst);
@@ -183,6 +191,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
     constexpr int TIH = (TOH - 1) * DOWN + 4, TIW = (TOW - 1) * DOWN + 4, CB4 = 16;
     __shared__ float4 sx[TIH * TIW * CB4];
     float sscale = 1.f, am = 0.f, ams = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (XO && xo.split_out) {
         const cv_split_hdr h = cv_split_header(xo.bound0, xo.bound1, xo.bound_coef);
         if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *reinterpret_cast<cv_split_hdr *>(xo.split_hdr) = h;
@@ -259,10 +268,26 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
                 }
             }
             const int64_t po = n * (int64_t)p.out_h * p.out_w + (int64_t)oy * p.out_w + ox;
-            ufd_store<XO>(out + po * p.minor + c0 + c4 * 4, (unsigned char *)xo.split_out + po * p.minor * 4, c0 + c4 * 4, v, xo, sscale, am, ams, n, p.minor);
+            ufd_store<XO>(out + po * p.minor + c0 + c4 * 4, (unsigned char *)xo.split_out + po * p.minor * 4, c0 + c4 * 4, v, xo, sscale, am, ams, n, p.minor,
+                          po * p.minor + c0 + c4 * 4, &bsum);
         }
     }
     if (XO) {
+        if (xo.adj_partials) {     // per-channel sums of the block's tile (the bias gradient's first stage): 16 pixel rows -> 1
+            __syncthreads();
+            sx[threadIdx.x] = bsum;                      // [pixel group 0..15][c4 0..15]
+            __syncthreads();
+            if (threadIdx.x < 16) {
+                float4 t = sx[threadIdx.x];
+#pragma unroll
+                for (int r = 1; r < 16; r++) {
+                    const float4 u = sx[r * 16 + threadIdx.x];
+                    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                }
+                const int64_t row = n * gridDim.x + tile;
+                *reinterpret_cast<float4 *>(xo.adj_partials + row * p.minor + c0 + threadIdx.x * 4) = t;
+            }
+        }
         if (xo.amax) cv_amax_publish(am, xo.amax, reinterpret_cast<float *>(sx));
         if (xo.split_out) cv_sat_check(ams, sscale);
     }
@@ -306,6 +331,9 @@ extern "C" int rick_upfirdn2d_ex_f32(const float *input, const float *kernel, fl
     if (ex->split_out && (!ex->split_hdr || !ex->bound0 || (minor & 31) || !(ex->bound_coef > 0.f) || ((uintptr_t)ex->split_out % 16)))
         return RICK_EINVAL;
     if (!out && !(ex->no_f32 && !ex->accumulate)) return RICK_EINVAL;
+    if (ex->adj_ref && !(kh == 4 && kw == 4 && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && minor % 64 == 0 && !tail &&
+                         ((uintptr_t)ex->adj_ref % 16) == 0 && (!ex->adj_partials || ((uintptr_t)ex->adj_partials % 16) == 0)))
+        return RICK_EINVAL;
     return upfirdn2d_impl(input, kernel, out ? out : (float *)ex->split_out, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x,
                           down_y, pad_x0, pad_x1, pad_y0, pad_y1, tail, stream, ex);
 }
@@ -405,3 +433,7 @@ planar_like:
 }
 
 CV_DEFINE_SAT_ACCESSOR(rick_sat_upfirdn2d)
+
+extern "C" int64_t rick_upfirdn2d_adjoint_rows(int64_t major, int out_h, int out_w) {
+    return major * cdiv(out_w, 8) * cdiv(out_h, 8);
+}

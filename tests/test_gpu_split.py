@@ -354,3 +354,26 @@ def test_generator_split_image_path_equals_on_the_fly_path():
         if a is not None:
             e = float((a - b).norm() / (b.norm() + 1e-30))
             assert e < (3e-2 if n.endswith("noise.weight") else 2e-4), (n, e)     # (noise strengths: the reference itself spreads 1e-2)
+
+
+def test_fir_adjoint_fused_equals_two_passes():
+    """Blur adjoint + activation adjoint in one launch (rick_upfirdn2d_ex_f32 with adj_ref): the image equals the two-pass
+    result's bit for bit under the same bound (same fmaf chain, same adjoint expression); the bias gradient agrees to fp32
+    summation order."""
+    from rick_amd.models import make_kernel
+    from rick_amd.op import dblock, split as sp
+    from rick_amd.op.upfirdn2d import _flipped
+    taps = make_kernel([1, 3, 3, 1]).to(DEV)
+    flip = _flipped(taps)
+    for n, c, h in [(2, 128, 64), (8, 128, 128), (1, 256, 16)]:
+        g = _octaves((n, c, h + 1, h + 1), -12, -6, 21)
+        y = _octaves((n, c, h, h), -2, 2, 22)
+        A = sp.amax(g)
+        ref_f, _ = dblock._fir_ex(g, flip, 1, 1, (1, 1, 1, 1))
+        ref_img, _, ref_gb = dblock._act_adjoint_split(ref_f, y, 0.2, math.sqrt(2), A, None, True, None)
+        img, gb = dblock._fir_adjoint_split(g, flip, (1, 1, 1, 1), y, 0.2, math.sqrt(2), A, True, None)
+        assert torch.equal(img.data, ref_img.data) and torch.equal(img.hdr[:3], ref_img.hdr[:3])
+        assert float((gb - ref_gb).abs().max() / ref_gb.abs().max()) < 1e-5
+        acc = torch.ones(c, device=DEV)
+        _, none = dblock._fir_adjoint_split(g, flip, (1, 1, 1, 1), y, 0.2, math.sqrt(2), A, True, acc)
+        assert none is None and float((acc - 1 - ref_gb).abs().max() / ref_gb.abs().max()) < 1e-5
