@@ -301,6 +301,9 @@ def main():
         med = lambda v: sorted(v)[len(v) // 2]                                         # noqa: E731
         nonreg = [t for t, names in iters if 'r1' not in names and 'plr' not in names]
         out['step_ms'] = {k: med(v) for k, v in per.items()}
+        if world > 1 and use_graphs:
+            out['step_ms_note'] = ('pipelined: with step graphs under data parallelism a step\'s all-reduce wait and optimiser '
+                                   'graph run behind the NEXT step\'s head and are charged to that step')
         out['nonreg_iteration'] = {'median_ms': med(nonreg), 'images_per_s': cfg.batch * world / (1e-3 * med(nonreg)),
                                    'n': len(nonreg), 'note': 'D step + G step + EMA (SURVEY 8d definition), GPU time of this rank'}
         tot16 = sum(t for t, _ in iters)

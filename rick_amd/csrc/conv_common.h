@@ -46,6 +46,10 @@ __device__ __forceinline__ unsigned pack_f16_rne(float a, float b) {   // v_cvt_
 }
 
 // amax (>= 0, finite) -> scale = 2^e and unscale = 2^-e with  amax * scale in [2^T, 2^(T+1));  amax == 0 -> 1, 1.
+// (amax == 0 means every SAMPLED value of the block was zero — the first chunk whole plus 8 192 samples of the others in
+// the igemm: a block of a masked / padded gradient map.  Unsampled non-zero values are then split as raw fp16: exact down
+// to 6e-8, flushed below — an absolute error of at most 2^-25 on operands that the block's own sample calls zero; the split
+// images (below) have no such case: their exponent comes from the exact maximum.)
 template <int T>
 __device__ __forceinline__ void cv_pow2_scale_t(float amax, float &scale, float &unscale) {
     int eb = (int)((__float_as_uint(amax) >> 23) & 0xffu);           // biased exponent (0 for zero / fp32 subnormals)

@@ -74,7 +74,13 @@ def hbm_launch(name, nbytes, fn, *args):
 
 def set_precision(name):
     """'fp16x3' (default; parity-grade, ~2^-22 relative per product) or 'fp16' (single pass, ~3x the MFMA rate,
-    ~2^-12 relative)."""
+    ~2^-12 relative).
+
+    PROCESS-WIDE on purpose, like the packed-weight caches and PackGroup tables: a backward pass is issued by the autograd
+    engine's device thread, not by the thread that ran the forward, so a thread-local setting would let the two halves of
+    one step disagree.  The C ABI below is re-entrant (rick_hip.h); this Python layer supports ONE training thread per
+    process — the deployment model is one process per GPU (rick_amd/dist.py), not nn.DataParallel's worker threads.  Only
+    the switches that are read in an op's forward (`second_order`, `grad_sink`) are thread-local."""
     global _SPLIT
     _SPLIT = {'fp16x3': 2, 'fp16': 1}[name]
 

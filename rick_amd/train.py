@@ -842,7 +842,11 @@ class RickTrainer:
         self._mark('ema')
 
     def _mark(self, name):
-        """bench.py's per-step-type timing: a HIP event on the launch stream after each step (no host sync)."""
+        """bench.py's per-step-type timing: a HIP event on the launch stream after each step (no host sync).  Under data
+        parallelism with step graphs the optimiser part of a step is deferred behind the next step's head (`_run`), so the
+        event of step k is recorded before its all-reduce wait and optimiser graph have run: that time is charged to step
+        k + 1 — per-step times of `--gpus N` runs are pipelined and not comparable with single-GPU ones (ADVICE round 3);
+        `ms_per_step` and `value` are unaffected (whole iterations, fenced)."""
         if self.step_events is not None:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
