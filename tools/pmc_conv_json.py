@@ -20,7 +20,7 @@ for d in sorted(glob.glob(os.path.join(root, 'k_*'))):
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
             vals[r['Kernel_Name'].split('(')[0].replace('void ', '')][r['Counter_Name']].append(float(r['Counter_Value']))
-    best = max((k for k in vals if 'conv' in k and 'reduce' not in k and 'pack' not in k), key=lambda k: sum(vals[k].get('SQ_INSTS_MFMA', [0])), default=None)
+    best = max((k for k in vals if 'conv' in k and 'reduce' not in k and 'pack' not in k and 'split_pack' not in k), key=lambda k: sum(vals[k].get('SQ_INSTS_MFMA', [0])), default=None)
     if best is None:
         continue
     c = {k: sum(v) / len(v) for k, v in vals[best].items()}
