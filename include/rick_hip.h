@@ -44,6 +44,13 @@ int rick_upfirdn2d_f32(const float *input, const float *kernel, float *out,
                        int up_x, int up_y, int down_x, int down_y,
                        int pad_x0, int pad_x1, int pad_y0, int pad_y1, void *stream);
 
+/* The same operator in the reference's other dtypes (op/upfirdn2d_kernel.cu:311-367 dispatches half / float / double):
+ * dtype 1 = float64, 2 = float16 (fp32 accumulation); planar [major, H, W] layout (minor == 1), kernel taps in the same
+ * dtype.  Correctness-first (one thread per output): for `.double()` gradcheck and `.half()` inference of drop-in users. */
+int rick_upfirdn2d_any(const void *input, const void *kernel, void *out, int dtype, int64_t major, int in_h, int in_w,
+                       int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                       int pad_y1, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * fused bias + activation — replaces fused.fused_bias_act(input, bias, refer, act, grad,
  * alpha, scale) (op/fused_bias_act.cpp:11-21, op/fused_bias_act_kernel.cu:18-99):
@@ -68,6 +75,9 @@ int rick_bias_act_f32(const float *x, const float *bias, const float *ref, float
  * reduction through `partials` (float[(C + 1) * rick_bias_act_bwd_blocks(rows, C)]).
  * gb / gnw / noise may be NULL.  accumulate != 0: the second stage ADDS the sums into gb / gnw (the caller passes
  * the parameters' gradient buffers: no temporary, no separate accumulation pass); one second-stage launch serves both. */
+/* rick_bias_act_f32 without the noise term in dtype 1 = float64 / 2 = float16 (op/fused_bias_act_kernel.cu:79). */
+int rick_bias_act_any(const void *x, const void *bias, const void *ref, void *out, int dtype, int64_t n, int64_t step_b,
+                      int64_t size_b, int act, int grad, float alpha, float scale, void *stream);
 int rick_bias_act_bwd_blocks(int64_t rows, int C);
 int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx, float *gb, float *gnw,
                           const float *noise, int64_t rows, int C, int64_t rows_per_img,

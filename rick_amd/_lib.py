@@ -55,6 +55,8 @@ SIGNATURES = {
     'rick_upfirdn2d_act_f32': (c_int, [c_fp, c_fp, c_fp, c_i64] + [c_int] * 13 + [ctypes.POINTER(ConvEpilogue), c_fp]),
     'rick_bias_act_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f,
                                   c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_fp]),
+    'rick_upfirdn2d_any': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64] + [c_int] * 12 + [c_fp]),
+    'rick_bias_act_any': (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_f, c_f, c_fp]),
     'rick_bias_act_bwd_blocks': (c_int, [c_i64, c_int]),
     'rick_bias_act_bwd_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_i64, c_i64, c_i64,
                                       c_f, c_f, c_fp, c_int, c_fp]),
@@ -171,6 +173,26 @@ def require_cuda_f32(*tensors):
                                + str(t.device))
         if t.dtype != torch.float32:
             raise RuntimeError(f'rick_amd ops compute in float32; got {t.dtype}')
+
+
+DTYPE_CODE = {torch.float64: 1, torch.float16: 2}      # rick_*_any entries (float32 has its own, fast entries)
+
+
+def require_cuda_float(*tensors):
+    """The two drop-in ops (upfirdn2d, fused_leaky_relu) accept the reference extension's dtypes — half, float, double
+    (op/upfirdn2d_kernel.cu:311, op/fused_bias_act_kernel.cu:79) — all of one dtype per call; returns that dtype."""
+    dt = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('rick_amd ops require CUDA/HIP tensors (no CPU fallback); got device ' + str(t.device))
+        if t.dtype not in (torch.float32, torch.float64, torch.float16):
+            raise RuntimeError(f'rick_amd ops support float16 / float32 / float64; got {t.dtype}')
+        if dt is not None and t.dtype != dt:
+            raise RuntimeError(f'rick_amd ops need one dtype per call; got {dt} and {t.dtype}')
+        dt = t.dtype
+    return dt
 
 
 def ptr(t):

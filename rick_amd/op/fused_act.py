@@ -162,9 +162,63 @@ class _Act(Function):
         return (gx, gb, None, gw, None, None)
 
 
+def _any_pointwise(x, bias, ref, grad_mode, slope, scale):
+    """fused_bias_act in float64 / float16 (rick_bias_act_any): x of any shape with channels on dim 1 (op/fused_act.py:52-57)."""
+    from .._lib import DTYPE_CODE
+    xc = x.contiguous()
+    out = torch.empty_like(xc)
+    step_b = 1
+    for d in xc.shape[2:]:
+        step_b *= d
+    check(lib.rick_bias_act_any(ptr(xc), ptr(bias.contiguous() if bias is not None else None), ptr(ref.contiguous() if ref is not None else None),
+                                ptr(out), DTYPE_CODE[x.dtype], xc.numel(), step_b, xc.shape[1] if bias is not None else 1, 3, grad_mode,
+                                slope, scale, stream_ptr()), 'rick_bias_act_any')
+    return out
+
+
+class _ActAnyBackward(Function):
+    """op/fused_act.py:19-48 (FusedLeakyReLUFunctionBackward) for float64 / float16."""
+
+    @staticmethod
+    def forward(ctx, g, out, slope, scale, has_bias):
+        ctx.save_for_backward(out)
+        ctx.cfg = (slope, scale, has_bias)
+        gx = _any_pointwise(g, None, out, 1, slope, scale)
+        gb = gx.sum([0] + list(range(2, gx.ndim))).detach() if has_bias else None
+        return gx, gb
+
+    @staticmethod
+    def backward(ctx, ggx, ggb):
+        (out,) = ctx.saved_tensors
+        slope, scale, has_bias = ctx.cfg
+        if ggx is None:
+            ggx = torch.zeros_like(out)
+        return _any_pointwise(ggx, ggb if has_bias else None, out, 1, slope, scale), None, None, None, None
+
+
+class _ActAny(Function):
+    """op/fused_act.py:51-70 (FusedLeakyReLUFunction) for float64 / float16: same three-level structure as the reference."""
+
+    @staticmethod
+    def forward(ctx, x, bias, slope, scale):
+        out = _any_pointwise(x, bias, None, 0, slope, scale)
+        ctx.save_for_backward(out)
+        ctx.cfg = (slope, scale, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        slope, scale, has_bias = ctx.cfg
+        gx, gb = _ActAnyBackward.apply(g, out, slope, scale, has_bias)
+        return gx, gb, None, None
+
+
 def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
-    """Reference signature (op/fused_act.py:106-107)."""
-    require_cuda_f32(input, bias)
+    """Reference signature (op/fused_act.py:106-107); float16 / float32 / float64 like the reference extension."""
+    from .._lib import require_cuda_float
+    if require_cuda_float(input, bias) != torch.float32:
+        return _ActAny.apply(input, bias, float(negative_slope), float(scale))
     return _Act.apply(input, bias, None, None, float(negative_slope), float(scale))
 
 

@@ -28,6 +28,14 @@ def _fir(x, taps, up_xy, down_xy, pad4):
     ow = (w * up_xy[0] + pad4[0] + pad4[1] - kw) // down_xy[0] + 1
     if oh <= 0 or ow <= 0:
         raise RuntimeError(f'upfirdn2d: empty output ({oh}x{ow})')
+    if x.dtype != torch.float32:
+        # float64 / float16 (the reference extension's other dtypes): the generic planar kernel
+        from .._lib import DTYPE_CODE
+        x = x.contiguous()
+        y = torch.empty((n, c, oh, ow), device=x.device, dtype=x.dtype)
+        check(lib.rick_upfirdn2d_any(ptr(x), ptr(taps), ptr(y), DTYPE_CODE[x.dtype], n * c, h, w, kh, kw, up_xy[0], up_xy[1],
+                                     down_xy[0], down_xy[1], pad4[0], pad4[1], pad4[2], pad4[3], stream_ptr()), 'rick_upfirdn2d_any')
+        return y
     if c % 64 == 0 or (c < 64 and c % 4 == 0):
         x = x.contiguous(memory_format=torch.channels_last)
         y = torch.empty((n, c, oh, ow), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
@@ -91,7 +99,8 @@ class _UpFirDn(Function):
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
     """Same signature and semantics as the reference op (op/upfirdn2d.py:145-156): one
     up / down / pad pair for both axes.  CPU tensors raise (there is no native fallback)."""
-    require_cuda_f32(input, kernel)
+    from .._lib import require_cuda_float
+    require_cuda_float(input, kernel)      # float16 / float32 / float64 like the reference extension (one dtype per call)
     if input.ndim != 4 or kernel.ndim != 2:
         raise RuntimeError('upfirdn2d expects input [N,C,H,W] and kernel [kh,kw]')
     return _UpFirDn.apply(input, kernel.contiguous(), (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))

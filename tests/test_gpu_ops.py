@@ -830,3 +830,57 @@ def test_conv_operand_exponent_edge_cases(case):
     yt = op.conv_transpose2d(xd, wd[:64], 2, 0, wscale=wscale)                 # weight given as [O, I, kh, kw]
     ytr = F.conv_transpose2d(xr, (wr[:64] * wscale).transpose(0, 1), stride=2)  # torch wants [I, O, kh, kw]
     assert rel_err(yt, ytr) < tol, rel_err(yt, ytr)
+
+
+# ------------------------------------------------------------------ the extensions' other dtypes (half / double)
+@pytest.mark.parametrize('up,down,pad', [(1, 1, (2, 1)), (2, 1, (2, 1)), (1, 2, (1, 1)), (2, 3, (0, 2))])
+def test_upfirdn2d_double_vs_oracle_and_gradcheck(up, down, pad):
+    """op.upfirdn2d in float64 (op/upfirdn2d_kernel.cu:311-367 dispatches half / float / double; the reference's gradcheck
+    idiom is `.double()`): values against the oracle at 1e-13, first and second derivatives by torch's own gradcheck /
+    gradgradcheck against finite differences."""
+    from oracle.ops_ref import upfirdn2d_ref
+    from rick_amd import op
+    torch.manual_seed(0)
+    k = torch.tensor([1., 3., 3., 1.], dtype=torch.float64)
+    k = (k[:, None] * k[None, :] / k.sum() ** 2).to(DEV)
+    x = torch.randn(2, 3, 9, 7, dtype=torch.float64, device=DEV)
+    y = op.upfirdn2d(x, k, up=up, down=down, pad=pad)
+    ref = upfirdn2d_ref(x.cpu(), k.cpu(), up=up, down=down, pad=pad)
+    assert y.dtype == torch.float64 and y.shape == ref.shape
+    assert float((y.cpu() - ref).abs().max()) < 1e-13
+    xs = torch.randn(1, 2, 5, 4, dtype=torch.float64, device=DEV, requires_grad=True)
+    f = lambda t: op.upfirdn2d(t, k, up=up, down=down, pad=pad)   # noqa: E731
+    assert torch.autograd.gradcheck(f, (xs,), eps=1e-6, atol=1e-8)
+    assert torch.autograd.gradgradcheck(f, (xs,), eps=1e-6, atol=1e-8)
+
+
+def test_fused_leaky_relu_double_gradcheck_and_half():
+    """op.fused_leaky_relu in float64 (values vs the oracle at 1e-15, gradcheck / gradgradcheck incl. the bias) and float16
+    (against the float32 op at half precision); mixed dtypes are refused like the extension's TORCH_CHECK."""
+    from oracle.ops_ref import fused_leaky_relu_ref
+    from rick_amd import op
+    torch.manual_seed(1)
+    x = torch.randn(3, 8, 5, 4, dtype=torch.float64, device=DEV)
+    b = torch.randn(8, dtype=torch.float64, device=DEV)
+    y = op.fused_leaky_relu(x, b, 0.2, 2 ** 0.5)
+    # (alpha and scale cross the binding as C floats, in the reference too: op/fused_bias_act.cpp:11-13)
+    a32, s32 = float(np.float32(0.2)), float(np.float32(2 ** 0.5))
+    assert float((y.cpu() - fused_leaky_relu_ref(x.cpu(), b.cpu(), a32, s32)).abs().max()) < 1e-14
+    # keep away from the kink for the finite differences
+    xs = (torch.randn(2, 4, 3, 3, dtype=torch.float64, device=DEV).sign() * (0.2 + torch.rand(2, 4, 3, 3, dtype=torch.float64, device=DEV))).requires_grad_(True)
+    bs = torch.zeros(4, dtype=torch.float64, device=DEV, requires_grad=True)
+    f = lambda t, u: op.fused_leaky_relu(t, u, 0.2, 2 ** 0.5)   # noqa: E731
+    assert torch.autograd.gradcheck(f, (xs, bs), eps=1e-6, atol=1e-8)
+    assert torch.autograd.gradgradcheck(f, (xs, bs), eps=1e-6, atol=1e-8)
+    xh, bh = x.half(), b.half()
+    yh = op.fused_leaky_relu(xh, bh, 0.2, 2 ** 0.5)
+    y32 = op.fused_leaky_relu(xh.float(), bh.float(), 0.2, 2 ** 0.5)
+    assert yh.dtype == torch.float16 and float((yh.float() - y32).abs().max()) <= 2e-3 * float(y32.abs().max())
+    kh = torch.ones(4, 4, dtype=torch.float16, device=DEV) / 16
+    uh = op.upfirdn2d(xh, kh, pad=(2, 1))
+    u32 = op.upfirdn2d(xh.float(), kh.float(), pad=(2, 1))
+    assert uh.dtype == torch.float16 and float((uh.float() - u32).abs().max()) <= 2e-3 * float(u32.abs().max())
+    with pytest.raises(RuntimeError):
+        op.fused_leaky_relu(x, b.float())
+    with pytest.raises(RuntimeError):
+        op.upfirdn2d(x, kh)
