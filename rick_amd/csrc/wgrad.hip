@@ -19,6 +19,9 @@
 #define WG_BUF12 1      // stride-2 patches (PMAX = 12): range-checked buffer loads as well, but one basic block per SLOT
 #endif
 #define WG_GY_BYTES (WG_TILE * CV_BM * 2)   // 16 KB (one of hi / lo)
+#ifndef WG_PIPE_B
+#define WG_PIPE_B 0      // experiment (round 4), measured and left off: see PIPE_B in the tile loop
+#endif
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
@@ -525,6 +528,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                 // whole tile (1 MFMA : 2 VALU with the LDS / VMEM instructions pinned: the scheduler then front-loads ~170
                 // SALU / VALU instructions and emits 11 % more code).
                 constexpr bool ONEBB = FAST != 0 && PMAX <= 4;
+                // PIPE_B (both operands split images, whole-tile form): with no conversion work left to spread, hipcc's
+                // scheduler hoists ALL 104 B-fragment reads of the tile to its top, runs out of VGPRs and shuttles the fragments
+                // through AGPRs — 208 v_accvgpr_{write,read,mov} per 216 MFMAs in the ISA (0.96 of the 1.21 non-MFMA VALU per
+                // MFMA the counters showed).  Here the fragments of slot s + 1 are read explicitly before the MFMAs of slot s and
+                // a sched_barrier closes every slot: bounded live ranges, 174 instead of 208 moves — and SLOWER: 380 vs 410 TF on
+                // 512 x 512 @64^2 (batch 8): the fences cost more issue slack than the moves do, as in round 3.  Off (WG_PIPE_B).
+                constexpr bool PIPE_B = WG_PIPE_B && PK == 3 && ONEBB;
+                f16x8 bq_hi, bq_lo;
+                auto read_b = [&](auto SN) {
+                    constexpr int S2 = decltype(SN)::value, kk2 = S2 / NT, tt2 = S2 % NT;
+                    const int toff = (g.dy[tt2] - t.dymin) * t.PW + (g.dx[tt2] - t.dxmin);
+                    const int pp0 = pbase[kk2][0] + toff, pp1 = pbase[kk2][1] + toff;
+                    const int o0 = pp0 * 64 + wg_pswz(b_kg, pp0, t.pkb) * 16 + b_sub;
+                    const int o1 = pp1 * 64 + wg_pswz(b_kg, pp1, t.pkb) * 16 + b_sub;
+                    bq_hi = tr_read2(bph, o0, o1);
+                    bq_lo = tr_read2(bpl, o0, o1);
+                };
+                if constexpr (PIPE_B) read_b(std::integral_constant<int, 0>{});
                 for_slots([&](auto SC) {
                     constexpr int S = decltype(SC)::value, kk = S / NT, tt = S % NT;
                     if constexpr (tt == 0) {
@@ -539,7 +560,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                     }
                     for_items(std::integral_constant<int, S * IPS>{}, [&](auto K) { convert_item(K, nbuf, ONE); });
                     for_items(std::integral_constant<int, S * IPS>{}, [&](auto K) { issue_item(K); });
-                    if (ONEBB || tt < g.ntaps) {     // (ONEBB: the host guarantees ntaps == NT)
+                    if constexpr (PIPE_B) {
+                        const f16x8 bhi = bq_hi, blo = bq_lo;
+                        if constexpr (S + 1 < NSLOT) read_b(std::integral_constant<int, S + 1>{});
+    #pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[i], bhi, acc[i][tt], 0, 0, 0);
+                            acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], blo, acc[i][tt], 0, 0, 0);
+                            acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], bhi, acc[i][tt], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (ONEBB || tt < g.ntaps) {     // (ONEBB: the host guarantees ntaps == NT)
                         const int ts = (ONEBB || tt < g.ntaps) ? tt : 0;
                         const int toff = (g.dy[ts] - t.dymin) * t.PW + (g.dx[ts] - t.dxmin);
                         const int pp0 = pbase[kk][0] + toff, pp1 = pbase[kk][1] + toff;
