@@ -231,24 +231,61 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
         if (pix < TIH * TIW) sx[pix * CB4 + c4] = ((okm >> k) & 1u) ? stage[k] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
+    // Outputs of a thread.  down == 1: four vertically adjacent pixels of one column, so the 7 x 4 input window is read
+    // from LDS once (28 ds_read_b128 instead of 64) — every output still accumulates its 16 taps y-outer / x-inner.
+    constexpr int NOUT = TOH * TOW / 16;
+    constexpr bool COLUMN = DOWN == 1 && TOH == 8 && TOW == 8;
+    float4 acc[NOUT];
 #pragma unroll
-    for (int j = 0; j < TOH * TOW / 16; j++) {
-        const int pix = (threadIdx.x >> 4) + 16 * j;
-        const int ty = pix / TOW, tx = pix % TOW;
-        const int oy = oy0 + ty, ox = ox0 + tx;
-        const float4 *xr = sx + ((ty * DOWN) * TIW + tx * DOWN) * CB4 + c4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < NOUT; j++) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (COLUMN) {
+        const int pg = threadIdx.x >> 4;
+        const float4 *xr = sx + (((pg >> 3) * 4) * TIW + (pg & 7)) * CB4 + c4;
 #pragma unroll
-        for (int y = 0; y < 4; y++)
+        for (int r = 0; r < 7; r++) {
+            float4 xv[4];
 #pragma unroll
-            for (int x = 0; x < 4; x++) {
-                const float kv = kr[(3 - y) * 4 + (3 - x)];
-                const float4 xv = xr[(y * TIW + x) * CB4];
-                v.x = __builtin_fmaf(xv.x, kv, v.x);
-                v.y = __builtin_fmaf(xv.y, kv, v.y);
-                v.z = __builtin_fmaf(xv.z, kv, v.z);
-                v.w = __builtin_fmaf(xv.w, kv, v.w);
+            for (int x = 0; x < 4; x++) xv[x] = xr[(r * TIW + x) * CB4];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int y = r - o;
+                if (y < 0 || y > 3) continue;
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const float kv = kr[(3 - y) * 4 + (3 - x)];
+                    acc[o].x = __builtin_fmaf(xv[x].x, kv, acc[o].x);
+                    acc[o].y = __builtin_fmaf(xv[x].y, kv, acc[o].y);
+                    acc[o].z = __builtin_fmaf(xv[x].z, kv, acc[o].z);
+                    acc[o].w = __builtin_fmaf(xv[x].w, kv, acc[o].w);
+                }
             }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NOUT; j++) {
+            const int pix = (threadIdx.x >> 4) + 16 * j;
+            const int ty = pix / TOW, tx = pix % TOW;
+            const float4 *xr = sx + ((ty * DOWN) * TIW + tx * DOWN) * CB4 + c4;
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const float kv = kr[(3 - y) * 4 + (3 - x)];
+                    const float4 xv = xr[(y * TIW + x) * CB4];
+                    acc[j].x = __builtin_fmaf(xv.x, kv, acc[j].x);
+                    acc[j].y = __builtin_fmaf(xv.y, kv, acc[j].y);
+                    acc[j].z = __builtin_fmaf(xv.z, kv, acc[j].z);
+                    acc[j].w = __builtin_fmaf(xv.w, kv, acc[j].w);
+                }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NOUT; j++) {
+        const int pg = threadIdx.x >> 4;
+        const int ty = COLUMN ? (pg >> 3) * 4 + j : (pg + 16 * j) / TOW;
+        const int tx = COLUMN ? (pg & 7) : (pg + 16 * j) % TOW;
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        float4 v = acc[j];
         if (oy < p.out_h && ox < p.out_w) {
             if (TAIL) {   // fused NoiseInjection + bias + LeakyReLU (same operation order as rick_bias_act_f32)
                 if (tail.bias) {
