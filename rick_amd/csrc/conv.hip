@@ -300,7 +300,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         const int px = pos & tw_mask, py = (pos >> t.tw_log2) & th_mask;
         int nbi = pos >> (t.tw_log2 + t.th_log2);
         nbi = nbi < t.nbe ? nbi : t.nbe - 1;     // image slots beyond nbe are masked in the epilogue; keep LDS reads in range
-        pb[j] = (nbi * t.PH + py * g.is) * t.PW + px * g.is;
+        pb[j] = (nbi * t.PH + py * g.is) * t.PW + (g.is == 2 ? px : px * g.is);   // (stride 2: de-interleaved columns, conv_tiling.h)
     }
 
     // ---- patch staging state.  The tile is fixed for the block, so validity, source offset (relative to
@@ -323,7 +323,8 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         p_rel[k] = 0;
         p_sc[k] = 0;
         // items past the patch land in a spare row behind it, so the LDS writes need no guard
-        p_lds[k] = (pix < t.NPP ? pix : t.NPP) * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
+        const int slot = pix < t.NPP ? cv_patch_slot(pix, ptab[pix], t, g.is) : t.NPP;
+        p_lds[k] = slot * 64 + cv_swz(c4 >> 1, slot) * 16 + (c4 & 1) * 8;
         if (pix < t.NPP) {
             const unsigned e = ptab[pix];
             const int nbi = (int)(e >> 20), py = (int)((e >> 10) & 1023), px = (int)(e & 1023);
@@ -387,7 +388,8 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 uint2 hi, lo;
                 if (iscale) split4v<SPLIT>(v, *reinterpret_cast<const float4 *>(sct + (int)(e >> 20) * cspan + (chunk - c_begin) * CV_CK + c4 * 4), hi, lo, satm);
                 else split4s<SPLIT>(v, xscale, hi, lo, satm);      // (the scale table only exists with an input scale)
-                const int off = pix * 64 + cv_swz(c4 >> 1, pix) * 16 + (c4 & 1) * 8;
+                const int slot = cv_patch_slot(pix, e, t, g.is);
+                const int off = slot * 64 + cv_swz(c4 >> 1, slot) * 16 + (c4 & 1) * 8;
                 *reinterpret_cast<uint2 *>(ph + off) = hi;
                 if (SPLIT == 2) *reinterpret_cast<uint2 *>(pl + off) = lo;
             }
@@ -578,7 +580,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 }
                 {
                     const unsigned char *wb = wbuf + (WDMA == 3 ? tap % 3 : (par + tap) & 1) * CV_WSTEP_BYTES;
-                    const int toff = (g.dy[tap] - t.dymin) * t.PW + (g.dx[tap] - t.dxmin);
+                    const int toff = (g.dy[tap] - t.dymin) * t.PW + cv_patch_col(g.dx[tap] - t.dxmin, t.PW, g.is);
                     f16x8 ahi[4], alo[4], bhi[NJ], blo[NJ];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
@@ -653,7 +655,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             __builtin_amdgcn_sched_barrier(0);   // prefetches are issued before the MFMAs, consumed after
             if (!(t.debug & 1)) {
                 const unsigned char *wb = wbuf + (ks & 1) * CV_WSTEP_BYTES;
-                const int toff = (g.dy[tap] - t.dymin) * t.PW + (g.dx[tap] - t.dxmin);
+                const int toff = (g.dy[tap] - t.dymin) * t.PW + cv_patch_col(g.dx[tap] - t.dxmin, t.PW, g.is);
                 f16x8 ahi[4], alo[4], bhi[NJ], blo[NJ];
     #pragma unroll
                 for (int i = 0; i < 4; i++) {

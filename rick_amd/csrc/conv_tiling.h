@@ -72,7 +72,7 @@ static int make_tiling(const rick_conv_geom *g, int tile_positions, ConvTiling *
     t->ncot = cdiv(g->Co, CV_BM);
     t->nsplit = 1;
     t->cps = t->nchunks;
-    t->pkb = (g->is == 1 && tw == 4) ? 3 : 2;
+    t->pkb = (g->is <= 2 && tw == 4) ? 3 : (g->is == 2 && tw == 3) ? 5 : 2;   // (tools/lds_sim.py)
     t->debug = ablation_env("RICK_CONV_DEBUG", 0);
     return 0;
 }
@@ -88,6 +88,17 @@ __device__ __forceinline__ void build_patch_table(unsigned *ptab, const ConvTili
         const int py = rem / t.PW, px = rem - py * t.PW;
         ptab[pix] = ((unsigned)nbi << 20) | ((unsigned)py << 10) | (unsigned)px;
     }
+}
+
+// Stride-2 inputs: every patch row is kept with its even and its odd columns de-interleaved ([even columns | odd columns]).
+// The pixels one MFMA fragment gathers — every other column — are then neighbours in LDS, and the slot swizzle that is
+// conflict-free for stride-1 layers is conflict-free for them as well (tools/lds_sim.py; with the plain row-major patch every B
+// read of a stride-2 layer was a 2-way conflict: 21 % / 28 % of the LDS cycles of the forward / weight-gradient kernel).  A tap
+// offset stays additive: column 2 px + dx lands at px + [(dx & 1) * half + (dx >> 1)].
+__device__ __forceinline__ int cv_patch_col(int px, int PW, int is) { return is == 2 ? (px >> 1) + (px & 1) * ((PW + 1) >> 1) : px; }
+// LDS pixel slot of patch pixel `pix` (row-major index, table entry e = nbi << 20 | py << 10 | px)
+__device__ __forceinline__ int cv_patch_slot(int pix, unsigned e, const ConvTiling &t, int is) {
+    return is == 2 ? ((int)(e >> 20) * t.PH + (int)((e >> 10) & 1023)) * t.PW + cv_patch_col((int)(e & 1023), t.PW, 2) : pix;
 }
 
 static int check_geom(const rick_conv_geom *g) {

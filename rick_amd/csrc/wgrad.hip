@@ -13,7 +13,11 @@
 //              a transposing read takes 32 B of 8 patch rows per 32-lane group — rows p..p+3 and p+8..p+11 of a
 //              16-wide position tile — so the two runs must differ in their slot key: bit 3 (pkb = 3, conflict-free;
 //              the igemm's bit 2 makes every such read 2-way: 31 % of the LDS cycles were conflicts in round 2);
-//              narrower tiles and stride-2 geometries keep bit 2 (tools/lds_sim.py)
+//              narrower stride-1 tiles keep bit 2.  Stride-2 patches store every row as [even columns | odd columns]
+//              (conv_tiling.h cv_patch_col), which turns the gather of every other pixel into the stride-1 pattern: bit 3
+//              is conflict-free there as well (row-major rows: 2-way on every read, 28 % of the LDS cycles; after: 8 % —
+//              and the same kernel time, tools/bench_split.py: the stride-2 form is bound by the issue of its 12-item
+//              staging, not by LDS) (tools/lds_sim.py)
 #define WG_TILE 64
 #ifndef WG_BUF12
 #define WG_BUF12 1      // stride-2 patches (PMAX = 12): range-checked buffer loads as well, but one basic block per SLOT
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             const int px = r & tw_mask, py = (r >> t.tw_log2) & th_mask;
             int nbi = r >> (t.tw_log2 + t.th_log2);
             nbi = nbi < t.nbe ? nbi : t.nbe - 1;   // masked rows (zero gy) still read finite patch data
-            pbase[kk][h] = (nbi * t.PH + py * g.is) * t.PW + px * g.is;
+            pbase[kk][h] = (nbi * t.PH + py * g.is) * t.PW + (g.is == 2 ? px : px * g.is);   // (stride 2: de-interleaved columns, conv_tiling.h)
         }
     const int b_kg = wn * 2 + (p >> 1), b_sub = (p & 1) * 8;
 
@@ -157,7 +161,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         const int pix = (threadIdx.x >> 3) + 32 * k;
         p_rel[k] = 0;
         p_pyx[k] = 0xffffffffu;
-        p_lds[k] = (pix < t.NPP ? pix : t.NPP) * 64 + wg_pswz(pc4 >> 1, pix, t.pkb) * 16 + (pc4 & 1) * 8;
+        const int slot = pix < t.NPP ? cv_patch_slot(pix, ptab[pix], t, g.is) : t.NPP;
+        p_lds[k] = slot * 64 + wg_pswz(pc4 >> 1, slot, t.pkb) * 16 + (pc4 & 1) * 8;
         if (pix < t.NPP) {
             const unsigned e = ptab[pix];
             p_rel[k] = (((int)(e >> 20) * g.IH + (int)((e >> 10) & 1023)) * g.IW + (int)(e & 1023)) * g.Ci;
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     #pragma unroll
                 for (int tt = 0; tt < NT; tt++) {
                     if (tt < g.ntaps) {
-                        const int toff = (g.dy[tt] - t.dymin) * t.PW + (g.dx[tt] - t.dxmin);
+                        const int toff = (g.dy[tt] - t.dymin) * t.PW + cv_patch_col(g.dx[tt] - t.dxmin, t.PW, g.is);
                         const int pp0 = pbase[kk][0] + toff, pp1 = pbase[kk][1] + toff;
                         const int o0 = pp0 * 64 + wg_pswz(b_kg, pp0, t.pkb) * 16 + b_sub;
                         const int o1 = pp1 * 64 + wg_pswz(b_kg, pp1, t.pkb) * 16 + b_sub;
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                 f16x8 bq_hi, bq_lo;
                 auto read_b = [&](auto SN) {
                     constexpr int S2 = decltype(SN)::value, kk2 = S2 / NT, tt2 = S2 % NT;
-                    const int toff = (g.dy[tt2] - t.dymin) * t.PW + (g.dx[tt2] - t.dxmin);
+                    const int toff = (g.dy[tt2] - t.dymin) * t.PW + cv_patch_col(g.dx[tt2] - t.dxmin, t.PW, g.is);
                     const int pp0 = pbase[kk2][0] + toff, pp1 = pbase[kk2][1] + toff;
                     const int o0 = pp0 * 64 + wg_pswz(b_kg, pp0, t.pkb) * 16 + b_sub;
                     const int o1 = pp1 * 64 + wg_pswz(b_kg, pp1, t.pkb) * 16 + b_sub;
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
                         __builtin_amdgcn_sched_barrier(0);
                     } else if (ONEBB || tt < g.ntaps) {     // (ONEBB: the host guarantees ntaps == NT)
                         const int ts = (ONEBB || tt < g.ntaps) ? tt : 0;
-                        const int toff = (g.dy[ts] - t.dymin) * t.PW + (g.dx[ts] - t.dxmin);
+                        const int toff = (g.dy[ts] - t.dymin) * t.PW + cv_patch_col(g.dx[ts] - t.dxmin, t.PW, g.is);
                         const int pp0 = pbase[kk][0] + toff, pp1 = pbase[kk][1] + toff;
                         const int o0 = pp0 * 64 + wg_pswz(b_kg, pp0, t.pkb) * 16 + b_sub;
                         const int o1 = pp1 * 64 + wg_pswz(b_kg, pp1, t.pkb) * 16 + b_sub;

@@ -30,6 +30,16 @@ def test_wgrad_patch_swizzle_key_bit():
     assert lds_sim.wgrad_patch_reads(4, 2, 18, 1, 2, verbose=False) == 4.0
 
 
+def test_stride2_patch_columns_deinterleaved():
+    """Stride-2 layers (conv_tiling.h cv_patch_col): with row-major patch rows every transposing read of the weight-gradient
+    kernel is a 2-way conflict whatever single key bit is used; with the even / odd columns of a row de-interleaved the
+    gathered pixels are neighbours and the stride-1 key (bit 3, 16-wide tile) is conflict-free."""
+    assert min(lds_sim.wgrad_patch_reads(4, 2, 33, 2, kb, verbose=False) for kb in range(7)) == 4.0
+    assert lds_sim.wgrad_patch_reads(4, 2, 33, 2, 3, verbose=False, deint=True) == 2.0
+    assert lds_sim.wgrad_patch_reads(2, 2, 9, 2, 2, verbose=False, deint=True) == 2.0
+    assert lds_sim.wgrad_patch_reads(3, 3, 17, 2, 5, verbose=False, deint=True) < 2.25
+
+
 CT2_LAYERS = [(n, ih, ci, co) for n in (1, 2, 3, 4, 8, 25)
               for ih, ci, co in ((4, 512, 512), (8, 512, 512), (16, 512, 512), (32, 512, 512), (64, 512, 256), (128, 256, 128))]
 

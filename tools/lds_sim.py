@@ -84,27 +84,32 @@ if __name__ == '__main__':
         ct2(*a, use_map=True)
 
 
-def wgrad_patch_reads(tw_log2, th_log2, PW, is_, key_bit, nbe=1, PH=None, verbose=True):
+def wgrad_patch_reads(tw_log2, th_log2, PW, is_, key_bit, nbe=1, PH=None, verbose=True, deint=False):
     """conv_wgrad_kernel's B-operand reads: ds_read_b64_tr_b16, lane (G = lane>>4, q = (lane>>2)&3, p = lane&3) reads 8 B of
-    patch row pbase(r) + toff, r = kk*32 + G*8 + h*4 + q, at slot (b_kg ^ key(pp)) * 16 + (p&1) * 8, b_kg = wn*2 + (p>>1)."""
+    patch row pbase(r) + toff, r = kk*32 + G*8 + h*4 + q, at slot (b_kg ^ key(pp)) * 16 + (p&1) * 8, b_kg = wn*2 + (p>>1).
+    deint (stride 2, round 4): patch rows stored [even columns | odd columns] (conv_tiling.h cv_patch_col) — the gathered
+    pixels are neighbours and key bit 3 is conflict-free for the 16-wide tile (4.0 -> 2.0 cycles)."""
     tw, th = 1 << tw_log2, 1 << th_log2
     tot = n = 0
+    half = (PW + 1) // 2
+    col = (lambda x: (x >> 1) + (x & 1) * half) if deint else (lambda x: x)
+    toffs = ([dy * PW + col(dx) for dy in range(3) for dx in range(3)] if deint else list(range(0, 3 * PW, max(PW // 2, 1))))
     for kk in range(2):
         for h in range(2):
             for wn in range(2):
-                for toff in range(0, 3 * PW, max(PW // 2, 1)):
+                for toff in toffs:
                     addrs = []
                     for lane in range(64):
                         G, q, p = lane >> 4, (lane >> 2) & 3, lane & 3
                         r = kk * 32 + G * 8 + h * 4 + q
                         px, py, nbi = r & (tw - 1), (r >> tw_log2) & (th - 1), r >> (tw_log2 + th_log2)
                         nbi = min(nbi, nbe - 1)
-                        pp = (nbi * (PH or ((th - 1) * is_ + 3)) + py * is_) * PW + px * is_ + toff
+                        pp = (nbi * (PH or ((th - 1) * is_ + 3)) + py * is_) * PW + (px if deint else px * is_) + toff
                         b_kg = wn * 2 + (p >> 1)
                         key = ((pp >> key_bit) & 1) << 1
                         addrs.append(pp * 64 + (b_kg ^ key) * 16 + (p & 1) * 8)
                     tot += cycles(addrs, G64, 8)
                     n += 1
     if verbose:
-        print(f'wgrad tile {tw}x{th} PW {PW} stride {is_} key bit {key_bit}: {tot / n:.2f} cycles per ds_read_b64_tr_b16 (2 = conflict-free)')
+        print(f'wgrad tile {tw}x{th} PW {PW} stride {is_} key bit {key_bit}{" de-interleaved" if deint else ""}: {tot / n:.2f} cycles per ds_read_b64_tr_b16 (2 = conflict-free)')
     return tot / n

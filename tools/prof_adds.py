@@ -37,3 +37,13 @@ tot = sum(v[1] for _, v in rows)
 print(f'{which}: {sum(v[0] for _, v in rows)} pointwise aten launches, {tot / 1e3:.3f} ms device self time')
 for (k, sh), (n, t) in rows[:45]:
     print(f'{t:9.1f} us {n:4d}x  {k:22s} {sh}')
+if os.environ.get('BY_NAME'):
+    byname = collections.defaultdict(lambda: [0, 0.0])
+    for ev in prof.key_averages():
+        if ev.self_device_time_total > 0:
+            byname[ev.key][0] += ev.count
+            byname[ev.key][1] += ev.self_device_time_total
+    rows = sorted(byname.items(), key=lambda kv: -kv[1][1])
+    print(f'--- by name: {sum(v[0] for _, v in rows)} events with device time, {sum(v[1] for _, v in rows) / 1e3:.3f} ms')
+    for k, (n, t) in rows[:70]:
+        print(f'{t:9.1f} us {n:5d}x  {k[:120]}')
