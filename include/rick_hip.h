@@ -410,6 +410,33 @@ int rick_modbank_fwd_f32(const float *lat, int B, int n_latent, int K, const ric
                          int total_blocks, float scale, float *out, void *stream);
 int rick_modbank_bwd_f32(const float *lat, const float *gs, int B, int n_latent, int K, const rick_modbank_desc *descs_device,
                          int n, int total_blocks, float scale, float *grad, int accumulate, void *stream);
+/* Demodulation bank: the demodulation coefficients of EVERY demodulated convolution of a generator (model_probe_tune.py:246-252)
+ * in one launch, their weight gradient in one more, wsq[o,i] = scale^2 sum_k w[o,i,k]^2 in a third that only runs when the
+ * weights have changed.  Same arithmetic and order per element as rick_wsq_f32 / rick_demod_f32 / rick_demod_bwd_w_f32
+ * (bit-identical).  Layer l reads s_l [B, I] at float offset s_off of the modulation bank's flat output and owns d_l / gd_l
+ * [B, O] at d_off of the flat coefficient / gradient buffers; gw (the parameter's gradient buffer, accumulated into) may be NULL.
+ * Block ranges: [blk_wsq, next) of rick_demod_blocks_wsq(O, I) blocks for the wsq and weight-gradient launches,
+ * [blk_demod, next) of rick_demod_blocks(O) for the coefficient launch, [blk_bwd_s, next) of rick_demod_blocks_bwd_s(I) for the
+ * style gradient gs_l [B, I] (written at s_off of gs_flat).  B <= 8. */
+typedef struct rick_demod_desc {
+    const float *w;         /* [O, I, K] contiguous */
+    float *wsq;             /* [O, I] */
+    float *gw;              /* [O, I, K] or NULL */
+    int64_t s_off, d_off;
+    int O, I, K;
+    float scale2;           /* (conv scale)^2 */
+    int blk_wsq, blk_demod, blk_bwd_s, reserved;
+} rick_demod_desc;
+int rick_demod_blocks_wsq(int O, int I);
+int rick_demod_blocks(int O);
+int rick_wsq_multi_f32(const rick_demod_desc *descs_device, int n, int total_blocks, void *stream);
+int rick_demod_multi_f32(const float *s_flat, float *d_flat, const rick_demod_desc *descs_device, int n, int total_blocks,
+                         int B, int max_I, float eps, void *stream);
+int rick_demod_bwd_w_multi_f32(const float *s_flat, const float *d_flat, const float *gd_flat,
+                               const rick_demod_desc *descs_device, int n, int total_blocks, int B, void *stream);
+int rick_demod_blocks_bwd_s(int I);
+int rick_demod_bwd_s_multi_f32(const float *s_flat, const float *d_flat, const float *gd_flat, float *gs_flat,
+                               const rick_demod_desc *descs_device, int n, int total_blocks, int B, int max_O, void *stream);
 /* EqualLinear forward on a short batch (the mapping network, model_probe_tune.py:139-173, 418-428; no autograd):
  *   x' = pixelnorm ? x * rsqrt(mean_k x^2 + 1e-8) : x                                  (PixelNorm, :92-98)
  *   out[b,o] = act(scale * sum_k x'[b,k] W[o,k] + bias[o] * bias_mul);  act != 0: gain * leaky_relu(., slope)

@@ -121,6 +121,13 @@ SIGNATURES = {
     'rick_demod_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_f, c_fp]),
     'rick_demod_bwd_s_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     'rick_demod_bwd_w_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_f, c_int, c_fp]),
+    'rick_demod_blocks_wsq': (c_int, [c_int, c_int]),
+    'rick_demod_blocks': (c_int, [c_int]),
+    'rick_demod_blocks_bwd_s': (c_int, [c_int]),
+    'rick_wsq_multi_f32': (c_int, [c_fp, c_int, c_int, c_fp]),
+    'rick_demod_multi_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_f, c_fp]),
+    'rick_demod_bwd_w_multi_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
+    'rick_demod_bwd_s_multi_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     'rick_modbank_blocks': (c_int, [c_int]),
     'rick_modbank_fwd_f32': (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int, c_int, c_f, c_fp, c_fp]),
     'rick_modbank_bwd_f32': (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_int, c_int, c_f, c_fp, c_int, c_fp]),

@@ -8,6 +8,7 @@
 #include "common.h"
 
 #define MOD_MAXB 32
+#define MB_MAXB 8         // modulation / demodulation banks: batch <= 8
 
 __global__ __launch_bounds__(256) void wsq_kernel(const float *__restrict__ w, float *__restrict__ wsq, int64_t OI, int K,
                                                   float scale2) {
@@ -181,6 +182,204 @@ extern "C" int rick_demod_bwd_w_f32(const float *w, const float *s, const float 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Demodulation bank: the three kernels above for EVERY demodulated convolution of a generator in one launch each (13 layers
+// at 256 px: 13 wsq + 13 demod launches of 5-6 us per forward, 13 weight-gradient launches of ~10 us per backward — 0.43 ms of
+// a train iteration).  Same arithmetic per element, in the same order (bit-identical to the per-layer kernels).  wsq depends
+// on the weights only: the host recomputes it once per update of the network (rick_wsq_multi_f32, with the weight packs) and
+// every forward in between reads it.  Layer l: s_l [B, I] at float offset s_off of the modulation bank's flat output,
+// d_l / gd_l [B, O] at d_off of the flat coefficient / gradient buffer; blocks [blk_*, next layer's blk_*).
+__global__ __launch_bounds__(256) void wsq_multi_kernel(const rick_demod_desc *__restrict__ descs, int n) {
+    int l = 0;
+    for (int i = 1; i < n; i++)
+        if ((int)blockIdx.x >= descs[i].blk_wsq) l = i;
+    const rick_demod_desc ds = descs[l];
+    const int64_t OI = (int64_t)ds.O * ds.I;
+    const int64_t i = (int64_t)((int)blockIdx.x - ds.blk_wsq) * 256 + threadIdx.x;
+    if (i >= OI) return;
+    const float *p = ds.w + i * ds.K;
+    float s = 0.f;
+    for (int k = 0; k < ds.K; k++) s = __builtin_fmaf(p[k], p[k], s);
+    ds.wsq[i] = s * ds.scale2;
+}
+
+__global__ __launch_bounds__(256) void demod_multi_kernel(const float *__restrict__ s_flat, float *__restrict__ d_flat,
+                                                          const rick_demod_desc *__restrict__ descs, int n, int B, float eps) {
+    extern __shared__ float s2[];   // [B][I]
+    int l = 0;
+    for (int i = 1; i < n; i++)
+        if ((int)blockIdx.x >= descs[i].blk_demod) l = i;
+    const rick_demod_desc ds = descs[l];
+    const int I = ds.I, O = ds.O;
+    const float *s = s_flat + ds.s_off;
+    for (int j = threadIdx.x; j < B * I; j += 256) {
+        const float v = s[j];
+        s2[j] = v * v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int o = ((int)blockIdx.x - ds.blk_demod) * 4 + (threadIdx.x >> 6);
+    if (o >= O) return;
+    float acc[MB_MAXB];
+#pragma unroll
+    for (int b = 0; b < MB_MAXB; b++) acc[b] = 0.f;
+    const float *wr = ds.wsq + (int64_t)o * I;
+    int i = lane;
+    for (; i + 192 < I; i += 256) {
+        const float w0 = wr[i], w1 = wr[i + 64], w2 = wr[i + 128], w3 = wr[i + 192];
+#pragma unroll
+        for (int b = 0; b < MB_MAXB; b++)
+            if (b < B) {
+                const float *sb = s2 + b * I + i;
+                acc[b] = __builtin_fmaf(sb[0], w0, acc[b]);
+                acc[b] = __builtin_fmaf(sb[64], w1, acc[b]);
+                acc[b] = __builtin_fmaf(sb[128], w2, acc[b]);
+                acc[b] = __builtin_fmaf(sb[192], w3, acc[b]);
+            }
+    }
+    for (; i < I; i += 64) {
+        const float wv = wr[i];
+#pragma unroll
+        for (int b = 0; b < MB_MAXB; b++)
+            if (b < B) acc[b] = __builtin_fmaf(s2[b * I + i], wv, acc[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < MB_MAXB; b++)
+        if (b < B) {
+            const float tot = wave_sum(acc[b]);
+            if (lane == 0) d_flat[ds.d_off + (int64_t)b * O + o] = rsqrtf(tot + eps);
+        }
+}
+
+__global__ __launch_bounds__(256) void demod_bwd_w_multi_kernel(const float *__restrict__ s_flat, const float *__restrict__ d_flat,
+                                                                const float *__restrict__ gd_flat,
+                                                                const rick_demod_desc *__restrict__ descs, int n, int B) {
+    int l = 0;
+    for (int i = 1; i < n; i++)
+        if ((int)blockIdx.x >= descs[i].blk_wsq) l = i;
+    const rick_demod_desc ds = descs[l];
+    if (!ds.gw) return;                                   // frozen layer
+    const int I = ds.I, O = ds.O, K = ds.K;
+    const int64_t j = (int64_t)((int)blockIdx.x - ds.blk_wsq) * 256 + threadIdx.x;
+    if (j >= (int64_t)O * I) return;
+    const float *s = s_flat + ds.s_off, *d = d_flat + ds.d_off, *gd = gd_flat + ds.d_off;
+    const int o = (int)(j / I), i = (int)(j - (int64_t)o * I);
+    float acc = 0.f;
+    for (int b = 0; b < B; b++) {
+        const float dv = d[(int64_t)b * O + o], sv = s[(int64_t)b * I + i];
+        acc = __builtin_fmaf(-0.5f * dv * dv * dv * gd[(int64_t)b * O + o], sv * sv, acc);
+    }
+    const float f = 2.f * ds.scale2 * acc;
+    const float *w = ds.w;
+    float *gw = ds.gw;
+    for (int k = 0; k < K; k++) gw[j * K + k] += w[j * K + k] * f;      // (always accumulates: gw is the parameter's .grad)
+}
+
+__global__ __launch_bounds__(64 * DBS_WAVES) void demod_bwd_s_multi_kernel(const float *__restrict__ s_flat,
+                                                                          const float *__restrict__ d_flat,
+                                                                          const float *__restrict__ gd_flat, float *__restrict__ gs_flat,
+                                                                          const rick_demod_desc *__restrict__ descs, int n, int B) {
+    extern __shared__ float tl[];   // [B][O] t values, then [DBS_WAVES][B][64] wave partials
+    int l = 0;
+    for (int i = 1; i < n; i++)
+        if ((int)blockIdx.x >= descs[i].blk_bwd_s) l = i;
+    const rick_demod_desc ds = descs[l];
+    const int I = ds.I, O = ds.O;
+    const float *s = s_flat + ds.s_off, *d = d_flat + ds.d_off, *gd = gd_flat + ds.d_off, *wsq = ds.wsq;
+    float *gs = gs_flat + ds.s_off;
+    float *part = tl + B * O;
+    for (int j = threadIdx.x; j < B * O; j += 64 * DBS_WAVES) {
+        const float dv = d[j];
+        tl[j] = -0.5f * dv * dv * dv * gd[j];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blk = (int)blockIdx.x - ds.blk_bwd_s;
+    const int i = blk * 64 + lane;
+    const int o_per = (O + DBS_WAVES - 1) / DBS_WAVES, o0 = wave * o_per, o1 = o0 + o_per < O ? o0 + o_per : O;
+    float acc[MB_MAXB];
+#pragma unroll
+    for (int b = 0; b < MB_MAXB; b++) acc[b] = 0.f;
+    if (i < I) {
+        const float *wc = wsq + i;
+        int o = o0;
+        for (; o + 3 < o1; o += 4) {
+            const float w0 = wc[(int64_t)o * I], w1 = wc[(int64_t)(o + 1) * I], w2 = wc[(int64_t)(o + 2) * I],
+                        w3 = wc[(int64_t)(o + 3) * I];
+#pragma unroll
+            for (int b = 0; b < MB_MAXB; b++)
+                if (b < B) {
+                    const float *tb = tl + b * O + o;
+                    acc[b] = __builtin_fmaf(tb[0], w0, acc[b]);
+                    acc[b] = __builtin_fmaf(tb[1], w1, acc[b]);
+                    acc[b] = __builtin_fmaf(tb[2], w2, acc[b]);
+                    acc[b] = __builtin_fmaf(tb[3], w3, acc[b]);
+                }
+        }
+        for (; o < o1; o++) {
+            const float wv = wc[(int64_t)o * I];
+#pragma unroll
+            for (int b = 0; b < MB_MAXB; b++)
+                if (b < B) acc[b] = __builtin_fmaf(tl[b * O + o], wv, acc[b]);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < MB_MAXB; b++)
+        if (b < B) part[(wave * B + b) * 64 + lane] = acc[b];
+    __syncthreads();
+    for (int j = threadIdx.x; j < B * 64; j += 64 * DBS_WAVES) {
+        const int b = j >> 6, ll = j & 63, ii = blk * 64 + ll;
+        if (ii < I) {
+            float tot = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < DBS_WAVES; wv++) tot += part[(wv * B + b) * 64 + ll];
+            gs[(int64_t)b * I + ii] = 2.f * s[(int64_t)b * I + ii] * tot;
+        }
+    }
+}
+
+extern "C" int rick_demod_blocks_bwd_s(int I) { return cdiv(I, 64); }
+
+extern "C" int rick_demod_bwd_s_multi_f32(const float *s_flat, const float *d_flat, const float *gd_flat, float *gs_flat,
+                                          const rick_demod_desc *descs_device, int n, int total_blocks, int B, int max_O,
+                                          void *stream) {
+    if (!s_flat || !d_flat || !gd_flat || !gs_flat || !descs_device || n < 1 || total_blocks < 1 || B < 1 || B > MB_MAXB || max_O < 1)
+        return RICK_EINVAL;
+    const size_t lds = ((size_t)B * max_O + DBS_WAVES * (size_t)B * 64) * sizeof(float);
+    if (lds > 160 * 1024) return RICK_EINVAL;
+    (void)hipFuncSetAttribute((const void *)demod_bwd_s_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(demod_bwd_s_multi_kernel, dim3((unsigned)total_blocks), dim3(64 * DBS_WAVES), lds, (hipStream_t)stream, s_flat,
+                       d_flat, gd_flat, gs_flat, descs_device, n, B);
+    RICK_LAUNCH_STATUS();
+}
+
+extern "C" int rick_demod_blocks_wsq(int O, int I) { return (int)cdiv64((int64_t)O * I, 256); }
+extern "C" int rick_demod_blocks(int O) { return cdiv(O, 4); }
+
+extern "C" int rick_wsq_multi_f32(const rick_demod_desc *descs_device, int n, int total_blocks, void *stream) {
+    if (!descs_device || n < 1 || total_blocks < 1) return RICK_EINVAL;
+    hipLaunchKernelGGL(wsq_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, descs_device, n);
+    RICK_LAUNCH_STATUS();
+}
+
+extern "C" int rick_demod_multi_f32(const float *s_flat, float *d_flat, const rick_demod_desc *descs_device, int n,
+                                    int total_blocks, int B, int max_I, float eps, void *stream) {
+    if (!s_flat || !d_flat || !descs_device || n < 1 || total_blocks < 1 || B < 1 || B > MB_MAXB || max_I < 1) return RICK_EINVAL;
+    const size_t lds = (size_t)B * max_I * sizeof(float);
+    if (lds > 64 * 1024) return RICK_EINVAL;
+    hipLaunchKernelGGL(demod_multi_kernel, dim3((unsigned)total_blocks), dim3(256), lds, (hipStream_t)stream, s_flat, d_flat,
+                       descs_device, n, B, eps);
+    RICK_LAUNCH_STATUS();
+}
+
+extern "C" int rick_demod_bwd_w_multi_f32(const float *s_flat, const float *d_flat, const float *gd_flat,
+                                          const rick_demod_desc *descs_device, int n, int total_blocks, int B, void *stream) {
+    if (!s_flat || !d_flat || !gd_flat || !descs_device || n < 1 || total_blocks < 1 || B < 1 || B > MB_MAXB) return RICK_EINVAL;
+    hipLaunchKernelGGL(demod_bwd_w_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, s_flat, d_flat,
+                       gd_flat, descs_device, n, B);
+    RICK_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Modulation bank: the style -> per-channel scale linears of EVERY modulated convolution of the generator
 // (ModulatedConv2d.modulation = EqualLinear(style_dim, in_channel, bias_init=1), model_probe_tune.py:233,246; 13
 // StyledConvs + 7 ToRGBs at 256 px) in ONE launch, and their weight / bias gradients in one more — instead of one
@@ -192,7 +391,6 @@ extern "C" int rick_demod_bwd_w_f32(const float *w, const float *s, const float 
 // io_off of the flat output / gradient-input buffer, gW_l / gb_l at gw_off / gb_off of the flat gradient buffer.
 // K % 256 == 0, B <= 8.
 #define MB_ROWS 32       // channels per block
-#define MB_MAXB 8
 
 __global__ __launch_bounds__(256) void modbank_fwd_kernel(const float *__restrict__ lat, int B, int n_latent, int K,
                                                           const rick_modbank_desc *__restrict__ descs, int n, float scale,

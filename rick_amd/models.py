@@ -27,6 +27,7 @@ from .op.upfirdn2d import upfirdn2d
 CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512}
 # tests / tools switch the one-node split-image ResBlock (op/dblock.py) off to compare with the per-layer path
 _USE_DBLOCK = not os.environ.get('RICK_NO_DBLOCK')
+_USE_DEMOD_BANK = not os.environ.get('RICK_NO_DEMOD_BANK')      # (A/B switch, tools/ab_*.sh)
 
 
 def _channels(res, channel_multiplier):
@@ -240,7 +241,7 @@ class StyledConv(nn.Module):
         tail = (self.activate.bias, noise, self.noise.weight, self.activate.negative_slope, self.activate.scale)
         if op.second_order_enabled():
             return fused_noise_bias_act(self.conv(x, style, s=s, d=d), *tail)
-        return self.conv(x, style, tail, s=s, next_s=next_s)
+        return self.conv(x, style, tail, s=s, d=d, next_s=next_s)
 
 
 class ToRGB(nn.Module):
@@ -321,6 +322,18 @@ class Generator(nn.Module, _FisherMixin):
                 idx += [i, i + 1, i + 2]
                 i += 2
             bank = self.__dict__['_modbank'] = _mc.ModulationBank(mods, idx)
+        return bank
+
+    def _demod_bank(self):
+        """DemodBank over the demodulated convolutions in forward order (conv1, then the two StyledConvs of every resolution)
+        with the position of each one's style vector in the modulation bank's output."""
+        bank = self.__dict__.get('_dmbank')
+        if bank is None:
+            convs, idx = [self.conv1.conv], [0]
+            for blk in range(len(self.to_rgbs)):
+                convs += [self.convs[2 * blk].conv, self.convs[2 * blk + 1].conv]
+                idx += [2 + 3 * blk, 3 + 3 * blk]
+            bank = self.__dict__['_dmbank'] = _mc.DemodBank(convs, idx, self._modulation_bank().C)
         return bank
 
     def _styles_batched(self, latent):
@@ -413,6 +426,12 @@ class Generator(nn.Module, _FisherMixin):
         if (latent.is_cuda and not op.second_order_enabled() and not latent.requires_grad and latent.ndim == 3
                 and latent.shape[0] <= 8 and latent.shape[1] == self.n_latent and latent.dtype == torch.float32):
             sb = self._modulation_bank()(latent)
+            if _USE_DEMOD_BANK:     # every layer's demodulation coefficients from one launch (wsq cached per weight update)
+                dl = self._demod_bank()(sb)
+                if dl is not None:
+                    bank = self._demod_bank()
+                    for j, d_l in zip(bank.s_index, dl):
+                        db[j] = d_l
         elif latent.is_cuda and op.second_order_enabled() and latent.ndim == 3 and latent.shape[1] == self.n_latent:
             sb, db = self._styles_batched(latent)
         # (next_s: the style scales of the following modulated convolution — a layer folds them into the split image it writes

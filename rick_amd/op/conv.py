@@ -89,6 +89,12 @@ def get_precision():
     return 'fp16x3' if _SPLIT == 2 else 'fp16'
 
 
+def weights_stamp(param):
+    """What a cached function of `param`'s values is valid for (the same triple the packed-weight caches compare)."""
+    grp = getattr(param, '_rick_group', None)
+    return (param._version, _weights_epoch, grp.epoch if grp is not None else -1, param.data_ptr())
+
+
 def bump_weights_epoch(params=None):
     """Invalidate cached packed weights (call after any raw-pointer parameter update).  With `params`
     (the parameters that were updated) only their PackGroups go stale; parameters outside any group, or
@@ -151,6 +157,7 @@ class PackGroup:
         self.total_blocks = 0
         self.retired = []       # tables a captured graph may still reference
         self.epoch = 0          # bumped when this network's parameters were updated through raw pointers
+        self.after_repack = []  # callables run behind the pack launch (weight-only side products: modconv.DemodBank's wsq)
 
     def _append(self, req):
         """Write the request's descriptor behind the existing ones (host mirror + the one device entry)."""
@@ -225,6 +232,8 @@ class PackGroup:
             for k in stale:
                 del self.reqs[k]
             self._rebuild()
+        for cb in self.after_repack:
+            cb()
         if not self.reqs:
             return
         check(lib.rick_conv_pack_weights_multi(ptr(self.table), self.n, self.total_blocks, _SPLIT, stream_ptr()),

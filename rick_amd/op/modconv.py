@@ -542,3 +542,213 @@ class _ModBank(Function):
             res.append(grad[bank.gw_off[i]:bank.gw_off[i] + c * K].view(c, K) if need_w else None)
             res.append(grad[bank.gb_off[i]:bank.gb_off[i] + c] if need_b else None)
         return tuple(res)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# rick_demod_desc (include/rick_hip.h), 72 bytes
+_DM_DESC = np.dtype([('w', '<u8'), ('wsq', '<u8'), ('gw', '<u8'), ('s_off', '<i8'), ('d_off', '<i8'), ('O', '<i4'), ('I', '<i4'),
+                     ('K', '<i4'), ('scale2', '<f4'), ('blk_wsq', '<i4'), ('blk_demod', '<i4'), ('blk_bwd_s', '<i4'),
+                     ('reserved', '<i4')])
+
+
+class DemodBank:
+    """The demodulation coefficients d_l = rsqrt(sum_i s_l^2 wsq_l + eps) of every demodulated convolution of a generator
+    (model_probe_tune.py:246-252) from ONE launch, their style and weight gradients from one launch each, and
+    wsq_l = scale^2 sum_k w_l^2 — a function of the weights only — recomputed once per update of the network instead of
+    in every forward (behind the weight packs, PackGroup.after_repack).  Per layer the four kernels of `_DemodFused` cost
+    13 x (5.6 + 6.0) us per forward and 13 x (9.6 + 10.2) us per backward at 256 px: 0.43 ms of a train iteration.  Same
+    arithmetic and summation order per element: the coefficients and gradients are bit-identical to the per-layer path.
+
+    `convs`: the ModulatedConv2d modules with demodulate=True in forward order; `s_index[l]`: position of layer l's style
+    vector in the ModulationBank's output list; `mod_C`: channel count of every entry of that list (its flat layout)."""
+
+    def __init__(self, convs, s_index, mod_C):
+        self.convs, self.s_index, self.mod_C = list(convs), list(s_index), list(mod_C)
+        self.O = [c.weight.shape[1] for c in self.convs]
+        self.I = [c.weight.shape[2] for c in self.convs]
+        self.K = [c.weight.shape[3] * c.weight.shape[4] for c in self.convs]
+        self.eps = self.convs[0].eps
+        if any(c.eps != self.eps or not c.demodulate or self.mod_C[j] != i for c, j, i in zip(self.convs, self.s_index, self.I)):
+            raise RuntimeError('DemodBank: layers must share eps and read a style vector of their input width')
+        self.blk_wsq, self.blk_demod, self.blk_bwd_s = [], [], []
+        a = b = c = 0
+        for o, i in zip(self.O, self.I):
+            self.blk_wsq.append(a)
+            self.blk_demod.append(b)
+            self.blk_bwd_s.append(c)
+            a += lib.rick_demod_blocks_wsq(o, i)
+            b += lib.rick_demod_blocks(o)
+            c += lib.rick_demod_blocks_bwd_s(i)
+        self.total_wsq, self.total_demod, self.total_bwd_s = a, b, c
+        self._wsq = None            # persistent [O_l * I_l] buffers
+        self._stamps = None
+        self._tables = {}           # (B, sink) -> (device table, signature)
+        self._retired = []
+        self._hooked = None
+
+    def weights(self):
+        return [c.weight for c in self.convs]
+
+    def offsets(self, B):
+        mod_off, pos = [], 0
+        for c in self.mod_C:
+            mod_off.append(pos)
+            pos += B * c
+        d_off, q = [], 0
+        for o in self.O:
+            d_off.append(q)
+            q += B * o
+        return [mod_off[j] for j in self.s_index], d_off, pos, q
+
+    def _sinks(self):
+        out = []
+        for w in self.weights():
+            g = w.grad
+            ok = (w.is_leaf and w.requires_grad and g is not None and g.is_contiguous() and g.dtype == torch.float32
+                  and g.numel() == w.numel())
+            out.append(g if ok else None)
+        return out
+
+    def table(self, B, device, sink=False):
+        ws = self.weights()
+        if self._wsq is None or self._wsq[0].device != device:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('DemodBank: buffers must exist before hipGraph capture (run the step eagerly once)')
+            self._wsq = [torch.empty(o * i, device=device, dtype=torch.float32) for o, i in zip(self.O, self.I)]
+            self._stamps = None
+        grads = self._sinks() if sink else [None] * len(ws)
+        sig = (tuple(w.data_ptr() for w in ws), tuple(g.data_ptr() if g is not None else 0 for g in grads),
+               tuple(q.data_ptr() for q in self._wsq))
+        ent = self._tables.get((B, sink))
+        if ent is None or ent[1] != sig:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('DemodBank: descriptor table must be built before hipGraph capture (run the step eagerly once)')
+            s_off, d_off, _, _ = self.offsets(B)
+            arr = np.zeros(len(ws), dtype=_DM_DESC)
+            for l, (w, c) in enumerate(zip(ws, self.convs)):
+                arr[l] = (w.data_ptr(), self._wsq[l].data_ptr(), grads[l].data_ptr() if grads[l] is not None else 0, s_off[l],
+                          d_off[l], self.O[l], self.I[l], self.K[l], np.float32(c.scale) * np.float32(c.scale), self.blk_wsq[l],
+                          self.blk_demod[l], self.blk_bwd_s[l], 0)
+            if ent is not None:
+                self._retired.append(ent[0])
+            ent = (torch.from_numpy(arr.view(np.uint8).copy()).to(device), sig)
+            self._tables[(B, sink)] = ent
+        return ent[0]
+
+    def _current(self):
+        from .conv import weights_stamp
+        return [weights_stamp(w) for w in self.weights()]
+
+    def refresh_wsq(self, force=False):
+        """wsq of every layer in one launch if any weight changed since the last one (host side; PackGroup.after_repack calls
+        it whenever the network is repacked, __call__ when it finds the stamps stale)."""
+        ws = self.weights()
+        if not ws[0].is_cuda:
+            return
+        cur = self._current()
+        if not force and self._stamps == cur and self._wsq is not None:
+            return
+        tab = self.table(1, ws[0].device)
+        check(lib.rick_wsq_multi_f32(ptr(tab), len(ws), self.total_wsq, stream_ptr()), 'rick_wsq_multi_f32')
+        self._stamps = cur
+
+    def _hook(self):
+        grp = getattr(self.weights()[0], '_rick_group', None)
+        if grp is not None and self._hooked is not grp:
+            import weakref
+            ref = weakref.ref(self)
+            grp.after_repack.append(lambda: ref() is not None and ref().refresh_wsq())
+            self._hooked = grp
+
+    def usable(self, s_list):
+        """The style vectors must be the ModulationBank's own views (one flat buffer in its layout), contiguous float32."""
+        B = s_list[self.s_index[0]].shape[0]
+        if B > 8 or any(not w.is_contiguous() for w in self.weights()):
+            return False
+        s_off, _, _, _ = self.offsets(B)
+        s0 = s_list[self.s_index[0]]
+        base = s0.data_ptr() - 4 * s_off[0]
+        return all(s_list[j].dtype == torch.float32 and s_list[j].is_contiguous() and s_list[j].data_ptr() == base + 4 * o
+                   for j, o in zip(self.s_index, s_off))
+
+    def __call__(self, s_list):
+        """s_list: the ModulationBank's outputs -> list of d_l [B, O_l] (None when the inputs do not have the bank's layout)."""
+        if not self.usable(s_list):
+            return None
+        self._hook()
+        self.refresh_wsq()
+        return list(_DemodBankFn.apply(self, *[s_list[j] for j in self.s_index], *self.weights()))
+
+
+class _DemodBankFn(Function):
+    @staticmethod
+    def forward(ctx, bank, *args):
+        L = len(bank.convs)
+        ss, ws = args[:L], args[L:]
+        B = ss[0].shape[0]
+        dev = ss[0].device
+        s_off, d_off, _, d_total = bank.offsets(B)
+        tab = bank.table(B, dev)
+        d_flat = torch.empty(d_total, device=dev, dtype=torch.float32)
+        s_base = ss[0].data_ptr() - 4 * s_off[0]
+        check(lib.rick_demod_multi_f32(s_base, ptr(d_flat), ptr(tab), L, bank.total_demod, B, max(bank.I), float(bank.eps),
+                                       stream_ptr()), 'rick_demod_multi_f32')
+        ctx.bank, ctx.B = bank, B
+        ctx.sink = grad_sink_enabled()
+        ctx.w_param = [param_like(w) for w in ws]
+        ctx.save_for_backward(d_flat, *ss, *ws)
+        ctx.set_materialize_grads(False)
+        return tuple(d_flat[o:o + B * n].view(B, n) for o, n in zip(d_off, bank.O))
+
+    @staticmethod
+    def backward(ctx, *gds):
+        bank, B = ctx.bank, ctx.B
+        L = len(bank.convs)
+        d_flat, *rest = ctx.saved_tensors
+        ss, ws = rest[:L], rest[L:]
+        need_s, need_w = ctx.needs_input_grad[1:1 + L], ctx.needs_input_grad[1 + L:]
+        if torch.is_grad_enabled():     # create_graph=True: the tensor-algebra form per layer, differentiable to any order
+            from ._twice import second_order_backward
+
+            def compose(*a):
+                return tuple(demod_coeff(a[L + l].view(bank.O[l], bank.I[l], *bank.convs[l].weight.shape[3:]), a[l],
+                                         bank.convs[l].scale, bank.eps) for l in range(L))
+            res = second_order_backward(compose, list(ss) + list(ws), list(need_s) + list(need_w), gds,
+                                        tuple([False] * L + list(ctx.w_param)))
+            return (None, *res)
+        if not (any(need_s) or any(need_w)) or all(g is None for g in gds):
+            return (None,) * (1 + 2 * L)
+        dev = d_flat.device
+        s_off, d_off, s_total, _ = bank.offsets(B)
+        gd_flat = torch.cat([(g.contiguous() if g is not None else d_flat.new_zeros(B * o)).reshape(-1) for g, o in zip(gds, bank.O)])
+        s_base = ss[0].data_ptr() - 4 * s_off[0]
+        gs = [None] * L
+        if any(need_s):
+            gs_flat = torch.empty(s_total, device=dev, dtype=torch.float32)
+            check(lib.rick_demod_bwd_s_multi_f32(s_base, ptr(d_flat), ptr(gd_flat), ptr(gs_flat), ptr(bank.table(B, dev)), L,
+                                                 bank.total_bwd_s, B, max(bank.O), stream_ptr()), 'rick_demod_bwd_s_multi_f32')
+            gs = [gs_flat[o:o + B * i].view(B, i) if n else None for o, i, n in zip(s_off, bank.I, need_s)]
+        gw = [None] * L
+        if any(need_w):
+            sinks = bank._sinks() if ctx.sink else [None] * L
+            if all(g is not None for g, n in zip(sinks, need_w) if n):
+                # op.grad_sink(): one launch adds every layer's gradient straight into the parameter's .grad (frozen layers and
+                # layers that need none carry a NULL pointer in the table and are skipped)
+                if any(g is not None and not n for g, n in zip(sinks, need_w)):
+                    sinks = None       # (a .grad buffer on a weight that must not receive a gradient: per-layer path below)
+            else:
+                sinks = None
+            if sinks is not None:
+                check(lib.rick_demod_bwd_w_multi_f32(s_base, ptr(d_flat), ptr(gd_flat), ptr(bank.table(B, dev, sink=True)), L,
+                                                     bank.total_wsq, B, stream_ptr()), 'rick_demod_bwd_w_multi_f32')
+            else:
+                for l in range(L):
+                    if not need_w[l]:
+                        continue
+                    w = ws[l]
+                    gw[l] = torch.empty_like(w)
+                    dl = d_flat[d_off[l]:d_off[l] + B * bank.O[l]]
+                    gl = gd_flat[d_off[l]:d_off[l] + B * bank.O[l]]
+                    check(lib.rick_demod_bwd_w_f32(ptr(w), ptr(ss[l]), ptr(dl), ptr(gl), ptr(gw[l]), B, bank.I[l], bank.O[l],
+                                                   bank.K[l], float(bank.convs[l].scale), 0, stream_ptr()), 'rick_demod_bwd_w_f32')
+        return (None, *gs, *gw)

@@ -1,0 +1,146 @@
+"""DemodBank (rick_amd/op/modconv.py): the demodulation coefficients of every generator layer from one launch, wsq cached per
+weight update — bit-identical to the per-layer kernels it replaces (same arithmetic, same order), forward and backward."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gen(size=64):
+    from rick_amd.models import Generator
+    torch.manual_seed(3)
+    g = Generator(size, 512, 2).cuda()
+    with torch.no_grad():
+        for p in g.parameters():            # spread the weights so that demodulation matters
+            if p.ndim == 5:
+                p.mul_(torch.rand(p.shape[1], device=p.device).view(1, -1, 1, 1, 1) * 2 + 0.2)
+    return g
+
+
+def _run(g, latent, noise, use_bank, sink=False):
+    import rick_amd.models as M
+    from rick_amd import op
+    M._USE_DEMOD_BANK = use_bank
+    try:
+        for p in g.parameters():
+            p.grad = torch.zeros_like(p) if sink else None
+        if sink:
+            with op.grad_sink():
+                img, _ = g([latent], input_is_latent=True, noise=noise)
+                (img * torch.linspace(-1, 1, img.numel(), device=img.device).view_as(img)).sum().backward()
+        else:
+            img, _ = g([latent], input_is_latent=True, noise=noise)
+            (img * torch.linspace(-1, 1, img.numel(), device=img.device).view_as(img)).sum().backward()
+        return img.detach().clone(), {n: p.grad.clone() for n, p in g.named_parameters() if p.grad is not None}
+    finally:
+        M._USE_DEMOD_BANK = True
+
+
+@pytest.mark.parametrize('sink', [False, True])
+def test_demod_bank_equals_per_layer_path_bitwise(sink):
+    g = _gen()
+    for p in g.style.parameters():
+        p.requires_grad_(False)
+    B = 4
+    latent = torch.randn(B, g.n_latent, 512, device='cuda')
+    noise = [torch.randn(1, 1, n.shape[-1], n.shape[-1], device='cuda') for n in g.make_noise()]
+    img0, gr0 = _run(g, latent, noise, False, sink)
+    img1, gr1 = _run(g, latent, noise, True, sink)
+    assert g.__dict__.get('_dmbank') is not None and g._dmbank._stamps is not None      # the bank did run
+    assert torch.equal(img0, img1)
+    assert gr0.keys() == gr1.keys() and len(gr0) > 20
+    for k in gr0:
+        assert torch.equal(gr0[k], gr1[k]), k
+
+
+def test_demod_bank_coefficients_and_wsq_refresh():
+    """d of every layer == demod_coeff_fused (bitwise) and == the tensor-algebra form (1e-6); after an in-place weight update the
+    cached wsq is recomputed (stamp = parameter version / weights epoch), not reused."""
+    from rick_amd.op import modconv as mc
+    g = _gen()
+    B = 3
+    latent = torch.randn(B, g.n_latent, 512, device='cuda')
+    with torch.no_grad():
+        sb = g._modulation_bank()(latent)
+        bank = g._demod_bank()
+        for rnd in range(2):
+            dl = bank(sb)
+            assert dl is not None and len(dl) == len(bank.convs)
+            for c, j, d in zip(bank.convs, bank.s_index, dl):
+                w = c.weight.view(c.out_channel, c.in_channel, c.kernel_size, c.kernel_size)
+                ref = mc.demod_coeff_fused(w, sb[j], c.scale, c.eps)
+                assert torch.equal(d, ref)
+                torch.testing.assert_close(d, mc.demod_coeff(w.double(), sb[j].double(), c.scale, c.eps).float(), rtol=2e-6, atol=0)
+            launched = bank._stamps
+            bank(sb)
+            assert bank._stamps is launched or bank._stamps == launched          # nothing changed: wsq not recomputed
+            for c in bank.convs[::3]:
+                c.weight.mul_(1.25)                                               # in place: bumps the version counter
+
+
+def test_demod_bank_create_graph_falls_back_to_tensor_algebra():
+    """A create_graph=True backward through the bank differentiates the per-layer tensor algebra: the second derivative of the
+    image w.r.t. a convolution weight through d exists and matches the per-layer path."""
+    import rick_amd.models as M
+    g = _gen(32)
+    for p in g.style.parameters():
+        p.requires_grad_(False)
+    latent = torch.randn(2, g.n_latent, 512, device='cuda')
+    noise = [torch.randn(1, 1, n.shape[-1], n.shape[-1], device='cuda') for n in g.make_noise()]
+    w = g.convs[0].conv.weight
+    out = []
+    for use in (False, True):
+        M._USE_DEMOD_BANK = use
+        try:
+            img, _ = g([latent], input_is_latent=True, noise=noise)
+            (g1,) = torch.autograd.grad(img.square().mean(), w, create_graph=True)
+            (g2,) = torch.autograd.grad(g1.square().sum(), w)
+            out.append((g1.detach(), g2))
+        finally:
+            M._USE_DEMOD_BANK = True
+    torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(out[0][1], out[1][1], rtol=2e-3, atol=1e-9)
+
+
+def test_trainer_graph_steps_bank_equals_per_layer_bitwise():
+    """Four graph-replayed iterations (D, R1, G, path length, EMA) with the demodulation bank leave exactly the generator,
+    discriminator, EMA weights, Adam moments and losses the per-layer kernels leave: the cached wsq is refreshed behind every weight
+    update (PackGroup.after_repack) and the banked backward adds the same gradients."""
+    import rick_amd.models as M
+    from rick_amd.synth import synth_reals, synth_tensor
+    from rick_amd.train import RickTrainer, TrainConfig
+    from tests.test_gpu_models import build
+    size, B = 32, 2
+    real = [synth_reals(B, size=size, seed=170 + k).cuda() for k in range(4)]
+    lat = {k: synth_tensor(f'dmbank/lat/{k}', (B if k != 'plr' else 1, 8, 512)).cuda() for k in ('d', 'g', 'plr')}
+    lat['plr'].requires_grad_(True)
+    pl_noise = synth_tensor('dmbank/pl', (1, 3, size, size)).cuda()
+
+    def run(use_bank):
+        M._USE_DEMOD_BANK = use_bank
+        try:
+            g, d = build(size)
+            tr = RickTrainer(TrainConfig(size=size, batch=B, warmup_iter=0), g, d, *build(size))
+            noises = [getattr(g.noises, f'noise_{i}') for i in range(g.num_layers)]
+            tr.enable_graphs(True)
+            tr._draw_inject('d')
+            tr._graph_latents = lambda key, batch: lat[key]
+            static_real = torch.empty_like(real[0])
+            for k in range(4):
+                static_real.copy_(real[k])
+                tr.d_step(static_real, None, g_noise=noises, graph=True)
+                tr.r1_step(static_real, graph=True)
+                tr.g_step(None, g_noise=noises, graph=True)
+                tr.plr_step(None, pl_noise=pl_noise, g_noise=noises, graph=True)
+                tr.ema_step()
+            torch.cuda.synchronize()
+            assert ('_dmbank' in g.__dict__) == use_bank
+            return tr
+        finally:
+            M._USE_DEMOD_BANK = True
+    a, b = run(False), run(True)
+    for fa, fb in ((a.g_flat, b.g_flat), (a.d_flat, b.d_flat), (a.g_ema_flat, b.g_ema_flat)):
+        assert torch.equal(fa.flat, fb.flat)
+    assert torch.equal(a.g_optim.m, b.g_optim.m) and torch.equal(a.g_optim.v, b.g_optim.v)
+    for k in ('d', 'g', 'r1', 'path'):
+        assert torch.equal(a.losses[k], b.losses[k])

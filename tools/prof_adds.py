@@ -47,3 +47,17 @@ if os.environ.get('BY_NAME'):
     print(f'--- by name: {sum(v[0] for _, v in rows)} events with device time, {sum(v[1] for _, v in rows) / 1e3:.3f} ms')
     for k, (n, t) in rows[:70]:
         print(f'{t:9.1f} us {n:5d}x  {k[:120]}')
+if os.environ.get('STACKS'):
+    # who launches the small copies / fills?  (python frames of the ops named in STACKS, comma separated)
+    want = os.environ['STACKS'].split(',')
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA],
+                                record_shapes=True, with_stack=True) as prof2:
+        fns[which]()
+        torch.cuda.synchronize()
+    seen = collections.Counter()
+    for ev in prof2.events():
+        if ev.name in want and ev.device_time_total > 0:
+            frames = [f for f in (ev.stack or []) if 'rick_amd' in f or 'tools/' in f][:3]
+            seen[(ev.name, str(ev.input_shapes)[:60], ' <- '.join(f.split('/')[-1][:60] for f in frames))] += 1
+    for (name, shp, st), n in seen.most_common(40):
+        print(f'{n:4d}x {name:14s} {shp:60s} {st}')
