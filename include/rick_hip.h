@@ -272,6 +272,18 @@ int rick_upfirdn2d_ex_f32(const float *input, const float *kernel, float *out,
 int64_t rick_upfirdn2d_adjoint_rows(int64_t major, int out_h, int out_w);
 /* out[c] (+)= sum_r partials[r * stride + c], c < ncols: the deterministic second stage of the per-block channel sums */
 int rick_colsum_f32(const float *partials, float *out, int64_t rows, int stride, int ncols, int accumulate, void *stream);
+/* Up to any number of such column sums in one launch per 32 items (bit-identical to rick_colsum_f32 item by item): out[c] (c < split,
+ * or all columns when out2 is NULL) / out2[c - split] = (accumulate ? old : 0) + sum_r partials[r * stride + col0 + c], r < nb.
+ * `items` is a HOST array: it travels in the kernel arguments, so the call may be captured into a hipGraph.  Used for the second
+ * stages of the bias / noise-strength gradients of a whole backward pass (rick_bias_act_bwd_f32 with accumulate bit 1 set leaves
+ * its partial rows [blocks][C + 1] unsummed: column C is the noise-strength term). */
+#define RICK_COLSUM_MAX 32
+typedef struct rick_colsum_item {
+    const float *partials;
+    float *out, *out2;
+    int nb, stride, ncols, col0, split, accumulate;
+} rick_colsum_item;
+int rick_colsum_multi_f32(const rick_colsum_item *items, int n, void *stream);
 int rick_bias_act_bwd_split_f32(const float *g, const float *ref, void *out1, float *hdr1, void *out2, float *hdr2,
                                 float mul2, const float *amax_g, float *gb, float *gnw, const float *noise,
                                 int64_t rows, int C, int64_t rows_per_img, int64_t noise_nb, int64_t noise_hw,

@@ -41,6 +41,13 @@ class ConvEpilogue(ctypes.Structure):
                 ('split_coef', c_f), ('split_scale', c_fp)]
 
 
+class ColsumItem(ctypes.Structure):
+    """rick_colsum_item (include/rick_hip.h)"""
+    _fields_ = [('partials', ctypes.c_void_p), ('out', ctypes.c_void_p), ('out2', ctypes.c_void_p), ('nb', ctypes.c_int),
+                ('stride', ctypes.c_int), ('ncols', ctypes.c_int), ('col0', ctypes.c_int), ('split', ctypes.c_int),
+                ('accumulate', ctypes.c_int)]
+
+
 class SplitOut(ctypes.Structure):
     """rick_split_out (include/rick_hip.h)."""
     _fields_ = [('split_out', c_fp), ('split_hdr', c_fp), ('bound0', c_fp), ('bound1', c_fp), ('bound_coef', c_f),
@@ -121,6 +128,7 @@ SIGNATURES = {
     'rick_demod_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_f, c_fp]),
     'rick_demod_bwd_s_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     'rick_demod_bwd_w_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_f, c_int, c_fp]),
+    'rick_colsum_multi_f32': (c_int, [ctypes.POINTER(ColsumItem), c_int, c_fp]),
     'rick_demod_blocks_wsq': (c_int, [c_int, c_int]),
     'rick_demod_blocks': (c_int, [c_int]),
     'rick_demod_blocks_bwd_s': (c_int, [c_int]),

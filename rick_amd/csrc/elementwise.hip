@@ -344,6 +344,72 @@ static int bias_act_bwd_run(const float *g, const float *ref, float *gx, float *
                             int64_t noise_nb, int64_t noise_hw, float alpha, float scale,
                             float *partials, int accumulate, void *stream, const BabSplit *sp);
 
+// Several column sums in ONE launch (rick_colsum_multi_f32): the second stages of the bias / noise-strength gradients of a whole
+// backward pass, whose results nobody reads before the optimiser.  Each item is summed exactly as partial_colsum_kernel<8> (or <1>
+// for a single column) sums it — same row groups, same four-way accumulation, same LDS tree: bit-identical.  The items travel
+// by value in the kernel arguments (no device table: safe under hipGraph capture).
+struct ColsumBatch {
+    rick_colsum_item it[RICK_COLSUM_MAX];
+    int blk_begin[RICK_COLSUM_MAX];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void colsum_multi_kernel(const ColsumBatch b) {
+    __shared__ float red[256];
+    int l = 0;
+    for (int i = 1; i < b.n; i++)
+        if ((int)blockIdx.x >= b.blk_begin[i]) l = i;
+    const rick_colsum_item it = b.it[l];
+    const int CPB = it.ncols == 1 ? 1 : 8, G = 256 / CPB;
+    const int cl = threadIdx.x % CPB, grp = threadIdx.x / CPB;
+    const int c = ((int)blockIdx.x - b.blk_begin[l]) * CPB + cl;
+    float s = 0.f;
+    if (c < it.ncols) {
+        const float *pp = it.partials + it.col0 + c;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int r = grp;
+        for (; r + 3 * G < it.nb; r += 4 * G) {
+            s0 += pp[(int64_t)r * it.stride];
+            s1 += pp[(int64_t)(r + G) * it.stride];
+            s2 += pp[(int64_t)(r + 2 * G) * it.stride];
+            s3 += pp[(int64_t)(r + 3 * G) * it.stride];
+        }
+        for (; r < it.nb; r += G) s0 += pp[(int64_t)r * it.stride];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = G / 2; off > 0; off >>= 1) {
+        if (grp < off) red[threadIdx.x] += red[threadIdx.x + off * CPB];
+        __syncthreads();
+    }
+    if (grp == 0 && c < it.ncols) {
+        const float v = red[cl];
+        const int split = it.out2 ? it.split : it.ncols;
+        float *dst = c < split ? it.out + c : it.out2 + (c - split);
+        *dst = it.accumulate ? *dst + v : v;
+    }
+}
+
+extern "C" int rick_colsum_multi_f32(const rick_colsum_item *items, int n, void *stream) {
+    if (!items || n < 1) return RICK_EINVAL;
+    for (int base = 0; base < n; base += RICK_COLSUM_MAX) {
+        ColsumBatch b;
+        const int m = n - base < RICK_COLSUM_MAX ? n - base : RICK_COLSUM_MAX;
+        int blk = 0;
+        for (int i = 0; i < m; i++) {
+            const rick_colsum_item &it = items[base + i];
+            if (!it.partials || !it.out || it.nb < 1 || it.ncols < 1 || it.stride < it.ncols) return RICK_EINVAL;
+            b.it[i] = it;
+            b.blk_begin[i] = blk;
+            blk += it.ncols == 1 ? 1 : cdiv(it.ncols, 8);
+        }
+        b.n = m;
+        hipLaunchKernelGGL(colsum_multi_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, b);
+    }
+    RICK_LAUNCH_STATUS();
+}
+
 extern "C" int rick_colsum_f32(const float *partials, float *out, int64_t rows, int stride, int ncols, int accumulate, void *stream) {
     if (!partials || !out || rows < 1 || rows > 0x7fffffff || stride < ncols || ncols < 1) return RICK_EINVAL;
     launch_colsum(partials, out, (int)rows, stride, ncols, 0, (hipStream_t)stream, nullptr, accumulate);
@@ -419,9 +485,10 @@ static int bias_act_bwd_run(const float *g, const float *ref, float *gx, float *
         hipLaunchKernelGGL((bias_act_bwd_kernel<false, false>), dim3(nb), dim3(256), lds, st, g, ref, gx, nz, partials, rows, C,
                            rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0, none);
     // one second-stage launch for both parameter gradients; accumulate: gb / gnw are the parameters' .grad (gradient sink)
-    if (gb && gnw) launch_colsum(partials, gb, nb, C + 1, C + 1, 0, st, nullptr, accumulate, gnw, C);
-    else if (gb) launch_colsum(partials, gb, nb, C + 1, C, 0, st, nullptr, accumulate);
-    else if (gnw) launch_colsum(partials, gnw, nb, C + 1, 1, C, st, nullptr, accumulate);
+    if (accumulate & 2) RICK_LAUNCH_STATUS();      // the caller sums the partial rows later (rick_colsum_multi_f32)
+    if (gb && gnw) launch_colsum(partials, gb, nb, C + 1, C + 1, 0, st, nullptr, accumulate & 1, gnw, C);
+    else if (gb) launch_colsum(partials, gb, nb, C + 1, C, 0, st, nullptr, accumulate & 1);
+    else if (gnw) launch_colsum(partials, gnw, nb, C + 1, 1, C, st, nullptr, accumulate & 1);
     RICK_LAUNCH_STATUS();
 }
 

@@ -3,7 +3,7 @@ additional HIP ops the MI355X engine is built from."""
 import contextlib
 import threading
 
-from .fused_act import FusedLeakyReLU, FusedLeakyReLU_kml, fused_leaky_relu, fused_noise_bias_act
+from .fused_act import FusedLeakyReLU, FusedLeakyReLU_kml, deferred_sums, fused_leaky_relu, fused_noise_bias_act
 from .upfirdn2d import upfirdn2d, upfirdn2d_noise_bias_act
 from .conv import (bump_weights_epoch, conv2d, conv2d_bias_act, conv_transpose2d, get_precision, grad_sink,
                    no_param_grads, register_pack_group, set_precision)
@@ -34,6 +34,6 @@ def second_order(enabled=True):
 
 
 __all__ = ['FusedLeakyReLU', 'FusedLeakyReLU_kml', 'fused_leaky_relu', 'fused_noise_bias_act', 'upfirdn2d', 'upfirdn2d_noise_bias_act',
-           'conv2d', 'conv2d_bias_act', 'conv_transpose2d', 'set_precision', 'get_precision', 'bump_weights_epoch', 'register_pack_group', 'grad_sink', 'no_param_grads',
+           'conv2d', 'conv2d_bias_act', 'conv_transpose2d', 'set_precision', 'get_precision', 'bump_weights_epoch', 'register_pack_group', 'grad_sink', 'deferred_sums', 'no_param_grads',
            'add_scale', 'chan_scale', 'equal_linear', 'hw_dot', 'minibatch_stddev', 'thin_fwd', 'thin_bwdx', 'torgb',
            'second_order', 'second_order_enabled', 'modconv']

@@ -66,10 +66,12 @@ def _act_adjoint_split(g, y, slope, scale, amax_g, mul2=None, want_b=False, sink
         gb = sink_b if sunk else torch.empty(c, device=g.device, dtype=g.dtype)
         part = torch.empty(lib.rick_bias_act_bwd_blocks(rows, c) * (c + 1), device=g.device, dtype=g.dtype)
     from .conv import hbm_launch
+    from .fused_act import defer_act_sums
+    later = sunk and defer_act_sums(part, lib.rick_bias_act_bwd_blocks(rows, c), c, gb, None)
     check(hbm_launch('bias_act_bwd', 4 * g.numel() * (3 if out2 is None else 4), lib.rick_bias_act_bwd_split_f32,
                      ptr(g), ptr(y), ptr(out1.data), ptr(out1.hdr), ptr(out2.data) if out2 else None,
                      ptr(out2.hdr) if out2 else None, float(mul2 or 0.0), ptr(amax_g), ptr(gb), None, None,
-                     rows, c, h * w, 1, 1, float(slope), float(scale), ptr(part), int(sunk), stream_ptr()),
+                     rows, c, h * w, 1, 1, float(slope), float(scale), ptr(part), int(sunk) | (2 if later else 0), stream_ptr()),
           'rick_bias_act_bwd_split_f32')
     return out1, out2, (None if sunk else gb)
 
@@ -105,9 +107,13 @@ def _fir_adjoint_split(g, taps, pad4, y, slope, gain, amax_g, want_b=False, sink
         if rows > 512 and rows % 64 == 0:      # two stages: [rows / 64][64 * c] -> [64][c] -> [c] (a single stage would walk 8 K rows per thread)
             mid = torch.empty(64 * c, device=g.device, dtype=torch.float32)
             check(lib.rick_colsum_f32(ptr(part), ptr(mid), rows // 64, 64 * c, 64 * c, 0, stream_ptr()), 'rick_colsum_f32')
-            check(lib.rick_colsum_f32(ptr(mid), ptr(gb), 64, c, c, int(sunk), stream_ptr()), 'rick_colsum_f32')
+            from .fused_act import defer_colsum
+            if not (sunk and defer_colsum(mid, gb, 64, c, c)):
+                check(lib.rick_colsum_f32(ptr(mid), ptr(gb), 64, c, c, int(sunk), stream_ptr()), 'rick_colsum_f32')
         else:
-            check(lib.rick_colsum_f32(ptr(part), ptr(gb), rows, c, c, int(sunk), stream_ptr()), 'rick_colsum_f32')
+            from .fused_act import defer_colsum
+            if not (sunk and defer_colsum(part, gb, rows, c, c)):
+                check(lib.rick_colsum_f32(ptr(part), ptr(gb), rows, c, c, int(sunk), stream_ptr()), 'rick_colsum_f32')
         if sunk:
             gb = None
     return img, gb

@@ -79,6 +79,56 @@ def param_sink(p, numel, enabled):
     return p.grad
 
 
+# Deferred second stages (process-wide on purpose, like conv._param_grads_off: the backward passes that append run on the
+# autograd engine's thread).  Inside `deferred_sums()` a bias / noise-strength gradient that goes into a gradient sink keeps
+# its per-block partial rows and is summed, together with every other one of the step, by ONE launch when the context exits
+# (rick_colsum_multi_f32: bit-identical item by item) — nobody reads those sums before the optimiser.  29 launches of ~4.7 us
+# per train iteration become 2.
+_deferred = None
+_DEFER_OFF = bool(__import__('os').environ.get('RICK_NO_DEFER'))       # (A/B switch, tools/ab_env.sh)
+
+
+class deferred_sums:
+    def __enter__(self):
+        global _deferred
+        self.prev, _deferred = _deferred, (None if _DEFER_OFF else [])
+        return self
+
+    def __exit__(self, *exc):
+        global _deferred
+        items, _deferred = _deferred, self.prev
+        if exc[0] is None:
+            flush_colsums(items)
+
+
+def defer_colsum(part, out, nb, stride, ncols, col0=0, out2=None, split=0, accumulate=1):
+    """Queue out[c] (+)= sum_r part[r * stride + col0 + c]; False when no deferred_sums() context is open."""
+    if _deferred is None:
+        return False
+    _deferred.append((part, out, out2, int(nb), int(stride), int(ncols), int(col0), int(split), int(accumulate)))
+    return True
+
+
+def flush_colsums(items):
+    if not items:
+        return
+    from .._lib import ColsumItem
+    arr = (ColsumItem * len(items))()
+    for a, (part, out, out2, nb, stride, ncols, col0, split, acc) in zip(arr, items):
+        a.partials, a.out, a.out2 = part.data_ptr(), out.data_ptr(), (out2.data_ptr() if out2 is not None else None)
+        a.nb, a.stride, a.ncols, a.col0, a.split, a.accumulate = nb, stride, ncols, col0, split, acc
+    check(lib.rick_colsum_multi_f32(arr, len(items), stream_ptr()), 'rick_colsum_multi_f32')
+
+
+def defer_act_sums(part, nblk, c, gb, gw):
+    """The second stage of rick_bias_act_bwd_*'s partial rows [nblk][c + 1] into the sinks gb / gw, deferred."""
+    if gb is not None and gw is not None:
+        return defer_colsum(part, gb, nblk, c + 1, c + 1, 0, gw, c)
+    if gb is not None:
+        return defer_colsum(part, gb, nblk, c + 1, c, 0)
+    return defer_colsum(part, gw, nblk, c + 1, 1, c)
+
+
 class _ActAdjoint(Function):
     """L*: g -> (gx, gb, gnw) given the saved output y (and noise).  A gradient that is not wanted is None (not a zero
     tensor).  sink_b / sink_w: the parameters' .grad buffers — the reduction's second stage adds the sums into them and
@@ -97,12 +147,15 @@ class _ActAdjoint(Function):
         gb = (sink_b if sunk else torch.empty(c, device=g.device, dtype=g.dtype)) if want_b else None
         gw = (sink_w if sunk else torch.empty(1, device=g.device, dtype=g.dtype)) if want_w else None
         part = None
+        later = False
         if want_b or want_w:
             nblk = lib.rick_bias_act_bwd_blocks(rows, c)
             part = torch.empty(nblk * (c + 1), device=g.device, dtype=g.dtype)
+            later = sunk and defer_act_sums(part, nblk, c, gb, gw)       # second stage with the rest of the step's (deferred_sums)
         from .conv import hbm_launch
         check(hbm_launch('bias_act_bwd', 12 * gr.numel(), lib.rick_bias_act_bwd_f32, ptr(gr), ptr(yr), ptr(gx), ptr(gb), ptr(gw), ptr(nz),
-                         rows, c, hw, nb, nhw, slope, scale, ptr(part), int(sunk), stream_ptr()), 'rick_bias_act_bwd_f32')
+                         rows, c, hw, nb, nhw, slope, scale, ptr(part), int(sunk) | (2 if later else 0), stream_ptr()),
+              'rick_bias_act_bwd_f32')
         ctx.save_for_backward(y, noise)
         ctx.cfg = (slope, scale)
         if sunk:

@@ -644,7 +644,8 @@ class RickTrainer:
                 fake_pred, real_pred = pred.chunk(2, 0)
                 d_loss = d_logistic_loss(real_pred, fake_pred)
                 self._zero_grad(self.d_flat)
-                d_loss.backward()
+                with op.deferred_sums():        # bias / noise-strength sums: one second-stage launch for the whole pass
+                    d_loss.backward()
             self.losses.update(d=d_loss.detach(), real_score=real_pred.detach().mean(), fake_score=fake_pred.detach().mean())
         self._run(key, fb, self.d_flat, self.d_optim, pre=(lambda: self._draw_inject(key)) if graph else None)
         return self.losses['d']
@@ -682,7 +683,8 @@ class RickTrainer:
                 fake_pred, _ = self.d(box.pop('fake'))
                 g_loss = g_nonsaturating_loss(fake_pred)
                 self._zero_grad(self.g_flat)
-                g_loss.backward()
+                with op.deferred_sums():        # bias / noise-strength sums: one second-stage launch for the whole pass
+                    g_loss.backward()
             self.losses['g'] = g_loss.detach()
         self._run(key, fb, self.g_flat, self.g_optim, pre=(lambda: self._draw_inject(key)) if graph else None, fb_head=head)
         return self.losses['g']

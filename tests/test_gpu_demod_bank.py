@@ -144,3 +144,52 @@ def test_trainer_graph_steps_bank_equals_per_layer_bitwise():
     assert torch.equal(a.g_optim.m, b.g_optim.m) and torch.equal(a.g_optim.v, b.g_optim.v)
     for k in ('d', 'g', 'r1', 'path'):
         assert torch.equal(a.losses[k], b.losses[k])
+
+
+def test_trainer_graph_steps_deferred_sums_equal_immediate_bitwise():
+    """op.deferred_sums(): the bias / noise-strength column sums of a whole backward pass from one launch at its end leave
+    exactly the weights, moments and losses the per-layer second stages leave (four graph-replayed iterations)."""
+    import rick_amd.op.fused_act as fa
+    from rick_amd.synth import synth_reals, synth_tensor
+    from rick_amd.train import RickTrainer, TrainConfig
+    from tests.test_gpu_models import build
+    size, B = 32, 2
+    real = [synth_reals(B, size=size, seed=270 + k).cuda() for k in range(4)]
+    lat = {k: synth_tensor(f'defer/lat/{k}', (B if k != 'plr' else 1, 8, 512)).cuda() for k in ('d', 'g', 'plr')}
+    lat['plr'].requires_grad_(True)
+    pl_noise = synth_tensor('defer/pl', (1, 3, size, size)).cuda()
+    launched = []
+    orig = fa.flush_colsums
+
+    def run(off):
+        fa._DEFER_OFF = off
+        fa.flush_colsums = lambda items: (launched.append(len(items or [])), orig(items))[1]
+        try:
+            g, d = build(size)
+            tr = RickTrainer(TrainConfig(size=size, batch=B, warmup_iter=0), g, d, *build(size))
+            noises = [getattr(g.noises, f'noise_{i}') for i in range(g.num_layers)]
+            tr.enable_graphs(True)
+            tr._draw_inject('d')
+            tr._graph_latents = lambda key, batch: lat[key]
+            static_real = torch.empty_like(real[0])
+            for k in range(4):
+                static_real.copy_(real[k])
+                tr.d_step(static_real, None, g_noise=noises, graph=True)
+                tr.r1_step(static_real, graph=True)
+                tr.g_step(None, g_noise=noises, graph=True)
+                tr.plr_step(None, pl_noise=pl_noise, g_noise=noises, graph=True)
+                tr.ema_step()
+            torch.cuda.synchronize()
+            return tr
+        finally:
+            fa._DEFER_OFF = False
+            fa.flush_colsums = orig
+    a = run(True)
+    assert max(launched, default=0) == 0
+    b = run(False)
+    assert max(launched) >= 5                  # several layers' sums per flush
+    for fa_, fb_ in ((a.g_flat, b.g_flat), (a.d_flat, b.d_flat), (a.g_ema_flat, b.g_ema_flat)):
+        assert torch.equal(fa_.flat, fb_.flat)
+    assert torch.equal(a.g_optim.m, b.g_optim.m) and torch.equal(a.d_optim.v, b.d_optim.v)
+    for k in ('d', 'g', 'r1', 'path'):
+        assert torch.equal(a.losses[k], b.losses[k])
