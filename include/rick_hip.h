@@ -349,6 +349,11 @@ int rick_torgb_fwd_f32(const float *x, const float *w, const float *s, float wsc
                        const float *add, float *t, int N, int64_t P, int C, int J, void *stream);
 int rick_torgb_bwdx_f32(const float *g, const float *w, const float *s, float wscale, float *gx, int N, int64_t P,
                         int C, int J, void *stream);
+/* ... added INTO gx (gx[n,p,c] += ...): the activation that feeds ToRGB also feeds the next layer, whose data gradient is
+ * already in gx — the second gradient arriving at the branch point is added by the kernel that produces it (same fp32 addition
+ * as autograd's accumulation: torch.equal). */
+int rick_torgb_bwdx_acc_f32(const float *g, const float *w, const float *s, float wscale, float *gx, int N, int64_t P,
+                            int C, int J, void *stream);
 int rick_thin_wgrad_blocks(int64_t P);
 int rick_thin_wgrad_f32(const float *t, const float *x, float *G, int N, int64_t P, int C, int J,
                         float *partials, void *stream);

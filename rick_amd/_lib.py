@@ -110,6 +110,7 @@ SIGNATURES = {
     'rick_thin_bwdx_f32': (c_int, [c_fp, c_fp, c_i64, c_fp, c_int, c_i64, c_int, c_int, c_fp]),
     'rick_torgb_fwd_f32': (c_int, [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_int, c_fp]),
     'rick_torgb_bwdx_f32': (c_int, [c_fp, c_fp, c_fp, c_f, c_fp, c_int, c_i64, c_int, c_int, c_fp]),
+    'rick_torgb_bwdx_acc_f32': (c_int, [c_fp, c_fp, c_fp, c_f, c_fp, c_int, c_i64, c_int, c_int, c_fp]),
     'rick_thin_wgrad_blocks': (c_int, [c_i64]),
     'rick_thin_wgrad_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_int, c_fp, c_fp]),
     'rick_chan_scale_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_i64, c_int, c_fp]),

@@ -179,7 +179,8 @@ extern "C" int rick_torgb_fwd_f32(const float *x, const float *w, const float *s
     return thin_fwd_launch(x, w, 0, add, t, N, P, C, J, m, stream);
 }
 
-// x[n,p,c] = sum_j t[n,j,p] * W[n,j,c]
+// x[n,p,c] = sum_j t[n,j,p] * W[n,j,c]     (ACC: x += ..., the second gradient arriving at a branch point added where it is produced)
+template <bool ACC>
 __global__ __launch_bounds__(256) void thin_bwdx_kernel(const float *__restrict__ t, const float *__restrict__ W,
                                                         int64_t w_bstride, float *__restrict__ x, int64_t P, int C, int J,
                                                         ThinMod m) {
@@ -205,6 +206,10 @@ __global__ __launch_bounds__(256) void thin_bwdx_kernel(const float *__restrict_
         for (int j = 0; j < THIN_MAXJ; j++) {
             const float tj = j < J ? tv[j] : 0.f;
             acc.x += tj * wv[j].x; acc.y += tj * wv[j].y; acc.z += tj * wv[j].z; acc.w += tj * wv[j].w;
+        }
+        if (ACC) {
+            const float4 o = xn[i4];
+            acc = make_float4(o.x + acc.x, o.y + acc.y, o.z + acc.z, o.w + acc.w);
         }
         xn[i4] = acc;
     }
@@ -280,11 +285,12 @@ extern "C" int rick_d_input_f32(const float *t, const float *W, const float *bia
 CV_DEFINE_SAT_ACCESSOR(rick_sat_thin)
 
 static int thin_bwdx_launch(const float *t, const float *W, int64_t w_bstride, float *x, int N, int64_t P, int C, int J, ThinMod m,
-                            void *stream) {
+                            void *stream, bool acc = false) {
     if (!x || !W || !t || N <= 0 || P <= 0 || C <= 0 || C % 4 || J < 1 || J > THIN_MAXJ || N > 65535) return RICK_EINVAL;
     int64_t nb = cdiv64(P * (C / 4), 256);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(thin_bwdx_kernel, dim3((unsigned)nb, N), dim3(256), 0, (hipStream_t)stream, t, W, w_bstride, x, P, C, J, m);
+    if (acc) hipLaunchKernelGGL(thin_bwdx_kernel<true>, dim3((unsigned)nb, N), dim3(256), 0, (hipStream_t)stream, t, W, w_bstride, x, P, C, J, m);
+    else hipLaunchKernelGGL(thin_bwdx_kernel<false>, dim3((unsigned)nb, N), dim3(256), 0, (hipStream_t)stream, t, W, w_bstride, x, P, C, J, m);
     RICK_LAUNCH_STATUS();
 }
 
@@ -299,6 +305,13 @@ extern "C" int rick_torgb_bwdx_f32(const float *g, const float *w, const float *
     if (!s || (((uintptr_t)s | (uintptr_t)w) & 15)) return RICK_EINVAL;
     const ThinMod m = {s, wscale, nullptr};
     return thin_bwdx_launch(g, w, 0, gx, N, P, C, J, m, stream);
+}
+
+extern "C" int rick_torgb_bwdx_acc_f32(const float *g, const float *w, const float *s, float wscale, float *gx, int N, int64_t P,
+                                       int C, int J, void *stream) {
+    if (!s || (((uintptr_t)s | (uintptr_t)w | (uintptr_t)gx) & 15)) return RICK_EINVAL;
+    const ThinMod m = {s, wscale, nullptr};
+    return thin_bwdx_launch(g, w, 0, gx, N, P, C, J, m, stream, true);
 }
 
 // G[n,j,c] = sum_p t[n,j,p] * x[n,p,c];  partials [blk][n][j][c]

@@ -27,6 +27,7 @@ from .op.upfirdn2d import upfirdn2d
 CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512}
 # tests / tools switch the one-node split-image ResBlock (op/dblock.py) off to compare with the per-layer path
 _USE_DBLOCK = not os.environ.get('RICK_NO_DBLOCK')
+_USE_RGB_FORK = not os.environ.get('RICK_NO_RGB_FORK')
 _USE_DEMOD_BANK = not os.environ.get('RICK_NO_DEMOD_BANK')      # (A/B switch, tools/ab_*.sh)
 
 
@@ -156,7 +157,7 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
 
-    def forward(self, x, style, tail=None, s=None, d=None, rgb_tail=None, next_s=None):
+    def forward(self, x, style, tail=None, s=None, d=None, rgb_tail=None, next_s=None, fork=False):
         """tail = (bias, noise, noise_weight, negative_slope, gain): apply StyledConv's NoiseInjection + FusedLeakyReLU
         as part of this layer (fused into the blur launch of the upsampling variant; first-order mode only).
         s = modulation(style) (and d, the demodulation coefficients) when the Generator has already evaluated them for
@@ -169,7 +170,8 @@ class ModulatedConv2d(nn.Module):
         if self.kernel_size == 1 and self.out_channel <= 4 and not self.demodulate:
             if rgb_tail is not None and not op.second_order_enabled():
                 # ToRGB: weight modulation, bias and the skip addition inside the one launch (first-order steps)
-                return op.torgb(x, w.view(self.out_channel, self.in_channel), s, rgb_tail[0], rgb_tail[1], self.scale)
+                f = op.torgb_fork if fork else op.torgb     # fork: -> (x for the next layer, rgb), one node for the branch point
+                return f(x, w.view(self.out_channel, self.in_channel), s, rgb_tail[0], rgb_tail[1], self.scale)
             Wn = (self.scale * w.view(1, self.out_channel, self.in_channel)) * s.unsqueeze(1)   # [B, 3, Ci]
             out = op.thin_fwd(x, Wn)                                 # planar [B, 3, H, W]
             if rgb_tail is not None:
@@ -252,9 +254,10 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
-    def forward(self, x, style, skip=None, s=None):
+    def forward(self, x, style, skip=None, s=None, fork=False):
         # out = conv(x, style) + bias; out = out + upsample(skip)   (model_probe_tune.py:366-370)
-        return self.conv(x, style, s=s, rgb_tail=(self.bias, self.upsample(skip) if skip is not None else None))
+        # fork (first-order CUDA path): returns (x, out) — x to be used by the next layer, see op.torgb_fork
+        return self.conv(x, style, s=s, rgb_tail=(self.bias, self.upsample(skip) if skip is not None else None), fork=fork)
 
 
 class _Mapping(nn.Sequential):
@@ -437,9 +440,14 @@ class Generator(nn.Module, _FisherMixin):
         # (next_s: the style scales of the following modulated convolution — a layer folds them into the split image it writes
         # for that convolution, op/modconv.py; first-order steps only, sb is None-filled otherwise)
         nblk = len(self.to_rgbs)
+        fork = (_USE_RGB_FORK and latent.is_cuda and latent.dtype == torch.float32 and not op.second_order_enabled()
+                and torch.is_grad_enabled() and not return_feats)
         out = self.conv1(self.input(latent), lat[0], noise=noise[0], s=sb[0], d=db[0], next_s=sb[2] if nblk else None)
         feats.append(out)
-        skip = self.to_rgb1(out, lat[1], s=sb[1])
+        if fork and nblk:
+            out, skip = self.to_rgb1(out, lat[1], s=sb[1], fork=True)
+        else:
+            skip = self.to_rgb1(out, lat[1], s=sb[1])
         i = 1
         for blk, to_rgb in enumerate(self.to_rgbs):
             out = self.convs[2 * blk](out, lat[i], noise=noise[2 * blk + 1], s=sb[2 + 3 * blk], d=db[2 + 3 * blk],
@@ -448,7 +456,10 @@ class Generator(nn.Module, _FisherMixin):
             out = self.convs[2 * blk + 1](out, lat[i + 1], noise=noise[2 * blk + 2], s=sb[3 + 3 * blk], d=db[3 + 3 * blk],
                                           next_s=sb[5 + 3 * blk] if blk + 1 < nblk else None)
             feats.append(out)
-            skip = to_rgb(out, lat[i + 2], skip, s=sb[4 + 3 * blk])
+            if fork and blk + 1 < nblk:      # `out` also feeds the next resolution: both gradients meet in ONE node (op.torgb_fork)
+                out, skip = to_rgb(out, lat[i + 2], skip, s=sb[4 + 3 * blk], fork=True)
+            else:
+                skip = to_rgb(out, lat[i + 2], skip, s=sb[4 + 3 * blk])
             i += 2
         image = skip.contiguous()
         if return_latents:

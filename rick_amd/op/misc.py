@@ -203,6 +203,19 @@ class _ThinWgrad(Function):
         return gt, gx
 
 
+def _torgb_param_grads(ctx, g, x, w, s):
+    gw = gs = gb = None
+    if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+        G = _ThinWgrad.apply(g, x)                                  # [n, J, c] = d loss / d W[n]
+        if ctx.needs_input_grad[1]:
+            gw = ctx.wscale * torch.einsum('njc,nc->jc', G, s)
+        if ctx.needs_input_grad[2]:
+            gs = torch.einsum('njc,jc->nc', G, ctx.wscale * w)
+    if ctx.bias_shape is not None and ctx.needs_input_grad[3]:
+        gb = g.sum((0, 2, 3)).view(ctx.bias_shape)
+    return gw, gs, gb
+
+
 class _ToRGB(Function):
     """rgb = ToRGB's modulated 1x1 conv + bias (+ upsampled skip) in ONE launch (model_probe_tune.py:246-248, 366-370):
     the per-sample weight (scale * w) * s is formed inside the kernel.  First-order autograd; the data gradient is one
@@ -252,15 +265,48 @@ class _ToRGB(Function):
             from .conv import hbm_launch
             check(hbm_launch('thin', 4 * (gx.numel() + g.numel()), lib.rick_torgb_bwdx_f32, ptr(g), ptr(w.contiguous()),
                              ptr(s.contiguous()), ctx.wscale, ptr(gx), n, h * wd, c, J, stream_ptr()), 'rick_torgb_bwdx_f32')
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            G = _ThinWgrad.apply(g, x)                                  # [n, J, c] = d loss / d W[n]
-            if ctx.needs_input_grad[1]:
-                gw = ctx.wscale * torch.einsum('njc,nc->jc', G, s)
-            if ctx.needs_input_grad[2]:
-                gs = torch.einsum('njc,jc->nc', G, ctx.wscale * w)
-        if ctx.bias_shape is not None and ctx.needs_input_grad[3]:
-            gb = g.sum((0, 2, 3)).view(ctx.bias_shape)
+        gw, gs, gb = _torgb_param_grads(ctx, g, x, w, s)
         return gx, gw, gs, gb, (g if ctx.needs_input_grad[4] else None), None
+
+
+class _ToRGBFork(Function):
+    """(x, rgb) = (x, ToRGB(x)): the activation that feeds ToRGB also feeds the next layer (model_probe_tune.py:362-368).  As one
+    node with two outputs, the node receives BOTH gradients of the branch point and the ToRGB data gradient is added into the
+    next layer's data gradient by the launch that produces it (rick_torgb_bwdx_acc_f32) — instead of a full-size tensor written
+    by ToRGB's backward, read again and added by autograd (three passes over the activation; same fp32 addition: torch.equal)."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, bias, add, wscale):
+        t = _ToRGB.forward(ctx, x, w, s, bias, add, wscale)
+        return x.view_as(x), t
+
+    @staticmethod
+    def backward(ctx, gx_next, g):
+        if g is None:
+            return gx_next, None, None, None, None, None
+        if gx_next is None or not ctx.needs_input_grad[0] or torch.is_grad_enabled():
+            res = list(_ToRGB.backward(ctx, g))         # (create_graph=True: the twice-differentiable composition)
+            if gx_next is not None and ctx.needs_input_grad[0]:
+                res[0] = gx_next if res[0] is None else res[0] + gx_next
+            return tuple(res)
+        x, w, s = ctx.saved_tensors
+        g = g.contiguous()
+        n, J, h, wd = g.shape
+        c = w.shape[1]
+        gw, gs, gb = _torgb_param_grads(ctx, g, x, w, s)
+        ok = (gx_next.dtype == torch.float32 and tuple(gx_next.shape) == (n, c, h, wd) and gx_next.data_ptr() % 16 == 0
+              and gx_next.is_contiguous(memory_format=torch.channels_last))
+        gx = gx_next if ok else gx_next.contiguous(memory_format=torch.channels_last).clone()
+        from .conv import hbm_launch
+        check(hbm_launch('thin', 4 * (2 * gx.numel() + g.numel()), lib.rick_torgb_bwdx_acc_f32, ptr(g), ptr(w.contiguous()),
+                         ptr(s.contiguous()), ctx.wscale, ptr(gx), n, h * wd, c, J, stream_ptr()), 'rick_torgb_bwdx_acc_f32')
+        return gx, gw, gs, gb, (g if ctx.needs_input_grad[4] else None), None
+
+
+def torgb_fork(x, w, s, bias=None, add=None, wscale=1.0):
+    """(x', rgb): rgb = torgb(x, ...), x' = x for the next layer — see _ToRGBFork."""
+    require_cuda_f32(x, w, s, bias, add)
+    return _ToRGBFork.apply(x, w, s, bias, add, float(wscale))
 
 
 def torgb(x, w, s, bias=None, add=None, wscale=1.0):
