@@ -306,7 +306,11 @@ class _ToRGBFork(Function):
 def torgb_fork(x, w, s, bias=None, add=None, wscale=1.0):
     """(x', rgb): rgb = torgb(x, ...), x' = x for the next layer — see _ToRGBFork."""
     require_cuda_f32(x, w, s, bias, add)
-    return _ToRGBFork.apply(x, w, s, bias, add, float(wscale))
+    xo, t = _ToRGBFork.apply(x, w, s, bias, add, float(wscale))
+    for a in ('_rick_split', '_rick_amax', '_rick_bound'):      # hand-over attributes of the producing layer (op/split.py) travel with x
+        if hasattr(x, a):
+            setattr(xo, a, getattr(x, a))
+    return xo, t
 
 
 def torgb(x, w, s, bias=None, add=None, wscale=1.0):
