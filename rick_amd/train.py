@@ -8,6 +8,7 @@ runs on ``fake.detach()``, the G step does not compute D weight gradients, and p
 no optimiser owns do not get gradients.  Results are unchanged.
 """
 import math
+import os
 import random
 from dataclasses import dataclass
 
@@ -478,12 +479,51 @@ class RickTrainer:
             t = self._inject[key] = torch.zeros((), dtype=torch.int64, device=self.device)
             self._layer_idx = torch.arange(n_latent, device=self.device).view(1, -1, 1)
         t.fill_(k)
+        self._advance_latent_pool(key)
+
+    # The mapping network is frozen (the optimiser owns none of its parameters, train_dynamic_update_prune.py:908-917) and its
+    # input is fresh noise: the W-space rows of the next LATENT_POOL steps of a step type are i.i.d. draws that do not depend
+    # on anything the training changes.  They are computed LATENT_POOL steps at a time by ONE pass through the 8 layers (eagerly,
+    # between graph replays) and a step's graph gathers its rows by a device-side index — instead of a randn + 8 mapping-layer
+    # launches of ~9-12 us inside every D, G and path-length step (0.2 ms of an iteration).
+    LATENT_POOL = 16
+
+    def _pool_ok(self):
+        return self.LATENT_POOL > 1 and not os.environ.get('RICK_NO_LATENT_POOL') and not any(
+            p.requires_grad for p in self.g.style.parameters())
+
+    def _fill_latent_pool(self, ent):
+        with torch.no_grad():
+            z = torch.randn(self.LATENT_POOL * ent['rows'], self.cfg.latent, device=self.device)
+            ent['w'].copy_(self.g.style(z).view(self.LATENT_POOL, ent['rows'], -1))
+
+    def _advance_latent_pool(self, key):
+        """Host side, before a step's graph runs (with _draw_inject): point the step at the next pool row, refill when used up."""
+        ent = getattr(self, '_lat_pool', {}).get(key)
+        if ent is None:
+            return
+        ent['pos'] += 1
+        if ent['pos'] >= self.LATENT_POOL:
+            self._fill_latent_pool(ent)
+            ent['pos'] = 0
+        ent['idx'].fill_(ent['pos'])
 
     def _graph_latents(self, key, batch):
         """[batch, n_latent, 512] W-space latents with the style switch applied on the device (same values as the
         reference's cat of repeated w1 / w2 rows)."""
-        z = torch.randn(2 * batch, self.cfg.latent, device=self.device)
-        w = self.g.style(z).view(2, batch, 1, -1)
+        if not self._pool_ok():
+            z = torch.randn(2 * batch, self.cfg.latent, device=self.device)
+            w = self.g.style(z).view(2, batch, 1, -1)
+            return torch.where(self._layer_idx < self._inject[key], w[0], w[1])
+        pools = self.__dict__.setdefault('_lat_pool', {})
+        ent = pools.get(key)
+        if ent is None or ent['rows'] != 2 * batch:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('latent pool must exist before hipGraph capture (run the step eagerly once)')
+            ent = pools[key] = dict(rows=2 * batch, pos=0, idx=torch.zeros(1, dtype=torch.int64, device=self.device),
+                                    w=torch.empty(self.LATENT_POOL, 2 * batch, self.cfg.latent, device=self.device))
+            self._fill_latent_pool(ent)
+        w = ent['w'].index_select(0, ent['idx']).view(2, batch, 1, -1)
         return torch.where(self._layer_idx < self._inject[key], w[0], w[1])
 
     def _run(self, key, fb, flat, optim, pre=None, fb_head=None):

@@ -1,5 +1,7 @@
-"""DemodBank (rick_amd/op/modconv.py): the demodulation coefficients of every generator layer from one launch, wsq cached per
-weight update — bit-identical to the per-layer kernels it replaces (same arithmetic, same order), forward and backward."""
+"""Step-level batching of small launches (round 4): DemodBank (rick_amd/op/modconv.py: the demodulation coefficients of every
+generator layer from one launch, wsq cached per weight update), op.deferred_sums (one second-stage launch per backward pass),
+op.torgb_fork (the branch-point gradient added by the kernel that produces it), the trainer's latent pool — each one
+bit-identical to the path it replaces wherever values are comparable."""
 import pytest
 import torch
 
@@ -224,3 +226,47 @@ def test_torgb_fork_adds_the_branch_gradient_in_the_kernel(sink):
     for k in gr0:
         assert torch.equal(gr0[k], gr1[k]), k
     assert adds1 <= adds0 - 3, (adds0, adds1)      # one big add per resolution below the last is gone (64 px: 4 of them)
+
+
+def test_latent_pool_serves_fresh_rows_and_refills():
+    """RickTrainer's latent pool: with a frozen mapping network the W-space rows of the next LATENT_POOL steps come from one
+    pass through the mapping layers; a graph-replayed step gathers its own rows by a device-side index.  Every step sees different
+    latents, the pool is refilled when used up, rows are exactly style(z) of the pool's noise, and a trainable mapping network
+    switches the pool off."""
+    from rick_amd.synth import synth_reals
+    from rick_amd.train import RickTrainer, TrainConfig
+    from tests.test_gpu_models import build
+    size, B = 32, 2
+    g, d = build(size)
+    tr = RickTrainer(TrainConfig(size=size, batch=B, warmup_iter=0), g, d, *build(size))
+    assert tr._pool_ok()
+    tr.enable_graphs(True)
+    real = synth_reals(B, size=size, seed=5).cuda()
+    seen = []
+    orig = g.forward
+
+    def spy(styles, **kw):
+        if kw.get('input_is_latent'):
+            seen.append(styles[0].detach().clone())
+        return orig(styles, **kw)
+    g.forward = spy                      # (eager warm-up steps only: a replayed graph does not call Python)
+    P = tr.LATENT_POOL
+    pool_rows = []
+    for k in range(P + 4):
+        tr.d_step(real, None, graph=True)
+        ent = tr._lat_pool['d']
+        pool_rows.append((int(ent['idx']), ent['w'][int(ent['idx'])].clone()))
+    torch.cuda.synchronize()
+    g.forward = orig
+    assert [i for i, _ in pool_rows] == [k % P for k in range(P + 4)]                  # advances, wraps after a refill
+    rows = torch.stack([r for _, r in pool_rows])
+    assert len({tuple(r.flatten()[:8].tolist()) for r in rows}) == P + 4               # all different (refilled, not re-used)
+    assert torch.isfinite(rows).all() and 0.1 < float(rows.std()) < 10
+    # what the eager steps fed the generator is the mixed view of exactly those rows
+    assert len(seen) >= 2
+    for lat, (_, r) in zip(seen[:2], pool_rows):          # (the third call is the capture: its clone only has values at replay)
+        w = r.view(2, B, -1)
+        assert all(bool((lat[:, j] == w[0]).all() or (lat[:, j] == w[1]).all()) for j in range(lat.shape[1]))
+    for p_ in g.style.parameters():
+        p_.requires_grad_(True)
+    assert not tr._pool_ok()
