@@ -84,6 +84,69 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__
     }
 }
 
+// Matrix-core form (C = 16 * NT, P % 16 == 0): the product is a [16 pixels x C] x [C x 16] GEMM per wave step with 3 of the 16
+// output columns in use — wasteful in FLOPs, free in time: v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate) needs
+// 32 of them per 16 pixels x 128 channels = 25 % of the matrix pipe at HBM rate, and there is no cross-lane reduction and no
+// per-pixel VALU left (the lanes-per-pixel form spends 3-5 shuffle steps x 4 accumulators per pixel: 2.9 TB/s at 128 channels,
+// 1.4 at 512).  A lane (pixel i = lane % 16, k = lane / 16) loads 16 bytes = channels 16 tb + 4 k .. + 3 of its pixel — the 4 k-lanes
+// of a pixel read 64 contiguous bytes — and component j feeds MFMA (tb, j), whose four K indices are the channels 16 tb + 4 k + j;
+// the B operand holds the matching weights W[o][16 tb + 4 k + j] (o = lane % 16, zero for o >= J), modulated once per block.
+// The result tile D[pixel][o] leaves as float4 stores of 4 consecutive pixels from the lanes with o < J.
+typedef float thin_f32x4 __attribute__((ext_vector_type(4)));
+template <int NT, int UNR>
+__global__ __launch_bounds__(256) void thin_fwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ W,
+                                                            int64_t w_bstride, const float *__restrict__ add,
+                                                            float *__restrict__ t, int64_t P, int C, int J, ThinMod m) {
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, k = lane >> 4;
+    const float *Wn = W + (int64_t)n * w_bstride;
+    float4 breg[NT];
+#pragma unroll
+    for (int tb = 0; tb < NT; tb++) {
+        const float4 wv = thin_w(Wn + (int64_t)(i < J ? i : 0) * C, m, n, C, 16 * tb + 4 * k);
+        breg[tb] = i < J ? wv : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float *xn = x + (int64_t)n * P * C + 4 * k;
+    const int64_t ngroups = P >> 4;
+    const int64_t gstride = (int64_t)gridDim.x * 4;
+    for (int64_t g0 = (int64_t)blockIdx.x * 4 + wave; g0 < ngroups; g0 += gstride * UNR) {
+        float4 xv[UNR][NT];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int64_t g = g0 + u * gstride;
+            const float *xp = xn + ((g < ngroups ? g : g0) * 16 + i) * C;
+#pragma unroll
+            for (int tb = 0; tb < NT; tb++) xv[u][tb] = *reinterpret_cast<const float4 *>(xp + 16 * tb);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int64_t g = g0 + u * gstride;
+            thin_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tb = 0; tb < NT; tb++) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][tb].x, breg[tb].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][tb].y, breg[tb].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][tb].z, breg[tb].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][tb].w, breg[tb].w, acc, 0, 0, 0);
+            }
+            if (g < ngroups && i < J) {      // D[pixel 4 k + r][o = i]
+                const int64_t o = ((int64_t)n * J + i) * P + g * 16 + 4 * k;
+                float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                if (m.bias) {
+                    const float bv = m.bias[i];
+                    v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+                }
+                if (add) {
+                    const float4 av = *reinterpret_cast<const float4 *>(add + o);
+                    v.x += av.x; v.y += av.y; v.z += av.z; v.w += av.w;
+                }
+                *reinterpret_cast<float4 *>(t + o) = v;
+            }
+        }
+    }
+}
+
 // Generic form (any C % 4 == 0): lanes stride over the channel quads, W re-read through L1.
 __global__ __launch_bounds__(256) void thin_fwd_generic_kernel(const float *__restrict__ x, const float *__restrict__ W,
                                                                int64_t w_bstride, const float *__restrict__ add,
@@ -130,6 +193,18 @@ static int thin_fwd_launch(const float *x, const float *W, int64_t w_bstride, co
     if (!x || !W || !t || N <= 0 || P <= 0 || C <= 0 || C % 4 || J < 1 || J > THIN_MAXJ || N > 65535) return RICK_EINVAL;
     const int C4 = C / 4;
     hipStream_t st = (hipStream_t)stream;
+    // matrix-core form: whole 16-pixel groups, 64 ... 512 channels in blocks of 16, 16-byte aligned operands
+    if ((P & 15) == 0 && (C == 64 || C == 128 || C == 256 || C == 512) &&
+        (((uintptr_t)x | (uintptr_t)t | (uintptr_t)(add ? add : t) | (uintptr_t)W | (uintptr_t)(m.smod ? m.smod : W)) & 15) == 0 && (w_bstride & 3) == 0) {
+        int64_t nbm = cdiv64(P >> 4, 4 * (C <= 128 ? 2 : 1));
+        if (nbm > 8192) nbm = 8192;
+        const dim3 gridm((unsigned)nbm, N), blkm(256);
+        if (C == 64) hipLaunchKernelGGL((thin_fwd_mfma_kernel<4, 2>), gridm, blkm, 0, st, x, W, w_bstride, add, t, P, C, J, m);
+        else if (C == 128) hipLaunchKernelGGL((thin_fwd_mfma_kernel<8, 2>), gridm, blkm, 0, st, x, W, w_bstride, add, t, P, C, J, m);
+        else if (C == 256) hipLaunchKernelGGL((thin_fwd_mfma_kernel<16, 1>), gridm, blkm, 0, st, x, W, w_bstride, add, t, P, C, J, m);
+        else hipLaunchKernelGGL((thin_fwd_mfma_kernel<32, 1>), gridm, blkm, 0, st, x, W, w_bstride, add, t, P, C, J, m);
+        RICK_LAUNCH_STATUS();
+    }
     // fast path: lanes per pixel = a power of two (>= 4: J lanes store) dividing C/4, every lane owns nq whole quads
     int lpp = 64;
     while (lpp > 4 && (C4 % lpp || lpp > C4)) lpp >>= 1;
