@@ -7,3 +7,10 @@ for c, r in [(512, 64), (256, 128), (128, 256)]:
     W = torch.randn(4, 3, c, device='cuda')
     t = timeit(lambda: misc.thin_fwd(x, W), reps=30)
     print(f'NQ={os.environ.get("RICK_THIN_NQ")} C={c} @{r}: {t*1e6:6.1f} us {x.numel()*4/t/1e12:5.2f} TB/s')
+for c, r in [(512, 64), (256, 128), (128, 256)]:
+    x = torch.randn(4, c, r, r, device='cuda').contiguous(memory_format=torch.channels_last)
+    tt = torch.randn(4, 3, r, r, device='cuda')
+    W = torch.randn(4, 3, c, device='cuda')
+    t = timeit(lambda: misc._ThinWgrad.apply(tt, x), reps=30)
+    t2 = timeit(lambda: misc.thin_bwdx(tt, W), reps=30)
+    print(f'C={c} @{r}: thin_wgrad {t*1e6:6.1f} us {x.numel()*4/t/1e12:5.2f} TB/s | thin_bwdx {t2*1e6:6.1f} us {x.numel()*4/t2/1e12:5.2f} TB/s (write)')
