@@ -19,3 +19,19 @@ with torch.no_grad(), torch.profiler.profile(activities=[torch.profiler.Profiler
 for ev in prof.key_averages():
     if 'kernel' in ev.key:
         print(f'{ev.key[:50]:50s} {ev.count:3d} x {ev.device_time_total / ev.count:6.1f} us')
+# backward kernels of the banks (one G step's worth)
+for p_ in g.style.parameters():
+    p_.requires_grad_(False)
+from rick_amd import op
+for p_ in g.parameters():
+    p_.grad = torch.zeros_like(p_)
+noise = [torch.randn(1, 1, n.shape[-1], n.shape[-1], device='cuda') for n in g.make_noise()]
+with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+    for _ in range(5):
+        with op.grad_sink():
+            img, _ = g([lat], input_is_latent=True, noise=noise)
+            img.square().mean().backward()
+    torch.cuda.synchronize()
+for ev in prof.key_averages():
+    if any(k in ev.key for k in ('demod', 'modbank', 'wsq')):
+        print(f'{ev.key[:50]:50s} {ev.count:3d} x {ev.device_time_total / ev.count:6.1f} us')
