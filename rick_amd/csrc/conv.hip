@@ -129,7 +129,9 @@ extern "C" int rick_conv_pack_weight(const float *w, int64_t s_co, int64_t s_ci,
 // Many weights in ONE launch (all convolutions of a network after an optimiser step): block b serves the
 // descriptor d with blk_begin[d] <= b < blk_begin[d+1]; a thread owns one (co, ci) of a 128 x 32 tile and
 // walks the tap slices (contiguous in memory for [O, I, kh, kw] parameters).
+#define PK_NS_MAX 16      // tap slices staged through LDS (RICK_MAX_TAPS); more: the per-thread tap walk
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const rick_pack_desc *__restrict__ descs, int n, int split) {
+    __shared__ float sw[256 * PK_NS_MAX];
     int d = 0;
     for (int i = 1; i < n; i++)
         if ((int)blockIdx.x >= descs[i].blk_begin) d = i;
@@ -138,7 +140,49 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const rick_pack_
     const int nchunks = (ds.Ci + CV_CK - 1) / CV_CK;
     const float pscale =
         reinterpret_cast<const float *>((const unsigned char *)ds.packed + packed_tile_bytes(ds.Co, ds.Ci, ds.nslices))[1];
-    const int i = ((int)blockIdx.x - ds.blk_begin) * 256 + threadIdx.x;   // over (cotile, chunk, r, k)
+    const int blk = (int)blockIdx.x - ds.blk_begin;      // 16 blocks per 128 x 32 tile: 8 rows x 32 k each
+    float satm = 0.f;
+    if (ds.nslices <= PK_NS_MAX) {
+        // A block's 8 rows x 32 k x nslices values are read in MEMORY order (coalesced runs of 32 * nslices floats for a
+        // [O, I, kh, kw] parameter, 8 * nslices for its transposed view) into LDS as [r][k][slice]; then one thread per
+        // (slice, row, 16-byte granule) converts 8 consecutive k and writes the granule's hi and lo halves as two 16-byte
+        // stores.  (One thread per (row, k) walking the slices read 4 bytes of every 36 per lane and wrote 2-byte pieces:
+        // 203 us per network.)  Same value per element — w * scale * 2^e, same conversion — so the image is byte-identical.
+        const int ns = ds.nslices, tile = blk >> 4, rg = blk & 15;
+        const int chunk = tile % nchunks, cot = tile / nchunks;
+        const int co0 = cot * CV_BM + rg * 8, ci0 = chunk * CV_CK;
+        const bool k_fast = llabs(ds.s_ci) <= llabs(ds.s_co);
+        for (int e = threadIdx.x; e < 256 * ns; e += 256) {
+            const int sl = e % ns, q = e / ns;
+            const int r = k_fast ? q >> 5 : q & 7, k = k_fast ? q & 31 : q >> 3;
+            const int co = co0 + r, ci = ci0 + k;
+            float v = 0.f;
+            if (co < ds.Co && ci < ds.Ci) v = ds.w[co * ds.s_co + ci * ds.s_ci + sl * ds.s_t] * ds.scale * pscale;
+            sw[(r * 32 + k) * ns + sl] = v;
+        }
+        __syncthreads();
+        unsigned char *base = (unsigned char *)ds.packed + (int64_t)tile * ns * CV_WSTEP_BYTES;
+        for (int it = threadIdx.x; it < 32 * ns; it += 256) {
+            const int sl = it >> 5, r = (it >> 2) & 7, gq = it & 3;
+            const float *src = sw + (r * 32 + gq * 8) * ns + sl;
+            unsigned short h[8], l[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                const float v = src[jj * ns];
+                satm = fmaxf(satm, fabsf(v));
+                split1(v, h[jj], l[jj], split);
+            }
+            const int row = rg * 8 + r;
+            unsigned char *dst = base + (int64_t)sl * CV_WSTEP_BYTES + row * 64 + cv_swz(gq, row) * 16;
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16),
+                                                         h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+            *reinterpret_cast<uint4 *>(dst + CV_WTILE_BYTES) = make_uint4(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16),
+                                                                          l[4] | ((unsigned)l[5] << 16), l[6] | ((unsigned)l[7] << 16));
+        }
+        cv_sat_report(satm);
+        return;
+    }
+    const int i = blk * 256 + threadIdx.x;   // over (cotile, chunk, r, k)
     const int k = i & 31, r = (i >> 5) & 127, tile = i >> 12;
     const int chunk = tile % nchunks, cot = tile / nchunks;
     const int co = cot * CV_BM + r, ci = chunk * CV_CK + k;
@@ -146,7 +190,6 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const rick_pack_
     const float *src = ds.w + (ok ? co * ds.s_co + ci * ds.s_ci : 0);
     unsigned short *dst = (unsigned short *)ds.packed + (int64_t)tile * ds.nslices * (CV_WSTEP_BYTES / 2) +
                           r * 32 + cv_swz(k >> 3, r) * 8 + (k & 7);
-    float satm = 0.f;
     for (int sl = 0; sl < ds.nslices; sl++) {
         float v = src[sl * ds.s_t] * ds.scale * pscale;
         if (!ok) v = 0.f;
