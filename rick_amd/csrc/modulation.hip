@@ -188,17 +188,34 @@ extern "C" int rick_demod_bwd_w_f32(const float *w, const float *s, const float 
 // on the weights only: the host recomputes it once per update of the network (rick_wsq_multi_f32, with the weight packs) and
 // every forward in between reads it.  Layer l: s_l [B, I] at float offset s_off of the modulation bank's flat output,
 // d_l / gd_l [B, O] at d_off of the flat coefficient / gradient buffer; blocks [blk_*, next layer's blk_*).
+#define WSQ_KMAX 9
 __global__ __launch_bounds__(256) void wsq_multi_kernel(const rick_demod_desc *__restrict__ descs, int n) {
     int l = 0;
     for (int i = 1; i < n; i++)
         if ((int)blockIdx.x >= descs[i].blk_wsq) l = i;
     const rick_demod_desc ds = descs[l];
     const int64_t OI = (int64_t)ds.O * ds.I;
-    const int64_t i = (int64_t)((int)blockIdx.x - ds.blk_wsq) * 256 + threadIdx.x;
+    const int64_t i0 = (int64_t)((int)blockIdx.x - ds.blk_wsq) * 256;
+    const int K = ds.K;
+    if (K <= WSQ_KMAX) {      // the block's 256 * K consecutive floats through LDS (coalesced), then the same k-ordered sum per (o, i)
+        __shared__ float sw[256 * WSQ_KMAX];
+        const int npair = OI - i0 < 256 ? (int)(OI - i0) : 256;
+        const float *w = ds.w + i0 * K;
+        for (int e = threadIdx.x; e < npair * K; e += 256) sw[e] = w[e];
+        __syncthreads();
+        if ((int)threadIdx.x < npair) {
+            const float *p = sw + threadIdx.x * K;
+            float s = 0.f;
+            for (int k = 0; k < K; k++) s = __builtin_fmaf(p[k], p[k], s);
+            ds.wsq[i0 + threadIdx.x] = s * ds.scale2;
+        }
+        return;
+    }
+    const int64_t i = i0 + threadIdx.x;
     if (i >= OI) return;
-    const float *p = ds.w + i * ds.K;
+    const float *p = ds.w + i * K;
     float s = 0.f;
-    for (int k = 0; k < ds.K; k++) s = __builtin_fmaf(p[k], p[k], s);
+    for (int k = 0; k < K; k++) s = __builtin_fmaf(p[k], p[k], s);
     ds.wsq[i] = s * ds.scale2;
 }
 
