@@ -233,6 +233,10 @@ int rick_conv_wgrad_f32(const float *x, const float *gy, float *gw,
 #define RICK_AMAX_SLOTS 16
 #define RICK_AMAX_FLOATS (16 * 32)
 int rick_amax_f32(const float *x, int64_t n, float *amax_word, void *stream);
+/* Identity of the hipGraph capture `stream` is recording into (hipStreamGetCaptureInfo's id), 0 when it is not capturing.
+ * Running maxima and headers a CAPTURED launch accumulates into must be zeroed by a fill inside the SAME graph: the host side
+ * (rick_amd/op/split.py) starts a fresh block of words whenever this value changes. */
+int rick_stream_capture_id(void *stream, unsigned long long *id);
 /* What a producer kernel does with its result besides (or instead of) the fp32 store. */
 typedef struct {
     void *split_out;        /* also write the result as a split image (NULL: no) */

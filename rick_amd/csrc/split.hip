@@ -25,6 +25,16 @@ extern "C" int rick_amax_f32(const float *x, int64_t n, float *amax_word, void *
     RICK_LAUNCH_STATUS();
 }
 
+extern "C" int rick_stream_capture_id(void *stream, unsigned long long *id) {
+    if (!id) return RICK_EINVAL;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long v = 0;
+    const hipError_t e = hipStreamGetCaptureInfo((hipStream_t)stream, &st, &v);
+    if (e != hipSuccess) return 1000 + (int)e;
+    *id = (st == hipStreamCaptureStatusActive) ? (v ? v : ~0ull) : 0ull;
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void split_pack_kernel(const float *__restrict__ x, unsigned char *__restrict__ out,
                                                          cv_split_hdr *__restrict__ hdr, const float *__restrict__ a0,
                                                          const float *__restrict__ a1, float coef, int64_t n4) {

@@ -166,7 +166,7 @@ class _DResBlock(Function):
         sc1, sc2, scs, slope, gain, pad2, pads, k1, k2, ks, compose = cfg
         N, C, H, W = x.shape
         O = w2.shape[0]
-        xpk = getattr(x, '_rick_split', None)
+        xpk = sp.taken(x, '_rick_split')
         xc = x.contiguous(memory_format=torch.channels_last)
         if xpk is None:
             xpk = sp.split_pack(xc)                     # block input from a producer that is not fused (the first block)
@@ -185,7 +185,7 @@ class _DResBlock(Function):
         opk = sp.SplitImage(torch.empty_like(t2), sp.new_words(4, dev), (A2, A3, _SQ))
         check(lib.rick_add_scale_split_f32(ptr(t2), ptr(sk), ptr(out), ptr(opk.data), ptr(opk.hdr), ptr(A2), ptr(A3),
                                            t2.numel() // O, O, _SQ, stream_ptr()), 'rick_add_scale_split_f32')
-        out._rick_split = opk
+        sp.hand(out, '_rick_split', opk)
         ctx.save_for_backward(x, w1, b1, w2, b2, ws, taps, t1, t2, xpk.data, xpk.hdr, b1pk.data, b1pk.hdr, xspk.data, xspk.hdr)
         ctx.cfg = cfg
         ctx.sink = grad_sink_enabled()
@@ -220,12 +220,12 @@ class _DResBlock(Function):
             g2in = torch.add(g_t2, g_out, alpha=_SQ).contiguous(memory_format=torch.channels_last)
             A = sp.amax(g2in)
             gz2, _, gb2 = _act_adjoint_split(g2in, t2, slope, gain, A, None, need[4], param_sink(b2, O, ctx.sink and need[4]))
-            Ag = getattr(g_out, '_rick_amax', None)
+            Ag = sp.taken(g_out, '_rick_amax')
             if Ag is None:
                 Ag = sp.amax(g_out)
             gsk = sp.split_pack(g_out * _SQ, Ag, None, _SQ)
         else:
-            Ag = getattr(g_out, '_rick_amax', None)
+            Ag = sp.taken(g_out, '_rick_amax')
             if Ag is None:
                 Ag = sp.amax(g_out)
             gz2, gsk, gb2 = _act_adjoint_split(g_out, t2, slope, gain * _SQ, Ag, mul2, need[4], param_sink(b2, O, ctx.sink and need[4]))
@@ -261,7 +261,7 @@ class _DResBlock(Function):
             adjs = (kh - pads[0] - 1, W - (W // 2) * 2 + pads[0], kh - pads[0] - 1, H - (H // 2) * 2 + pads[0])
             Agx = sp.new_amax(dev)
             gx, _ = _fir_ex(g_xs, flip, 2, 1, adjs, out=gx, amax=Agx, accumulate=True)
-            gx._rick_amax = Agx
+            sp.hand(gx, '_rick_amax', Agx)
         return gx, gw1, gb1, gw2, gb2, gws, None, None
 
 
@@ -293,7 +293,7 @@ class _DInput(Function):
         ex.split_out, ex.split_hdr, ex.bound0, ex.bound1, ex.bound_coef = ptr(pk.data), ptr(pk.hdr), ptr(bound), None, 1.0
         check(lib.rick_d_input_f32(ptr(t), ptr(W), ptr(bc), ptr(x), n, h * w, O, J, float(slope), float(gain), ctypes.byref(ex),
                                    stream_ptr()), 'rick_d_input_f32')
-        x._rick_split = pk
+        sp.hand(x, '_rick_split', pk)
         ctx.save_for_backward(img, weight, bias, x, W)
         ctx.cfg = (wscale, slope, gain, compose)
         ctx.sink = grad_sink_enabled()

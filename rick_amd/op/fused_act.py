@@ -85,26 +85,51 @@ def param_sink(p, numel, enabled):
 # (rick_colsum_multi_f32: bit-identical item by item) — nobody reads those sums before the optimiser.  29 launches of ~4.7 us
 # per train iteration become 2.
 _deferred = None
+_deferred_owner = None      # ident of the thread that opened the outermost context
 _DEFER_OFF = bool(__import__('os').environ.get('RICK_NO_DEFER'))       # (A/B switch, tools/ab_env.sh)
 
 
 class deferred_sums:
+    """with op.deferred_sums(): loss.backward()
+
+    ONE backward pass at a time, process-wide: the list is filled from the autograd engine's threads, which cannot be told
+    apart by the thread that called backward().  A second thread that enters while a context is open gets a RuntimeError
+    instead of another thread's sums (nn.DataParallel worker threads only run FORWARD passes; backward is one call from the
+    main thread — INTEGRATION.md section 1).  Nesting on the opening thread is allowed."""
+
     def __enter__(self):
-        global _deferred
-        self.prev, _deferred = _deferred, (None if _DEFER_OFF else [])
+        global _deferred, _deferred_owner
+        import threading
+        me = threading.get_ident()
+        if _deferred_owner is not None and _deferred_owner != me:
+            raise RuntimeError('op.deferred_sums(): already open on another thread (one backward pass at a time)')
+        self.prev, self.prev_owner = _deferred, _deferred_owner
+        _deferred, _deferred_owner = (None if _DEFER_OFF else []), me
         return self
 
     def __exit__(self, *exc):
-        global _deferred
-        items, _deferred = _deferred, self.prev
+        global _deferred, _deferred_owner
+        items, _deferred, _deferred_owner = _deferred, self.prev, self.prev_owner
         if exc[0] is None:
             flush_colsums(items)
 
 
 def defer_colsum(part, out, nb, stride, ncols, col0=0, out2=None, split=0, accumulate=1):
-    """Queue out[c] (+)= sum_r part[r * stride + col0 + c]; False when no deferred_sums() context is open."""
+    """Queue out[c] (+)= sum_r part[r * stride + col0 + c]; False when no deferred_sums() context is open.
+
+    The items of one flush run as blocks of ONE launch, each doing a plain read-add-write of its destination: two items with the
+    same destination would race.  A module applied twice in one backward (D called separately on real and fake, a shared bias)
+    queues its sink twice — the items queued so far are then launched first (stream order = the order of the immediate path)."""
+    global _deferred
     if _deferred is None:
         return False
+    dst = {out.data_ptr()} | ({out2.data_ptr()} if out2 is not None else set())
+    for it in _deferred:
+        if it[1].data_ptr() in dst or (it[2] is not None and it[2].data_ptr() in dst):
+            items = list(_deferred)
+            del _deferred[:]
+            flush_colsums(items)
+            break
     _deferred.append((part, out, out2, int(nb), int(stride), int(ncols), int(col0), int(split), int(accumulate)))
     return True
 

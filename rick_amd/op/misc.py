@@ -14,6 +14,9 @@ from torch.autograd import Function
 from .._lib import check, lib, ptr, require_cuda_f32, stream_ptr
 
 
+stats = {'fork_inplace': 0, 'fork_copy': 0}     # how op.torgb_fork's backward added the branch gradient (tests)
+
+
 def _nhwc(x):
     return x.contiguous(memory_format=torch.channels_last)
 
@@ -294,9 +297,16 @@ class _ToRGBFork(Function):
         n, J, h, wd = g.shape
         c = w.shape[1]
         gw, gs, gb = _torgb_param_grads(ctx, g, x, w, s)
-        ok = (gx_next.dtype == torch.float32 and tuple(gx_next.shape) == (n, c, h, wd) and gx_next.data_ptr() % 16 == 0
+        # In place only into a buffer its producer marked as exclusively owned (autograd's contract forbids modifying a
+        # gradient input that somebody else may hold: a tensor hook, retain_grad() on the forked activation, a backward that
+        # returns one tensor for two inputs).  The mark is consumed; anything else is copied first.
+        ok = (gx_next.__dict__.pop('_rick_owned', False) and gx_next.dtype == torch.float32
+              and tuple(gx_next.shape) == (n, c, h, wd) and gx_next.data_ptr() % 16 == 0
               and gx_next.is_contiguous(memory_format=torch.channels_last))
         gx = gx_next if ok else gx_next.contiguous(memory_format=torch.channels_last).clone()
+        for a in ('_rick_split', '_rick_amax', '_rick_bound'):      # hand-over attributes described gx_next alone, not the sum
+            gx.__dict__.pop(a, None)
+        stats['fork_inplace' if ok else 'fork_copy'] += 1
         from .conv import hbm_launch
         check(hbm_launch('thin', 4 * (2 * gx.numel() + g.numel()), lib.rick_torgb_bwdx_acc_f32, ptr(g), ptr(w.contiguous()),
                          ptr(s.contiguous()), ctx.wscale, ptr(gx), n, h * wd, c, J, stream_ptr()), 'rick_torgb_bwdx_acc_f32')
@@ -307,9 +317,8 @@ def torgb_fork(x, w, s, bias=None, add=None, wscale=1.0):
     """(x', rgb): rgb = torgb(x, ...), x' = x for the next layer — see _ToRGBFork."""
     require_cuda_f32(x, w, s, bias, add)
     xo, t = _ToRGBFork.apply(x, w, s, bias, add, float(wscale))
-    for a in ('_rick_split', '_rick_amax', '_rick_bound'):      # hand-over attributes of the producing layer (op/split.py) travel with x
-        if hasattr(x, a):
-            setattr(xo, a, getattr(x, a))
+    from . import split as sp
+    sp.rehand(x, xo)      # still-valid hand-over attributes of the producing layer (op/split.py) travel with x
     return xo, t
 
 

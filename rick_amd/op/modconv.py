@@ -50,7 +50,7 @@ def _bound_tail(w0, c0, gain, nw=None, w_noise=None, bias=None, mul=None):
 def _tensor_amax(t):
     """The running-maximum word of a tensor: the one its producer measured (attribute), else a stand-alone pass."""
     from . import split as sp
-    a = getattr(t, '_rick_amax', None)
+    a = sp.taken(t, '_rick_amax')
     return a if a is not None else sp.amax(t)
 
 
@@ -61,7 +61,8 @@ def _same_tensor(a, b):
 
 def _input_image(x, s):
     """The split image of s * x its producer attached to x, if it was made for THIS scale tensor."""
-    img = getattr(x, '_rick_split', None)
+    from . import split as sp
+    img = sp.taken(x, '_rick_split')
     return img if (img is not None and _same_tensor(getattr(img, 'scale_of', None), s)) else None
 
 
@@ -202,12 +203,12 @@ class _ModConvFused(Function):
             if xin is not None:
                 A = sp.new_amax(x.device)
                 y = _convT_launch(None, wp, O, kh, kw, 2, 0, (oh, ow), oscale=d, x_split=xin, amax=A)
-                y._rick_bound = (A, 1.0)
+                sp.hand(y, '_rick_bound', (A, 1.0))
                 stats['fprop'] += 1
             else:
                 y = _convT_launch(x, wp, O, kh, kw, 2, 0, (oh, ow), iscale=s, oscale=d)
                 if use:
-                    y._rick_bound = (_tensor_amax(x), math.sqrt(4.0 * I))     # (a stride-2 output pixel sees <= 4 of the 9 taps)
+                    sp.hand(y, '_rick_bound', (_tensor_amax(x), math.sqrt(4.0 * I)))     # (a stride-2 output pixel sees <= 4 of the 9 taps)
         elif tail:
             bias, noise, nw = bias.contiguous(), noise.contiguous(), nw.contiguous()
             epi = _epilogue(bias, noise, nw, slope, gain)
@@ -229,9 +230,9 @@ class _ModConvFused(Function):
             else:
                 y = _conv_launch(x, wp, O, kh, kw, 1, kh // 2, iscale=s, oscale=d, epi=epi)
             if use:
-                y._rick_amax = A
+                sp.hand(y, '_rick_amax', A)
                 if img is not None:
-                    y._rick_split = img
+                    sp.hand(y, '_rick_split', img)
                     stats['produced'] += 1
         else:
             y = _conv_launch(x, wp, O, kh, kw, 1, kh // 2, iscale=s, oscale=d)
@@ -279,7 +280,8 @@ class _ModConvFused(Function):
             else:
                 g, gb, gnw = _ActAdjoint.apply(g, y, noise, slope, gain, want_b, want_w, sink_b, sink_w)
         elif sup is not None and sup['dgrad']:
-            img = getattr(g_in, '_rick_split', None)    # written by the blur's adjoint (op/upfirdn2d.py) with THIS d folded in
+            from . import split as sp
+            img = sp.taken(g_in, '_rick_split')    # written by the blur's adjoint (op/upfirdn2d.py) with THIS d folded in
             if img is not None and _same_tensor(getattr(img, 'scale_of', None), d):
                 gpk = img
         wT = w.transpose(0, 1)
@@ -319,6 +321,8 @@ class _ModConvFused(Function):
                 gd = _hw_dot_act_raw(g, y, bias, noise, nw, slope, gain, divisor=d)
             else:
                 gd = _hw_dot_raw(g, y, divisor=d)
+        if gx is not None:
+            gx._rick_owned = True        # a fresh buffer nobody else holds: op.torgb_fork may accumulate into it in place
         return (gx, gw, gs, gd, None, None, None, gb, None, gnw, None, None, None)
 
 

@@ -11,16 +11,26 @@ import torch
 from .._lib import check, lib, ptr, stream_ptr
 
 
+def capture_id():
+    """Identity of the hipGraph capture the current stream records into (0: eager issue)."""
+    import ctypes
+    v = ctypes.c_ulonglong(0)
+    check(lib.rick_stream_capture_id(stream_ptr(), ctypes.byref(v)), 'rick_stream_capture_id')
+    return v.value
+
+
 class _Arena(threading.local):
     """Zero-initialised device words handed out in slices (running maxima, headers): one fill launch per 128 KB
-    instead of one per tensor.  A chunk is never shared between eager issue and a hipGraph capture — the words a captured
-    launch accumulates into must be re-zeroed by a fill that is part of the same graph."""
+    instead of one per tensor.  A chunk belongs to ONE capture (or to eager issue): the words a captured launch accumulates
+    into must be re-zeroed by a fill that is part of the same graph — two graphs captured back to back (the D step, then the
+    G step) used to share a chunk whose fill only the first one replayed.  The key is the stream's capture
+    id, so it holds on the autograd engine's thread (its own thread-local arena) without any hand-over."""
 
     def __init__(self):
-        self.chunk, self.pos, self.cap = None, 0, False
+        self.chunk, self.pos, self.cap = None, 0, 0
 
     def take(self, n, device):
-        cap = torch.cuda.is_current_stream_capturing()
+        cap = capture_id()
         n4 = (n + 3) // 4 * 4                      # 16-byte aligned slices
         if self.chunk is None or self.pos + n4 > self.chunk.numel() or cap != self.cap or self.chunk.device != device:
             self.chunk, self.pos, self.cap = torch.zeros(32768, device=device, dtype=torch.float32), 0, cap
@@ -61,6 +71,31 @@ class SplitImage:
     @property
     def shape(self):
         return self.data.shape
+
+
+def hand(t, name, value):
+    """Attach a hand-over attribute (`_rick_split`, `_rick_amax`, `_rick_bound`) to tensor `t` together with what it
+    describes: the tensor's version counter and address at this moment."""
+    setattr(t, name, (value, t._version, t.data_ptr()))
+
+
+def taken(t, name):
+    """The attribute `hand` attached — or None when the tensor was modified in place since (x.mul_(), an in-place gradient
+    accumulation, a hook): a stale image or a maximum that is too small would give finite but wrong products (ADVICE round 4);
+    the consumer then measures / packs again."""
+    ent = getattr(t, name, None)
+    if ent is None:
+        return None
+    value, version, address = ent
+    return value if (t._version == version and t.data_ptr() == address) else None
+
+
+def rehand(src, dst, names=('_rick_split', '_rick_amax', '_rick_bound')):
+    """Carry still-valid hand-over attributes of `src` over to `dst`, an alias of the same values (a view_as output)."""
+    for a in names:
+        v = taken(src, a)
+        if v is not None:
+            hand(dst, a, v)
 
 
 def amax(x, word=None):

@@ -96,13 +96,44 @@ class _UpFirDn(Function):
         return gx, None, None, None, None
 
 
+def _host_route(x, taps, up, down, pad):
+    """CPU tensors (op/upfirdn2d.py:145-149 sends them to its torch-native form: ADA in a data worker, model debugging on
+    the host).  Plain differentiable torch, any float dtype: the zero-stuffed, padded (negative pad: cropped) signal is
+    written into one zero canvas by a strided slice assignment, correlated with the flipped taps as a 1-channel
+    convolution over [N*C, 1, H', W'] — the arithmetic the reference's CPU path performs, so fp32 results are equal
+    bit for bit — and decimated by a strided slice.  This is host-side product code, not the test oracle."""
+    import torch.nn.functional as F
+    n, c, h, w = x.shape
+    kh, kw = taps.shape
+    ch, cw = h * up + pad[0] + pad[1], w * up + pad[0] + pad[1]
+    oh, ow = (ch - kh) // down + 1, (cw - kw) // down + 1
+    if ch < kh or cw < kw or oh <= 0 or ow <= 0:
+        raise RuntimeError(f'upfirdn2d: empty output ({oh}x{ow})')
+
+    def span(extent, canvas):
+        # input sample i sits at canvas position pad0 + i * up: the samples whose position is inside [0, canvas)
+        lo = max(0, -(pad[0] // up))                    # smallest i with pad0 + i * up >= 0
+        hi = min(extent, (canvas - 1 - pad[0]) // up + 1)
+        return lo, hi, pad[0] + lo * up
+    y0, y1, py = span(h, ch)
+    x0, x1, px = span(w, cw)
+    canvas = x.new_zeros((n * c, 1, ch, cw))
+    if y1 > y0 and x1 > x0:
+        canvas[:, 0, py:py + (y1 - y0 - 1) * up + 1:up, px:px + (x1 - x0 - 1) * up + 1:up] = \
+            x.reshape(n * c, h, w)[:, y0:y1, x0:x1]
+    full = F.conv2d(canvas, torch.flip(taps, [0, 1]).to(x.dtype).view(1, 1, kh, kw))
+    return full[:, 0, ::down, ::down].reshape(n, c, oh, ow)
+
+
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
-    """Same signature and semantics as the reference op (op/upfirdn2d.py:145-156): one
-    up / down / pad pair for both axes.  CPU tensors raise (there is no native fallback)."""
-    from .._lib import require_cuda_float
-    require_cuda_float(input, kernel)      # float16 / float32 / float64 like the reference extension (one dtype per call)
+    """Same signature and semantics as the reference op (op/upfirdn2d.py:145-156): one up / down / pad pair for both
+    axes; device tensors run the HIP kernels, CPU tensors the torch route above (the reference's own device dispatch)."""
     if input.ndim != 4 or kernel.ndim != 2:
         raise RuntimeError('upfirdn2d expects input [N,C,H,W] and kernel [kh,kw]')
+    if input.device.type == 'cpu':
+        return _host_route(input, kernel, int(up), int(down), (int(pad[0]), int(pad[1])))
+    from .._lib import require_cuda_float
+    require_cuda_float(input, kernel)      # float16 / float32 / float64 like the reference extension (one dtype per call)
     return _UpFirDn.apply(input, kernel.contiguous(), (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
 
 
@@ -133,7 +164,8 @@ class _FirAct(Function):
         y = torch.empty((n, c, oh, ow), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
         tail = _epilogue(bias, noise, nw, slope, gain)
         next_s, ctx.bwd_scale = extra if extra is not None else (None, None)
-        xb = getattr(x_in, '_rick_bound', None)
+        from . import split as sp
+        xb = sp.taken(x_in, '_rick_bound')
         if xb is not None and c % 4 == 0:
             from . import split as sp
             from .modconv import _bound_tail, _tensor_amax
@@ -151,9 +183,9 @@ class _FirAct(Function):
                     ptr(img.data), ptr(img.hdr), ptr(bound), None, 1.0, ptr(ns))
             check(lib.rick_upfirdn2d_ex_f32(ptr(x), ptr(taps), ptr(y), n, h, w, c, kh, kw, 1, 1, 1, 1, pad4[0], pad4[1], pad4[2],
                                             pad4[3], ctypes.byref(tail), ctypes.byref(ex), stream_ptr()), 'rick_upfirdn2d_ex_f32')
-            y._rick_amax = A
+            sp.hand(y, '_rick_amax', A)
             if img is not None:
-                y._rick_split = img
+                sp.hand(y, '_rick_split', img)
         else:
             from .conv import hbm_launch
             check(hbm_launch('upfirdn2d', 4 * (x.numel() + y.numel()), lib.rick_upfirdn2d_act_f32, ptr(x), ptr(taps), ptr(y), n, h, w,
@@ -195,7 +227,7 @@ class _FirAct(Function):
                 bound = _bound_tail(_tensor_amax(g), _abs_sum(ctx.flipped) * abs(gain) * max(1.0, abs(slope)), 1.0, mul=bsc)
                 gx, img = _fir_ex(gz, ctx.flipped, 1, 1, adj, split_bound=bound, chan_scale=bsc)
                 img.scale_of = bs
-                gx._rick_split = img
+                sp.hand(gx, '_rick_split', img)
             else:
                 gx = _fir(gz, ctx.flipped, (1, 1), (1, 1), adj)
         return (gx, None, None, gb, None, gw, None, None, None)

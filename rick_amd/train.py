@@ -492,10 +492,16 @@ class RickTrainer:
         return self.LATENT_POOL > 1 and not os.environ.get('RICK_NO_LATENT_POOL') and not any(
             p.requires_grad for p in self.g.style.parameters())
 
+    def _style_stamp(self):
+        """What the pooled rows are valid for: the mapping network's weights as loaded (load_state_dict copies in place and
+        bumps _version; the optimiser never touches them)."""
+        return tuple((p._version, p.data_ptr()) for p in self.g.style.parameters())
+
     def _fill_latent_pool(self, ent):
         with torch.no_grad():
             z = torch.randn(self.LATENT_POOL * ent['rows'], self.cfg.latent, device=self.device)
             ent['w'].copy_(self.g.style(z).view(self.LATENT_POOL, ent['rows'], -1))
+        ent['stamp'] = self._style_stamp()
 
     def _advance_latent_pool(self, key):
         """Host side, before a step's graph runs (with _draw_inject): point the step at the next pool row, refill when used up."""
@@ -503,7 +509,9 @@ class RickTrainer:
         if ent is None:
             return
         ent['pos'] += 1
-        if ent['pos'] >= self.LATENT_POOL:
+        if ent['pos'] >= self.LATENT_POOL or ent.get('stamp') != self._style_stamp():
+            # used up — or the mapping network was reloaded (checkpoint.resume / load_source on a trainer that has already
+            # stepped): rows computed with the old weights are not draws of the current model
             self._fill_latent_pool(ent)
             ent['pos'] = 0
         ent['idx'].fill_(ent['pos'])
@@ -655,7 +663,9 @@ class RickTrainer:
         active = tuple(fp.params[i].requires_grad for i in fp.opt_idx)
         st = [optim.steps[i] for i in fp.opt_idx]
         rel = tuple(s - st[0] for s in st)
-        return (active, rel, optim.lr, tuple(optim.betas), optim.eps)
+        # (+ whether the step gathers its latents from the pool: mapping-network parameters that become trainable after a
+        # capture switch the step back to drawing and mapping its own noise)
+        return (active, rel, optim.lr, tuple(optim.betas), optim.eps, self._pool_ok())
 
     def invalidate_graphs(self):
         """Drop every captured step (after loading a checkpoint or changing optimiser hyper-parameters)."""
@@ -664,6 +674,7 @@ class RickTrainer:
             st.pop('graphs', None)
             st['n'] = 0                                       # two eager warm-up steps before the next capture
         self._fisher_state = None
+        self.__dict__.pop('_lat_pool', None)                  # pooled W rows belong to the weights they were mapped with
 
     # ---- steps (each returns the loss tensor; no host sync)
     def d_step(self, real_img, noise, i=10 ** 9, g_noise=None, graph=False):

@@ -15,6 +15,19 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'saturates: the test provokes fp16 saturation on purpose (the counter may be non-zero)')
 
 
+# Collection order of the GPU suite: kernel parity first, then the models / loop body, then the rows either side of the
+# hot path, and the multi-process data-parallel tests LAST — under `-x` a red late test must never hide the parity tests.
+_ORDER = ['test_gpu_ops', 'test_gpu_split', 'test_gpu_models', 'test_gpu_step_batching', 'test_gpu_determinism',
+          'test_augment', 'test_eval_stats', 'test_data_path', 'test_checkpoint', 'test_gpu_dp']
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _ORDER.index(mod) if mod in _ORDER else len(_ORDER) - 1     # unknown modules: before test_gpu_dp
+    items.sort(key=rank)                                                   # stable: order inside a module is kept
+
+
 @pytest.fixture(scope='session')
 def golden():
     import numpy as np

@@ -114,13 +114,29 @@ def _run(mode):
     return outs
 
 
+def describe_difference(net, x, y, size=32):
+    """Per parameter: how many elements of two flat parameter buffers differ and by how much (names the layer)."""
+    from rick_amd.models import Discriminator, Generator
+    from rick_amd.train import FlatParams, d_optim_filter, g_optim_filter
+    mod, flt = ((Generator(size, 512, 8), g_optim_filter) if net == 1 else (Discriminator(size), d_optim_filter))
+    fp = FlatParams(mod.named_parameters(), flt)
+    lines = []
+    for n in fp.names:
+        lo, hi = fp.segment(n)
+        ne = int((x[lo:hi] != y[lo:hi]).sum())
+        if ne:
+            lines.append(f'{n}: {ne} of {hi - lo} differ, max |d| {np.abs(x[lo:hi] - y[lo:hi]).max():.3e} '
+                         f'(max |p| {np.abs(y[lo:hi]).max():.3e})')
+    return '\n'.join(lines)
+
+
 def test_two_rank_trainer_bucketed_equals_blocking_allreduce():
     a = _run('bucketed')
     b = _run('blocking')
     for net in (1, 2):
-        assert np.array_equal(a[0][net], a[1][net])               # replicas stay identical
+        assert np.array_equal(a[0][net], a[1][net]), describe_difference(net, a[0][net], a[1][net])   # replicas stay identical
         assert np.isfinite(a[0][net]).all()
-        assert np.array_equal(a[0][net], b[0][net])               # same update as the plain exchange
+        assert np.array_equal(a[0][net], b[0][net]), describe_difference(net, a[0][net], b[0][net])   # same update as the plain exchange
 
 
 # ------------------------------------------------------------------------------------------------------------------

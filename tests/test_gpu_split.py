@@ -151,7 +151,7 @@ def test_discriminator_resblock_one_node_vs_per_layer(N, C, O, H):
     """Forward values, input gradient and every parameter gradient of the split-image block against the per-layer path
     (the round-3 path, itself pinned to the reference's goldens) and against an fp64 torch evaluation."""
     from rick_amd import models, op
-    from rick_amd.op import dblock
+    from rick_amd.op import dblock, split as sp
     blk = _block(C, O)
     x0 = _octaves((N, C, H, H), -3, 2, 8)
     assert dblock.block_supported(x0, blk.conv1[0].weight, blk.conv2[1].weight, blk.skip[1].weight)
@@ -170,7 +170,7 @@ def test_discriminator_resblock_one_node_vs_per_layer(N, C, O, H):
         finally:
             models._USE_DBLOCK = True
         if mode:
-            assert getattr(out, '_rick_split', None) is not None
+            assert sp.taken(out, '_rick_split') is not None
     assert _sat() == 0
 
     def rel(a, b):
@@ -302,7 +302,7 @@ def test_discriminator_input_layer_one_launch_equals_two_op_path():
             g = torch.autograd.grad((y * y).sum(), [img, layer[0].weight, layer[1].bias])
             res[mode] = [y.detach()] + [t.detach() for t in g]
             if mode:
-                pk = y._rick_split
+                pk = sp.taken(y, '_rick_split')
                 assert float(pk.hdr[2]) >= float(y.abs().max())
                 assert torch.equal(pk.data, sp.split_pack(y.detach(), *pk.bound).data)
         finally:

@@ -228,6 +228,41 @@ def test_torgb_fork_adds_the_branch_gradient_in_the_kernel(sink):
     assert adds1 <= adds0 - 3, (adds0, adds1)      # one big add per resolution below the last is gone (64 px: 4 of them)
 
 
+def test_torgb_fork_never_modifies_a_gradient_it_does_not_own():
+    """the in-place accumulate is taken only into a buffer the producing backward marked as exclusively owned
+    (the modulated convolution's fresh data gradient).  A gradient that arrives from anywhere else — here from torch's own
+    multiplication backward, which carries no mark — is copied first, and the result equals the unfused form."""
+    from rick_amd import op
+    from rick_amd.op import misc
+    torch.manual_seed(5)
+    n, c, h = 2, 64, 16
+    x = torch.randn(n, c, h, h, device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.randn(3, c, device='cuda', requires_grad=True)
+    s = torch.rand(n, c, device='cuda') + 0.5
+    const = torch.randn(n, c, h, h, device='cuda').contiguous(memory_format=torch.channels_last)
+    keep = const.clone()
+    before = dict(misc.stats)
+    xo, t = op.torgb_fork(x, w, s, wscale=0.125)
+    ((xo * const).sum() + (t * t).sum()).backward()
+    gx_fork, gw_fork = x.grad.clone(), w.grad.clone()
+    assert torch.equal(const, keep)
+    assert misc.stats['fork_copy'] == before['fork_copy'] + 1 and misc.stats['fork_inplace'] == before['fork_inplace']
+    x.grad = w.grad = None
+    t2 = op.torgb(x, w, s, wscale=0.125)
+    ((x * const).sum() + (t2 * t2).sum()).backward()
+    assert torch.equal(t, t2) and torch.equal(gw_fork, w.grad)
+    assert torch.allclose(gx_fork, x.grad, rtol=0, atol=1e-6 * float(x.grad.abs().max()))   # a + b vs b + a: same fp32 sum
+    # the generator's own hand-over is the owned, in-place one
+    g = _gen()
+    for p in g.style.parameters():
+        p.requires_grad_(False)
+    latent = torch.randn(2, g.n_latent, 512, device='cuda')
+    noise = [torch.randn(1, 1, m.shape[-1], m.shape[-1], device='cuda') for m in g.make_noise()]
+    before = dict(misc.stats)
+    _run(g, latent, noise, True, False)
+    assert misc.stats['fork_inplace'] >= before['fork_inplace'] + 3 and misc.stats['fork_copy'] == before['fork_copy']
+
+
 def test_latent_pool_serves_fresh_rows_and_refills():
     """RickTrainer's latent pool: with a frozen mapping network the W-space rows of the next LATENT_POOL steps come from one
     pass through the mapping layers; a graph-replayed step gathers its own rows by a device-side index.  Every step sees different
@@ -270,3 +305,49 @@ def test_latent_pool_serves_fresh_rows_and_refills():
     for p_ in g.style.parameters():
         p_.requires_grad_(True)
     assert not tr._pool_ok()
+
+
+def test_latent_pool_follows_reloaded_mapping_network():
+    """pooled W rows are values of the mapping network AS IT WAS when the pool was filled.  Loading other
+    mapping weights into a trainer that has already stepped (checkpoint.resume / load_source) must not leave up to 15 steps
+    training on rows of the old network: the next step refills the pool from the loaded weights (in place — a captured step
+    keeps gathering from the same buffer), and invalidate_graphs() / resume() drop the pool with the graphs."""
+    from rick_amd import checkpoint
+    from rick_amd.synth import synth_reals
+    from rick_amd.train import RickTrainer, TrainConfig
+    from tests.test_gpu_models import build
+    size, B = 32, 2
+    g, d = build(size)
+    tr = RickTrainer(TrainConfig(size=size, batch=B, warmup_iter=0), g, d, *build(size))
+    tr.enable_graphs(True)
+    real = synth_reals(B, size=size, seed=5).cuda()
+    for _ in range(4):                                   # two eager steps, the capture, one replay
+        tr.d_step(real, None, graph=True)
+    ent = tr._lat_pool['d']
+    assert int(ent['idx']) == 3
+    buf = ent['w'].data_ptr()
+    sd = {k: v.clone() for k, v in g.state_dict().items()}
+    for k in sd:
+        if k.startswith('style.') and k.endswith('weight'):
+            sd[k] = sd[k] * 1.25
+    g.load_state_dict(sd)
+    torch.manual_seed(11)
+    tr.d_step(real, None, graph=True)                    # a replay; its host side refilled the pool first
+    torch.cuda.synchronize()
+    assert tr._lat_pool['d'] is ent and ent['w'].data_ptr() == buf and int(ent['idx']) == 0
+    torch.manual_seed(11)
+    with torch.no_grad():
+        z = torch.randn(tr.LATENT_POOL * 2 * B, 512, device='cuda')
+        want = g.style(z).view(tr.LATENT_POOL, 2 * B, -1)
+    assert torch.equal(ent['w'], want)
+    # resume(): graphs and pool go together; the next eager step builds a fresh pool from the restored weights
+    ck = checkpoint.state_dict(tr)
+    checkpoint.resume(tr, ck)
+    assert '_lat_pool' not in tr.__dict__
+    torch.manual_seed(12)
+    tr.d_step(real, None, graph=True)
+    torch.manual_seed(12)
+    with torch.no_grad():
+        z = torch.randn(tr.LATENT_POOL * 2 * B, 512, device='cuda')
+        want = g.style(z).view(tr.LATENT_POOL, 2 * B, -1)
+    assert torch.equal(tr._lat_pool['d']['w'], want)

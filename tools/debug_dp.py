@@ -1,23 +1,17 @@
-"""Where the bucketed and the blocking data-parallel runs of tests/test_gpu_dp.py differ (parameter, magnitude)."""
+"""Where the bucketed and the blocking data-parallel runs of tests/test_gpu_dp.py differ (parameter, count, magnitude) —
+and whether each mode agrees with ITSELF (mode dependence vs run-to-run non-determinism)."""
 import os
 import sys
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.test_gpu_dp import _run  # noqa: E402
+from tests.test_gpu_dp import _run, describe_difference  # noqa: E402
 
 if __name__ == '__main__':
-    from rick_amd.models import Discriminator, Generator
-    from rick_amd.train import FlatParams, d_optim_filter, g_optim_filter
-    a, b = _run('bucketed'), _run('blocking')
-    g, d = Generator(32, 512, 8), Discriminator(32)
-    for net, mod, flt in ((1, g, g_optim_filter), (2, d, d_optim_filter)):
-        fp = FlatParams(mod.named_parameters(), flt)
-        x, y = a[0][net], b[0][net]
-        print('net', net, 'equal', np.array_equal(x, y), 'ranks equal', np.array_equal(a[0][net], a[1][net]))
-        for n in fp.names:
-            lo, hi = fp.segment(n)
-            dd = np.abs(x[lo:hi] - y[lo:hi]).max()
-            if dd > 0:
-                print(f'  {n:44s} max abs diff {dd:.3e}  (max |p| {np.abs(y[lo:hi]).max():.3e})')
+    a, a2, b, b2 = _run('bucketed'), _run('bucketed'), _run('blocking'), _run('blocking')
+    for label, x, y in (('bucketed vs bucketed', a, a2), ('blocking vs blocking', b, b2), ('bucketed vs blocking', a, b)):
+        for net in (1, 2):
+            print(label, 'net', net, 'equal', np.array_equal(x[0][net], y[0][net]),
+                  'ranks equal', np.array_equal(x[0][net], x[1][net]))
+            print(describe_difference(net, x[0][net], y[0][net]))
