@@ -464,6 +464,22 @@ int rick_demod_bwd_s_multi_f32(const float *s_flat, const float *d_flat, const f
  * x [B, K], W [O, K], bias [O] or NULL, out [B, O].  B <= 16, K % 4 == 0, x / W 16-byte aligned. */
 int rick_equal_linear_f32(const float *x, const float *W, const float *bias, float *out, int B, int K, int O,
                           float scale, float bias_mul, int act, float slope, float gain, int pixelnorm, void *stream);
+/* EqualLinear WITH gradients on a short batch (the discriminator's final layers, model_probe_tune.py:699-702, in every D pass;
+ * F.linear(input, weight * scale, bias * lr_mul) of :157-168): three products closed under differentiation, each one pass
+ * over the [O, K] matrix, summed in a fixed order (bit-reproducible run to run — the library GEMMs they replace may use
+ * atomically accumulated split-K solutions for M = batch, K = 8192).  B <= 16, K % 4 == 0, matrices 16-byte aligned.
+ *   fwd   out[b,o] = alpha * sum_k x[b,k] W[o,k] + bias_mul * bias[o]          (bias may be NULL)
+ *   dgrad out[b,k] = alpha * sum_o g[b,o] W[o,k]
+ *   wgrad gw[o,k] (+)= alpha * sum_b g[b,o] x[b,k];  gb[o] (+)= bias_mul * sum_b g[b,o]   (gw or gb may be NULL)
+ * `workspace`: rick_linear_{fwd,dgrad}_workspace_floats() floats (0: may be NULL), 16-byte aligned. */
+int64_t rick_linear_fwd_workspace_floats(int B, int K, int O);
+int rick_linear_fwd_f32(const float *x, const float *W, const float *bias, float *out, int B, int K, int O, float alpha,
+                        float bias_mul, float *workspace, void *stream);
+int64_t rick_linear_dgrad_workspace_floats(int B, int K, int O);
+int rick_linear_dgrad_f32(const float *g, const float *W, float *out, int B, int K, int O, float alpha, float *workspace,
+                          void *stream);
+int rick_linear_wgrad_f32(const float *g, const float *x, float *gw, float *gb, int B, int K, int O, float alpha,
+                          float bias_mul, int accumulate, void *stream);
 
 /* Masked Adam over a flat parameter buffer (mask bits: 1 = freeze (grad := 0),
  * 2 = prune (param := 0, grad := 0); mask may be NULL), torch.optim.Adam semantics

@@ -142,6 +142,11 @@ SIGNATURES = {
     'rick_modbank_fwd_f32': (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int, c_int, c_f, c_fp, c_fp]),
     'rick_modbank_bwd_f32': (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_int, c_int, c_f, c_fp, c_int, c_fp]),
     'rick_equal_linear_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_f, c_f, c_int, c_f, c_f, c_int, c_fp]),
+    'rick_linear_fwd_workspace_floats': (c_i64, [c_int, c_int, c_int]),
+    'rick_linear_fwd_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_f, c_f, c_fp, c_fp]),
+    'rick_linear_dgrad_workspace_floats': (c_i64, [c_int, c_int, c_int]),
+    'rick_linear_dgrad_f32': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_f, c_fp, c_fp]),
+    'rick_linear_wgrad_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_f, c_f, c_int, c_fp]),
     'rick_adam_prepare_f32': (c_int, [c_fp, c_int, c_int, c_f, c_f, c_fp, c_fp]),
     'rick_masked_adam_dev_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f, c_f, c_f, c_f, c_fp, c_fp]),
     'rick_ema_f32': (c_int, [c_fp, c_fp, c_i64, c_f, c_fp]),

@@ -35,3 +35,12 @@ __device__ __forceinline__ float block_sum_256(float v, float *red /* >= 4 float
     __syncthreads();
     return red[0] + red[1] + red[2] + red[3];
 }
+
+// 16-byte load through a pointer that is KNOWN to address global memory.  Pointers read from descriptor tables are generic
+// to the compiler (FLAT loads: 64-bit per-lane address pairs, LDS / scratch aperture checks); this form yields
+// `global_load_dwordx4 v, v_off, s[base]`.
+typedef float rick_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_global4(const float *p) {
+    const rick_f32x4 v = *(const rick_f32x4 __attribute__((address_space(1))) *)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}

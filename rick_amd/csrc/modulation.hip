@@ -418,6 +418,8 @@ extern "C" int rick_demod_bwd_w_multi_f32(const float *s_flat, const float *d_fl
 // io_off of the flat output / gradient-input buffer, gW_l / gb_l at gw_off / gb_off of the flat gradient buffer.
 // K % 256 == 0, B <= 8.
 #define MB_ROWS 32       // channels per block
+// acc = fma(a, b, acc) as ONE scalar-lane instruction the vectoriser cannot pair up (see modbank_fwd_kernel)
+#define MB_FMAC(acc, a, b) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b))
 
 __global__ __launch_bounds__(256) void modbank_fwd_kernel(const float *__restrict__ lat, int B, int n_latent, int K,
                                                           const rick_modbank_desc *__restrict__ descs, int n, float scale,
@@ -437,6 +439,14 @@ __global__ __launch_bounds__(256) void modbank_fwd_kernel(const float *__restric
     // the wave's 8 weight rows are fetched together, one k slice (256 floats) at a time: 8 independent 16-byte loads in flight per
     // lane instead of a dependent load -> reduce chain per row (the launch is latency-bound: 40 -> ~10 us for the 20 layers of a
     // 256-px generator).  Per (row, b) the products are accumulated in the same k order as before: same values.
+    //
+    // The multiply-adds are written as explicit v_fmac_f32 (MB_FMAC).  Left to the compiler this loop becomes 128 v_pk_fma_f32
+    // (two rows per instruction, the latent element broadcast by op_sel) — and THAT form returned 1-3 wrong outputs (off by one
+    // lane's partial sum) in 3-8 % of its launches whenever another process kept the same GPU busy, never when it ran alone
+    // (round 5: tools/stress_ops.py, tools/stress_bank.py; it is what turned tests/test_gpu_dp.py red on the driver's box in
+    // round 4: two ranks share cuda:0 there).  Same loop, same loads, scalar FMAs: 0 differences in 30 000 launches under the
+    // same load; so was the round-3 one-row-at-a-time form.  No other kernel of the library showed the effect (18 op families
+    // and full G / D passes, 2 000 launches each).  Cause not established (the ISA's waits and hazards read correctly).
     constexpr int RW = MB_ROWS / 4;
     float acc[RW][MB_MAXB];
 #pragma unroll
@@ -456,10 +466,10 @@ __global__ __launch_bounds__(256) void modbank_fwd_kernel(const float *__restric
                 const float4 lv = *reinterpret_cast<const float4 *>(sl + b * K + k);
 #pragma unroll
                 for (int r = 0; r < RW; r++) {
-                    acc[r][b] = __builtin_fmaf(wv[r].x, lv.x, acc[r][b]);
-                    acc[r][b] = __builtin_fmaf(wv[r].y, lv.y, acc[r][b]);
-                    acc[r][b] = __builtin_fmaf(wv[r].z, lv.z, acc[r][b]);
-                    acc[r][b] = __builtin_fmaf(wv[r].w, lv.w, acc[r][b]);
+                    MB_FMAC(acc[r][b], wv[r].x, lv.x);
+                    MB_FMAC(acc[r][b], wv[r].y, lv.y);
+                    MB_FMAC(acc[r][b], wv[r].z, lv.z);
+                    MB_FMAC(acc[r][b], wv[r].w, lv.w);
                 }
             }
     }

@@ -357,11 +357,74 @@ extern "C" int rick_d_input_f32(const float *t, const float *W, const float *bia
     RICK_LAUNCH_STATUS();
 }
 
+// Column-owner form of thin_bwdx (C / 4 divides 256): a thread owns one channel quad — its J modulated weight rows live in
+// registers for the whole launch — and walks the block's pixels, 256 / (C / 4) of them per step, TB_UNR steps in flight.  The
+// round-4 form (one output quad per thread and iteration: an int64 division, J weight loads with the style multiply and J
+// scalar loads for 16 bytes stored, 8 192 single-iteration blocks at 512 ch @64^2) ran 2.7 TB/s there; same sums, same order.
+#define TB_UNR 4
+template <bool ACC>
+__global__ __launch_bounds__(256) void thin_bwdx_cols_kernel(const float *__restrict__ t, const float *__restrict__ W,
+                                                             int64_t w_bstride, float *__restrict__ x, int64_t P, int C, int J,
+                                                             ThinMod m, int pix_per_block) {
+    const int n = blockIdx.y;
+    const int C4 = C >> 2, rows = 256 / C4;
+    const int c4 = threadIdx.x % C4, r = threadIdx.x / C4;
+    const float *Wn = W + (int64_t)n * w_bstride;
+    const float *tn = t + (int64_t)n * J * P;
+    float4 *xn = reinterpret_cast<float4 *>(x + (int64_t)n * P * C);
+    float4 wv[THIN_MAXJ];
+#pragma unroll
+    for (int j = 0; j < THIN_MAXJ; j++) wv[j] = thin_w(Wn + (int64_t)(j < J ? j : J - 1) * C, m, n, C, c4 * 4);
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = p0 + pix_per_block < P ? p0 + pix_per_block : P;
+    auto one = [&](int64_t p, const float (&tv)[THIN_MAXJ], const float4 old) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < THIN_MAXJ; j++) {
+            const float tj = j < J ? tv[j] : 0.f;
+            acc.x += tj * wv[j].x; acc.y += tj * wv[j].y; acc.z += tj * wv[j].z; acc.w += tj * wv[j].w;
+        }
+        if (ACC) acc = make_float4(old.x + acc.x, old.y + acc.y, old.z + acc.z, old.w + acc.w);
+        xn[p * C4 + c4] = acc;
+    };
+    int64_t p = p0 + r;
+    for (; p + (TB_UNR - 1) * rows < p1; p += TB_UNR * rows) {
+        float tv[TB_UNR][THIN_MAXJ];
+        float4 old[TB_UNR];
+#pragma unroll
+        for (int u = 0; u < TB_UNR; u++) {
+#pragma unroll
+            for (int j = 0; j < THIN_MAXJ; j++) tv[u][j] = tn[(int64_t)(j < J ? j : J - 1) * P + p + u * rows];
+            old[u] = ACC ? xn[(p + u * rows) * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < TB_UNR; u++) one(p + u * rows, tv[u], old[u]);
+    }
+    for (; p < p1; p += rows) {
+        float tv[THIN_MAXJ];
+#pragma unroll
+        for (int j = 0; j < THIN_MAXJ; j++) tv[j] = tn[(int64_t)(j < J ? j : J - 1) * P + p];
+        one(p, tv, ACC ? xn[p * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+}
+
 CV_DEFINE_SAT_ACCESSOR(rick_sat_thin)
 
 static int thin_bwdx_launch(const float *t, const float *W, int64_t w_bstride, float *x, int N, int64_t P, int C, int J, ThinMod m,
                             void *stream, bool acc = false) {
     if (!x || !W || !t || N <= 0 || P <= 0 || C <= 0 || C % 4 || J < 1 || J > THIN_MAXJ || N > 65535) return RICK_EINVAL;
+    const int C4 = C / 4;
+    if (C4 <= 256 && 256 % C4 == 0) {
+        // ~2 048 blocks (8 per CU) with at least TB_UNR steps each
+        const int rows = 256 / C4;
+        int64_t ppb = cdiv64(P * N, 2048);
+        if (ppb < (int64_t)TB_UNR * rows) ppb = (int64_t)TB_UNR * rows;
+        ppb = cdiv64(ppb, rows) * rows;
+        const unsigned nbx = (unsigned)cdiv64(P, ppb);
+        if (acc) hipLaunchKernelGGL(thin_bwdx_cols_kernel<true>, dim3(nbx, N), dim3(256), 0, (hipStream_t)stream, t, W, w_bstride, x, P, C, J, m, (int)ppb);
+        else hipLaunchKernelGGL(thin_bwdx_cols_kernel<false>, dim3(nbx, N), dim3(256), 0, (hipStream_t)stream, t, W, w_bstride, x, P, C, J, m, (int)ppb);
+        RICK_LAUNCH_STATUS();
+    }
     int64_t nb = cdiv64(P * (C / 4), 256);
     if (nb > 4096) nb = 4096;
     if (acc) hipLaunchKernelGGL(thin_bwdx_kernel<true>, dim3((unsigned)nb, N), dim3(256), 0, (hipStream_t)stream, t, W, w_bstride, x, P, C, J, m);
@@ -396,19 +459,31 @@ extern "C" int rick_torgb_bwdx_acc_f32(const float *g, const float *w, const flo
 extern "C" int rick_thin_wgrad_blocks(int64_t P) {
     int64_t nb = cdiv64(P, THINW_ROWS);
     if (nb > 256) nb = 256;
-    return (int)(nb < 1 ? 1 : nb);
+    if (nb < 1) nb = 1;
+    if (cdiv64(P, nb) > 2048) nb = cdiv64(P, 2048);      // the block's slice of t sits in LDS (J x pixels)
+    return (int)nb;
 }
 
-// float4 over channels: thread owns 4 consecutive channels of a row-lane, J x 4 accumulators.
+// float4 over channels: thread owns 4 consecutive channels of a row-lane, J x 4 accumulators.  The block's slice of t
+// (J x pixels) is staged in LDS once (coalesced) — the per-row scalar loads of round 4 sat in front of every FMA group — and
+// TW_UNR rows are in flight per thread (same per-thread summation order: rows in increasing p).
+#define TW_UNR 8
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float *__restrict__ t, const float *__restrict__ x,
                                                          float *__restrict__ partials, int64_t P, int C, int J) {
-    extern __shared__ float lds[];   // [256 * 4]
+    extern __shared__ float lds[];   // [256 * 4] reduction scratch, then [J][ppb] slice of t
     const int n = blockIdx.y, N = gridDim.y, nb = gridDim.x;
     const int64_t ppb = cdiv64(P, nb);
     const int64_t p0 = (int64_t)blockIdx.x * ppb, p1 = p0 + ppb < P ? p0 + ppb : P;
+    const int np = (int)(p1 - p0);
     const float *xn = x + (int64_t)n * P * C;
     const float *tn = t + (int64_t)n * J * P;
     float *pb = partials + ((int64_t)blockIdx.x * N + n) * J * C;
+    float *st = lds + 1024;                                   // [THIN_MAXJ][ppb]; rows j >= J hold row J - 1 (never stored)
+    for (int e = threadIdx.x; e < THIN_MAXJ * np; e += 256) {
+        const int j = e / np, i = e - j * np;
+        st[j * (int)ppb + i] = tn[(int64_t)(j < J ? j : J - 1) * P + p0 + i];
+    }
+    __syncthreads();
     const int ncol = C >> 2;
     for (int cbase = 0; cbase < ncol; cbase += 256) {
         const int cg = ncol - cbase < 256 ? ncol - cbase : 256;
@@ -418,25 +493,23 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float *__restrict
 #pragma unroll
         for (int j = 0; j < THIN_MAXJ; j++) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (lane_r < rpb) {
-            auto row = [&](int64_t p, const float4 xv) {
-                float tv[THIN_MAXJ];
-#pragma unroll
-                for (int j = 0; j < THIN_MAXJ; j++) tv[j] = tn[(int64_t)(j < J ? j : J - 1) * P + p];   // no branch
+            auto row = [&](int i, const float4 xv) {
 #pragma unroll
                 for (int j = 0; j < THIN_MAXJ; j++) {   // accumulators of rows j >= J are never stored
-                    acc[j].x += tv[j] * xv.x; acc[j].y += tv[j] * xv.y; acc[j].z += tv[j] * xv.z; acc[j].w += tv[j] * xv.w;
+                    const float tv = st[j * (int)ppb + i];
+                    acc[j].x += tv * xv.x; acc[j].y += tv * xv.y; acc[j].z += tv * xv.z; acc[j].w += tv * xv.w;
                 }
             };
-            const float *xc = xn + (int64_t)(cbase + lane_c) * 4;
-            int64_t p = p0 + lane_r;
-            for (; p + 3 * rpb < p1; p += 4 * rpb) {       // four rows in flight per thread (same summation order)
-                const float4 x0 = *reinterpret_cast<const float4 *>(xc + p * C);
-                const float4 x1 = *reinterpret_cast<const float4 *>(xc + (p + rpb) * C);
-                const float4 x2 = *reinterpret_cast<const float4 *>(xc + (p + 2 * rpb) * C);
-                const float4 x3 = *reinterpret_cast<const float4 *>(xc + (p + 3 * rpb) * C);
-                row(p, x0); row(p + rpb, x1); row(p + 2 * rpb, x2); row(p + 3 * rpb, x3);
+            const float *xc = xn + p0 * C + (int64_t)(cbase + lane_c) * 4;
+            int i = lane_r;
+            for (; i + (TW_UNR - 1) * rpb < np; i += TW_UNR * rpb) {
+                float4 xv[TW_UNR];
+#pragma unroll
+                for (int u = 0; u < TW_UNR; u++) xv[u] = *reinterpret_cast<const float4 *>(xc + (int64_t)(i + u * rpb) * C);
+#pragma unroll
+                for (int u = 0; u < TW_UNR; u++) row(i + u * rpb, xv[u]);
             }
-            for (; p < p1; p += rpb) row(p, *reinterpret_cast<const float4 *>(xc + p * C));
+            for (; i < np; i += rpb) row(i, *reinterpret_cast<const float4 *>(xc + (int64_t)i * C));
         }
 #pragma unroll
         for (int j = 0; j < THIN_MAXJ; j++) {
@@ -478,7 +551,9 @@ extern "C" int rick_thin_wgrad_f32(const float *t, const float *x, float *G, int
     if (((uintptr_t)x | (uintptr_t)partials) % 16) return RICK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nb = rick_thin_wgrad_blocks(P);
-    hipLaunchKernelGGL(thin_wgrad_kernel, dim3(nb, N), dim3(256), 1024 * sizeof(float), st, t, x, partials, P, C, J);
+    const size_t lds = (1024 + (size_t)THIN_MAXJ * cdiv64(P, nb)) * sizeof(float);
+    if (lds > 64 * 1024) return RICK_EINVAL;
+    hipLaunchKernelGGL(thin_wgrad_kernel, dim3(nb, N), dim3(256), lds, st, t, x, partials, P, C, J);
     const int64_t n = (int64_t)N * J * C;
     hipLaunchKernelGGL(thin_partial_sum_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, partials, G, nb, n);
     RICK_LAUNCH_STATUS();

@@ -29,6 +29,7 @@ CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512}
 _USE_DBLOCK = not os.environ.get('RICK_NO_DBLOCK')
 _USE_RGB_FORK = not os.environ.get('RICK_NO_RGB_FORK')
 _USE_DEMOD_BANK = not os.environ.get('RICK_NO_DEMOD_BANK')      # (A/B switch, tools/ab_*.sh)
+_USE_OWN_LINEAR = not os.environ.get('RICK_NO_OWN_LINEAR')      # EqualLinear with gradients on op.linear (else torch.addmm)
 
 
 def _channels(res, channel_multiplier):
@@ -75,8 +76,9 @@ def Downsample(kernel, factor=2):
 
 
 class EqualLinear(nn.Module):
-    """model_probe_tune.py:139-173.  The GEMM itself is a plain library call (rocBLAS via
-    F.linear); the bias + LeakyReLU tail is the fused HIP op."""
+    """model_probe_tune.py:139-173.  Short batches (every use inside the training loop: the mapping network and D's final
+    layers at <= 16 rows) run the library's own one-pass, fixed-order products (op.equal_linear without a graph, op.linear with
+    gradients of any order); longer batches and N-D inputs go to the BLAS library.  The bias + LeakyReLU tail is the fused op."""
 
     def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
         super().__init__()
@@ -98,8 +100,14 @@ class EqualLinear(nn.Module):
             return op.equal_linear(x, self.weight, self.bias, self.scale, self.lr_mul, bool(self.activation), pixelnorm)
         if pixelnorm:
             x = x * torch.rsqrt(torch.mean(x ** 2, dim=1, keepdim=True) + 1e-8)
-        # x @ (W * scale)^T as one rocBLAS call (scale = GEMM alpha) instead of a [out, in] elementwise pass
         bias = self.bias if self.lr_mul == 1 or self.bias is None else self.bias * self.lr_mul
+        if _USE_OWN_LINEAR and op._linear.supported(x, self.weight):
+            # with gradients, short batch (D's final layers in every D pass): forward, data and weight gradient are one pass
+            # over the matrix each, summed in a fixed order (rick_amd/csrc/linear.hip)
+            if self.activation:
+                return fused_leaky_relu(op.linear(x, self.weight, None, self.scale), bias)
+            return op.linear(x, self.weight, self.bias, self.scale, self.lr_mul)
+        # x @ (W * scale)^T as one rocBLAS call (scale = GEMM alpha) instead of a [out, in] elementwise pass
         if x.ndim != 2:
             out = F.linear(x, self.weight * self.scale)
             if self.activation:

@@ -67,10 +67,18 @@ def test_upfirdn2d_nhwc_bitexact(cfg):
     assert rel_err(gx, gxr) < 2e-6
 
 
-def test_upfirdn2d_rejects_cpu():
+def test_upfirdn2d_device_dispatch_agrees():
+    """op/upfirdn2d.py:145-149: CPU tensors take the host route, device tensors the HIP kernels — same values (the host route
+    itself is pinned against the reference's CPU results in tests/test_op_cpu_dispatch.py); mixing devices is an error."""
     from rick_amd.op import upfirdn2d
+    x = torch.randn(2, 3, 9, 9)
+    k = torch.ones(4, 4) / 16
+    y_host = upfirdn2d(x, k, up=2, pad=(2, 1))
+    y_dev = upfirdn2d(x.cuda(), k.cuda(), up=2, pad=(2, 1))
+    assert y_host.device.type == 'cpu' and y_dev.is_cuda
+    assert rel_err(y_dev, y_host) < 2e-6
     with pytest.raises(RuntimeError):
-        upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(4, 4) / 16)
+        upfirdn2d(x.cuda(), k)
 
 
 # ------------------------------------------------------------------------- fused act
@@ -714,6 +722,107 @@ def test_equal_linear_short_batch_kernel(B, K, O, act, pn):
     if act:
         ref = F.leaky_relu(ref, 0.2) * math.sqrt(2)
     assert y.shape == ref.shape and rel_err(y, ref) < 2e-6
+
+
+@pytest.mark.parametrize('B,K,O,bias', [(8, 8192, 512, False), (4, 8192, 512, True), (8, 512, 1, True), (1, 512, 512, True),
+                                        (16, 2052, 37, True), (3, 64, 40, False)])
+def test_linear_family_values_and_gradients_vs_fp64(B, K, O, bias):
+    """op.linear = F.linear(x, W * scale, bias * lr_mul) (model_probe_tune.py:157-168) on rick_linear_{fwd,dgrad,wgrad}_f32:
+    value, the three first-order gradients and the second-order terms R1 needs (gradient of |dy/dx|^2 w.r.t. W, b and x
+    through the family's own double backward) against the same expressions in float64."""
+    from rick_amd import op
+    gen = torch.Generator().manual_seed(B * 7 + K + O)
+    x = torch.randn(B, K, generator=gen).to(DEV).requires_grad_(True)
+    w = torch.randn(O, K, generator=gen).to(DEV).requires_grad_(True)
+    b = torch.randn(O, generator=gen).to(DEV).requires_grad_(True) if bias else None
+    gy = torch.randn(B, O, generator=gen).to(DEV)
+    alpha, mul = 1 / math.sqrt(K), 0.5
+    xd, wd, gyd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True), gy.double()
+    bd = b.detach().double().requires_grad_(True) if bias else None
+
+    def f32():
+        return op.linear(x, w, b, alpha, mul)
+
+    def f64():
+        return xd @ (wd * alpha).t() + (bd * mul if bias else 0.0)
+    y, yd = f32(), f64()
+    assert rel_err(y, yd) < 2e-6
+    ins, insd = [t for t in (x, w, b) if t is not None], [t for t in (xd, wd, bd) if t is not None]
+    g1 = torch.autograd.grad(y, ins, gy)
+    g1d = torch.autograd.grad(yd, insd, gyd)
+    for a, r in zip(g1, g1d):
+        assert rel_err(a, r) < 2e-6
+    # second order: h = d<y, gy>/dx (depends on W only), loss = sum (h * c)^2 + sum y  -> gradients w.r.t. W, b (and x through y)
+    c = torch.randn(B, K, generator=gen).to(DEV)
+    (h,) = torch.autograd.grad(f32(), x, gy, create_graph=True)
+    (hd,) = torch.autograd.grad(f64(), xd, gyd, create_graph=True)
+    assert rel_err(h, hd) < 2e-6
+    g2 = torch.autograd.grad((h * c).pow(2).sum() + (f32() * gy).sum(), ins)
+    g2d = torch.autograd.grad((hd * c.double()).pow(2).sum() + (f64() * gyd).sum(), insd)
+    for a, r in zip(g2, g2d):
+        assert rel_err(a, r) < 5e-6
+    # third member's double backward: gradient of a function of dL/dW w.r.t. the upstream gradient and x
+    gyr = gy.clone().requires_grad_(True)
+    gyrd = gyd.clone().requires_grad_(True)
+    (gw,) = torch.autograd.grad(f32(), w, gyr, create_graph=True)
+    (gwd,) = torch.autograd.grad(f64(), wd, gyrd, create_graph=True)
+    g3 = torch.autograd.grad(gw.pow(2).sum(), [gyr, x])
+    g3d = torch.autograd.grad(gwd.pow(2).sum(), [gyrd, xd])
+    for a, r in zip(g3, g3d):
+        assert rel_err(a, r) < 5e-6
+
+
+def test_linear_family_is_bit_reproducible_and_sinks_add_in_place():
+    """Fixed summation order: 200 evaluations of forward / data gradient / weight gradient of the 8192 -> 512 layer give ONE
+    bit pattern each.  Under op.grad_sink() the weight and bias gradients are added into the parameters' .grad by the kernel
+    (nothing returned to autograd), equal to .grad + gradient of the plain path."""
+    from rick_amd import op
+    import importlib
+    L = importlib.import_module('rick_amd.op.linear')      # (the package attribute `linear` is the function)
+    torch.manual_seed(4)
+    B, K, O = 8, 8192, 512
+    x, w, g = torch.randn(B, K, device=DEV), torch.randn(O, K, device=DEV), torch.randn(B, O, device=DEV)
+    first = (L._p1(x, w, None, 0.01, 0.0), L._p2(g, w, 0.01), L._p3(g, x, 0.01)[0])
+    for _ in range(200):
+        again = (L._p1(x, w, None, 0.01, 0.0), L._p2(g, w, 0.01), L._p3(g, x, 0.01)[0])
+        assert all(torch.equal(a, b) for a, b in zip(first, again))
+    wp, bp = torch.nn.Parameter(w.clone()), torch.nn.Parameter(torch.randn(O, device=DEV))
+    xr = x.clone().requires_grad_(True)
+    (op.linear(xr, wp, bp, 0.01, 0.5) * g).sum().backward()
+    gw0, gb0, gx0 = wp.grad.clone(), bp.grad.clone(), xr.grad.clone()
+    base_w, base_b = torch.randn_like(wp), torch.randn_like(bp)
+    wp.grad, bp.grad, xr.grad = base_w.clone(), base_b.clone(), None
+    with op.grad_sink():
+        (op.linear(xr, wp, bp, 0.01, 0.5) * g).sum().backward()
+    assert torch.equal(xr.grad, gx0)
+    assert torch.equal(wp.grad, base_w + gw0) and torch.equal(bp.grad, base_b + gb0)
+
+
+def test_discriminator_final_layers_run_the_linear_family():
+    """EqualLinear with gradients at batch <= 16 (D's final_linear, model_probe_tune.py:699-702) runs op.linear: same logits and
+    gradients as the BLAS route (RICK_NO_OWN_LINEAR) to fp32 rounding, and no GEMM launch from torch in a D forward + backward."""
+    import rick_amd.models as M
+    torch.manual_seed(6)
+    d = M.Discriminator(32).to(DEV)
+    img = torch.randn(4, 3, 32, 32, device=DEV)
+    res = {}
+    for own in (True, False):
+        M._USE_OWN_LINEAR = own
+        try:
+            d.zero_grad(set_to_none=True)
+            with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+                out, _ = d(img)
+                out.square().sum().backward()
+                torch.cuda.synchronize()
+            gemms = [ev.key for ev in prof.key_averages() if 'Cijk' in ev.key or 'rocblas' in ev.key.lower() or 'hipblas' in ev.key.lower()]
+            res[own] = (out.detach().clone(), {n: p.grad.clone() for n, p in d.named_parameters() if 'final_linear' in n}, gemms)
+        finally:
+            M._USE_OWN_LINEAR = True
+    assert not res[True][2], res[True][2]
+    assert res[False][2]                                        # (the switch does switch)
+    assert rel_err(res[True][0], res[False][0]) < 1e-5
+    for k in res[True][1]:
+        assert rel_err(res[True][1][k], res[False][1][k]) < 1e-5, k
 
 
 def test_mapping_network_fast_path_equals_autograd_path():

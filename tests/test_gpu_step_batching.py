@@ -351,3 +351,45 @@ def test_latent_pool_follows_reloaded_mapping_network():
         z = torch.randn(tr.LATENT_POOL * 2 * B, 512, device='cuda')
         want = g.style(z).view(tr.LATENT_POOL, 2 * B, -1)
     assert torch.equal(tr._lat_pool['d']['w'], want)
+
+
+def test_back_to_back_captures_do_not_share_running_maxima():
+    """running maxima / image headers come from an arena of zero-filled words; a graph must contain the fill
+    of the words ITS launches accumulate into.  Steps captured back to back (prepare_graphs, the
+    loop below) used to share one arena block, zero-filled by the first graph only, so a G replay that did not follow a D replay kept
+    the previous replay's maxima (looser exponents: results no longer equal to eager).  Here: two G replays in a row, the first
+    on 4x larger latents; the second must equal an eager G step on its own latents bit for bit."""
+    from rick_amd.op import split as sp
+    from rick_amd.synth import synth_reals, synth_tensor
+    from rick_amd.train import RickTrainer, TrainConfig
+    from tests.test_gpu_models import build
+    size, B = 32, 2
+    real = synth_reals(B, size=size, seed=5).cuda()
+
+    def trainer():
+        g, d = build(size)
+        tr = RickTrainer(TrainConfig(size=size, batch=B, warmup_iter=0), g, d, *build(size))
+        tr.g_optim.lr = tr.d_optim.lr = 0.0            # parameters stay put: repeated steps are comparable
+        tr.enable_graphs(True)
+        lat = torch.zeros(B, g.n_latent, 512, device='cuda')
+        tr._graph_latents = lambda key, batch: lat[:batch]
+        return tr, lat
+    small = synth_tensor('arena/lat', (B, 8, 512)).cuda()              # n_latent = 8 at 32 px
+    a, lat_a = trainer()
+    noises = [synth_tensor(f'arena/noise/{i}', tuple(getattr(a.g.noises, f'noise_{i}').shape)).cuda() for i in range(a.g.num_layers)]
+    lat_a.copy_(small)
+    for _ in range(3):                                  # third round: the D capture and the G capture are back to back
+        a.d_step(real, None, g_noise=noises, graph=True)
+        a.g_step(None, g_noise=noises, graph=True)
+    assert all('graphs' in a._gs[k] for k in ('d', 'g'))
+    lat_a.copy_(small * 4)
+    a.g_step(None, g_noise=noises, graph=True)          # replay on large latents
+    lat_a.copy_(small)
+    a.g_step(None, g_noise=noises, graph=True)          # replay again, no D replay in between
+    got = a.g_flat.grad.clone()
+    b, lat_b = trainer()
+    lat_b.copy_(small)
+    b.g_step(None, g_noise=noises, graph=True)          # first call of a step type: eager
+    assert 'graphs' not in b._gs['g']
+    assert torch.equal(got, b.g_flat.grad)
+    assert sp.capture_id() == 0

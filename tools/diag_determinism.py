@@ -17,34 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-class _LocalDP:
-    """Single-process stand-in for DataParallelGrads in eager mode: same trainer code path (no gradient sink)."""
-
-    hooks_enabled = True
-    active = True
-    world = 1
-
-    def __init__(self, mode):
-        self.mode = mode
-        self.fired = 0
-
-    def attach(self, *flats):
-        import torch
-        for flat in flats:
-            for i in flat.opt_idx:
-                def hook(p, self=self):
-                    self.fired += 1
-                    if self.mode == 'sync':
-                        torch.cuda.synchronize()
-                    elif self.mode == 'copy':
-                        p.grad.cpu()
-                flat.params[i].register_post_accumulate_grad_hook(hook)
-
-    def prepare(self, flat):
-        pass
-
-    def all_reduce(self, flat):
-        pass
+def _LocalDP(mode):
+    """Single-process stand-in for DataParallelGrads in eager mode (tests/test_gpu_determinism.py)."""
+    from tests.test_gpu_determinism import LocalDP
+    dp = LocalDP()
+    dp.mode = mode
+    return dp
 
 
 def worker(mode, out):
