@@ -415,9 +415,9 @@ static int thin_bwdx_launch(const float *t, const float *W, int64_t w_bstride, f
     if (!x || !W || !t || N <= 0 || P <= 0 || C <= 0 || C % 4 || J < 1 || J > THIN_MAXJ || N > 65535) return RICK_EINVAL;
     const int C4 = C / 4;
     if (C4 <= 256 && 256 % C4 == 0) {
-        // ~2 048 blocks (8 per CU) with at least TB_UNR steps each
+        // ~1 024 blocks (4 per CU) with at least TB_UNR steps each
         const int rows = 256 / C4;
-        int64_t ppb = cdiv64(P * N, 2048);
+        int64_t ppb = cdiv64(P * N, 1024);      // (512 / 1024 / 2048 / 4096 blocks measured: 8.4 / 8.2 / 9.3 / 9.4 us at 512 ch @64^2)
         if (ppb < (int64_t)TB_UNR * rows) ppb = (int64_t)TB_UNR * rows;
         ppb = cdiv64(ppb, rows) * rows;
         const unsigned nbx = (unsigned)cdiv64(P, ppb);
@@ -529,20 +529,33 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float *__restrict
     }
 }
 
+// out[i] = sum_b partials[b][i]: 32 outputs x 8 groups per block, group g adds blocks g, g + 8, ... (four loads in flight), the
+// eight group sums are added in index order — a fixed order, and 48-192 blocks instead of the 6-24 single-thread-per-output
+// blocks of round 4 (21 us for 1 536 outputs x 256 partials: longer than the 134 MB pass that produced them).
 __global__ __launch_bounds__(256) void thin_partial_sum_kernel(const float *__restrict__ partials, float *__restrict__ out,
                                                                int nb, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // four loads in flight (the stage is latency-bound); fixed order
-    int b = 0;
-    for (; b + 3 < nb; b += 4) {
-        s0 += partials[(int64_t)b * n + i];
-        s1 += partials[(int64_t)(b + 1) * n + i];
-        s2 += partials[(int64_t)(b + 2) * n + i];
-        s3 += partials[(int64_t)(b + 3) * n + i];
+    __shared__ float red[8][32];
+    const int lo = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + lo;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int b = grp;
+        for (; b + 24 < nb; b += 32) {
+            s0 += partials[(int64_t)b * n + i];
+            s1 += partials[(int64_t)(b + 8) * n + i];
+            s2 += partials[(int64_t)(b + 16) * n + i];
+            s3 += partials[(int64_t)(b + 24) * n + i];
+        }
+        for (; b < nb; b += 8) s0 += partials[(int64_t)b * n + i];
     }
-    for (; b < nb; b++) s0 += partials[(int64_t)b * n + i];
-    out[i] = (s0 + s1) + (s2 + s3);
+    red[grp][lo] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        float s = red[0][lo];
+#pragma unroll
+        for (int g = 1; g < 8; g++) s += red[g][lo];
+        out[i] = s;
+    }
 }
 
 extern "C" int rick_thin_wgrad_f32(const float *t, const float *x, float *G, int N, int64_t P, int C, int J,
@@ -555,6 +568,6 @@ extern "C" int rick_thin_wgrad_f32(const float *t, const float *x, float *G, int
     if (lds > 64 * 1024) return RICK_EINVAL;
     hipLaunchKernelGGL(thin_wgrad_kernel, dim3(nb, N), dim3(256), lds, st, t, x, partials, P, C, J);
     const int64_t n = (int64_t)N * J * C;
-    hipLaunchKernelGGL(thin_partial_sum_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, partials, G, nb, n);
+    hipLaunchKernelGGL(thin_partial_sum_kernel, dim3((unsigned)cdiv64(n, 32)), dim3(256), 0, st, partials, G, nb, n);
     RICK_LAUNCH_STATUS();
 }

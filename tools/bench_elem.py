@@ -1,5 +1,5 @@
 """Micro-benchmark of the HBM-bound kernels at the layer shapes of the 256-px networks (GPU).
-Prints algorithmic GB/s (bytes that must move once / time) per op and shape."""
+Prints device time and algorithmic GB/s (bytes that must move once / device time) per op and shape."""
 import os
 import sys
 
@@ -12,16 +12,18 @@ from rick_amd.op.upfirdn2d import upfirdn2d                # noqa: E402
 
 
 def timeit(fn, reps=20, warm=3):
+    """GPU time of one call = the summed DEVICE durations of the kernels it launches (torch.profiler), averaged over `reps`.
+    (Round 4 timed a back-to-back loop with two events: every op below ~30 MB then read the HOST's 12-27 us per Python call,
+    and a first-touch allocation inside the loop produced the 2 057 us `act_bwd` row of r04_hbm_microbench.txt.)"""
+    from torch.profiler import ProfilerActivity, profile
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e-3
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+    return sum(ev.device_time_total for ev in prof.key_averages()) / reps * 1e-6
 
 
 B = int(os.environ.get('B', 4))
