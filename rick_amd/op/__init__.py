@@ -6,7 +6,7 @@ import threading
 from .fused_act import FusedLeakyReLU, FusedLeakyReLU_kml, deferred_sums, fused_leaky_relu, fused_noise_bias_act
 from .upfirdn2d import upfirdn2d, upfirdn2d_noise_bias_act
 from .conv import (bump_weights_epoch, conv2d, conv2d_bias_act, conv_transpose2d, get_precision, grad_sink,
-                   no_param_grads, register_pack_group, set_precision)
+                   no_param_grads, register_pack_group, set_precision, wgrad_overlap)
 from .misc import add_scale, chan_scale, equal_linear, hw_dot, minibatch_stddev, thin_bwdx, thin_fwd, torgb, torgb_fork
 from . import linear as _linear      # (module first: the next line rebinds the package attribute `linear` to the function)
 from .linear import linear
@@ -36,6 +36,6 @@ def second_order(enabled=True):
 
 
 __all__ = ['FusedLeakyReLU', 'FusedLeakyReLU_kml', 'fused_leaky_relu', 'fused_noise_bias_act', 'upfirdn2d', 'upfirdn2d_noise_bias_act',
-           'conv2d', 'conv2d_bias_act', 'conv_transpose2d', 'set_precision', 'get_precision', 'bump_weights_epoch', 'register_pack_group', 'grad_sink', 'deferred_sums', 'no_param_grads',
+           'conv2d', 'conv2d_bias_act', 'conv_transpose2d', 'set_precision', 'get_precision', 'bump_weights_epoch', 'register_pack_group', 'grad_sink', 'deferred_sums', 'no_param_grads', 'wgrad_overlap',
            'add_scale', 'chan_scale', 'equal_linear', 'hw_dot', 'minibatch_stddev', 'thin_fwd', 'thin_bwdx', 'torgb', 'torgb_fork',
            'second_order', 'second_order_enabled', 'modconv', 'linear']

@@ -18,6 +18,7 @@ two dims are jointly contiguous.  `set_precision()` selects fp16x3 (default: fp1
 per-block power-of-two operand exponent, 2^-22 per product, fp32 accumulate) or plain fp16 MFMA.
 """
 import ctypes
+import os
 import threading
 
 import numpy as np
@@ -521,8 +522,70 @@ def _sink_target(key, shape, enabled):
     return p.grad.view(shape)
 
 
+# ---- weight gradients off the critical path -----------------------------------------------------------------------------
+# A layer's data gradient feeds the next layer's backward; its weight gradient feeds nothing until the optimiser.  Inside
+# `wgrad_overlap()` every SUNK weight-gradient launch (op.grad_sink(): the result is added into the parameter's .grad, no tensor
+# goes back to autograd) is issued on a second HIP stream: the hardware then fills the CUs a data-gradient launch leaves idle —
+# the tail of its last round of blocks, the 4^2...32^2 layers whose grids cover a quarter of the chip — with weight-gradient
+# blocks, in eager issue and (fork / join captured) in the replayed step graphs.  Values cannot change: every launch reads and
+# writes what it did before, each .grad is written by ONE stream between fork and join (the DemodBank's accumulate joins
+# first), and the kernels sum in a fixed order.
+# MEASURED (round 5, tools/ab_overlap.sh, two alternating same-box pairs): 158.3 images/s with the side stream against 165.3
+# without (D step 10.70 vs 10.38 ms, G step 10.21 vs 9.92): the MFMA launches already fill the chip (a weight-gradient wave
+# takes a whole SIMD's 512 registers, so its blocks only land on CUs that have drained), two co-running kernels evict each
+# other's L2 lines, and the replayed graphs gain fork / join nodes.  OFF by default (RICK_WGRAD_OVERLAP=1 switches it on);
+# tests/test_gpu_step_batching.py keeps the value-equality test.
+_side = {'on': False, 'stream': None, 'pending': False}
+_OVERLAP_OFF = not os.environ.get('RICK_WGRAD_OVERLAP')
+
+
+class wgrad_overlap:
+    """with op.grad_sink(), op.wgrad_overlap(): loss.backward()   — joins the side stream on exit."""
+
+    def __enter__(self):
+        self.prev = _side['on']
+        if not _OVERLAP_OFF and torch.cuda.is_available():
+            if _side['stream'] is None or _side['stream'].device.index != torch.cuda.current_device():
+                if torch.cuda.is_current_stream_capturing():
+                    return self               # the side stream must exist before a capture (run the step eagerly once)
+                _side['stream'] = torch.cuda.Stream()
+            _side['on'] = True
+        return self
+
+    def __exit__(self, *exc):
+        join_side()
+        _side['on'] = self.prev
+
+
+def join_side():
+    """Make the current stream wait for the weight gradients issued on the side stream so far."""
+    if _side['pending']:
+        torch.cuda.current_stream().wait_stream(_side['stream'])
+        _side['pending'] = False
+
+
 def _wgrad_launch(a, b, kh, kw, s, p, alpha=1.0, ascale=None, bscale=None, out=None, transposed=False, a_split=None,
                   b_split=None):
+    """_wgrad_launch_now — on the side stream when the result is sunk and `wgrad_overlap()` is open (not under bench.py's
+    launch profiler: its per-kernel event timings want the kernels one at a time)."""
+    if out is None or not _side['on'] or _prof is not None:
+        return _wgrad_launch_now(a, b, kh, kw, s, p, alpha, ascale, bscale, out, transposed, a_split, b_split)
+    side = _side['stream']
+    side.wait_stream(torch.cuda.current_stream())          # the operands' producers (and the zeroing of .grad) come first
+    with torch.cuda.stream(side):
+        r = _wgrad_launch_now(a, b, kh, kw, s, p, alpha, ascale, bscale, out, transposed, a_split, b_split)
+    # autograd frees the operands as soon as the node returns: the allocator must not hand their memory to a main-stream
+    # launch before the side stream is done with it
+    for t in (a, b, ascale, bscale, getattr(a_split, 'data', None), getattr(a_split, 'hdr', None),
+              getattr(b_split, 'data', None), getattr(b_split, 'hdr', None)):
+        if t is not None:
+            t.record_stream(side)
+    _side['pending'] = True
+    return r
+
+
+def _wgrad_launch_now(a, b, kh, kw, s, p, alpha=1.0, ascale=None, bscale=None, out=None, transposed=False, a_split=None,
+                      b_split=None):
     """gw[o,i,ky,kx] = alpha * sum a[n,o,pos] b[n,i,pos*s + k - p]  -> contiguous [O, I, kh, kw].
     `out`: ADD the result into this contiguous tensor instead ([O, I, kh, kw], or [I, O, kh, kw] when `transposed` — the
     parameter layout of a transposed convolution's weight gradient)."""

@@ -153,6 +153,9 @@ class _DemodFused(Function):
                   'rick_demod_bwd_s_f32')
         if ctx.needs_input_grad[0]:
             sink = _sink_target(ctx.key, w.shape, ctx.sink)      # op.grad_sink(): add straight into the parameter's .grad
+            if sink is not None:
+                from .conv import join_side
+                join_side()      # (the layer's weight gradient may be accumulating into the same .grad on the side stream)
             gw = torch.empty_like(w) if sink is None else None
             check(lib.rick_demod_bwd_w_f32(ptr(w), ptr(s), ptr(d), ptr(gd), ptr(sink if sink is not None else gw), B, I, O,
                                            kh * kw, ctx.wscale, int(sink is not None), stream_ptr()), 'rick_demod_bwd_w_f32')
@@ -743,6 +746,8 @@ class _DemodBankFn(Function):
             else:
                 sinks = None
             if sinks is not None:
+                from .conv import join_side
+                join_side()      # the layers' own weight gradients (side stream, op.wgrad_overlap) write the same .grad buffers
                 check(lib.rick_demod_bwd_w_multi_f32(s_base, ptr(d_flat), ptr(gd_flat), ptr(bank.table(B, dev, sink=True)), L,
                                                      bank.total_wsq, B, stream_ptr()), 'rick_demod_bwd_w_multi_f32')
             else:

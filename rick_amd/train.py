@@ -695,7 +695,9 @@ class RickTrainer:
                 fake_pred, real_pred = pred.chunk(2, 0)
                 d_loss = d_logistic_loss(real_pred, fake_pred)
                 self._zero_grad(self.d_flat)
-                with op.deferred_sums():        # bias / noise-strength sums: one second-stage launch for the whole pass
+                # bias / noise-strength sums: one second-stage launch for the whole pass; (RICK_WGRAD_OVERLAP=1: sunk weight
+                # gradients on a second stream next to the data-gradient chain — measured slower, off by default, op/conv.py)
+                with op.deferred_sums(), op.wgrad_overlap():
                     d_loss.backward()
             self.losses.update(d=d_loss.detach(), real_score=real_pred.detach().mean(), fake_score=fake_pred.detach().mean())
         self._run(key, fb, self.d_flat, self.d_optim, pre=(lambda: self._draw_inject(key)) if graph else None)
@@ -734,7 +736,7 @@ class RickTrainer:
                 fake_pred, _ = self.d(box.pop('fake'))
                 g_loss = g_nonsaturating_loss(fake_pred)
                 self._zero_grad(self.g_flat)
-                with op.deferred_sums():        # bias / noise-strength sums: one second-stage launch for the whole pass
+                with op.deferred_sums(), op.wgrad_overlap():
                     g_loss.backward()
             self.losses['g'] = g_loss.detach()
         self._run(key, fb, self.g_flat, self.g_optim, pre=(lambda: self._draw_inject(key)) if graph else None, fb_head=head)

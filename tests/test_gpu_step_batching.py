@@ -393,3 +393,39 @@ def test_back_to_back_captures_do_not_share_running_maxima():
     assert 'graphs' not in b._gs['g']
     assert torch.equal(got, b.g_flat.grad)
     assert sp.capture_id() == 0
+
+
+@pytest.mark.parametrize('graphs', [False, True], ids=['eager', 'graphs'])
+def test_wgrad_overlap_leaves_every_value_unchanged(graphs):
+    """op.wgrad_overlap(): the sunk weight-gradient launches of a D / G step run on a second stream next to the data-gradient
+    chain (fork / join captured into the step graphs).  Same launches on the same data: parameters, moments and losses after
+    D, G, D, G steps are bit-identical to the one-stream run, eagerly and replayed."""
+    from rick_amd.op import conv as cv
+    from rick_amd.synth import synth_reals
+    from rick_amd.train import RickTrainer, TrainConfig
+    from tests.test_gpu_models import build
+    size, B = 64, 4
+    real = synth_reals(B, size=size, seed=5).cuda()
+    out = []
+    for off in (True, False):
+        cv._OVERLAP_OFF = off
+        try:
+            import random
+            random.seed(2)
+            torch.manual_seed(2)
+            g, d = build(size)
+            tr = RickTrainer(TrainConfig(size=size, batch=B, warmup_iter=0), g, d, *build(size))
+            tr.enable_graphs(graphs)
+            launched = cv._side['pending']
+            for k in range(4 if graphs else 2):
+                tr.d_step(real, None if graphs else [torch.randn(B, 512, device='cuda')], graph=graphs)
+                tr.g_step(None if graphs else [torch.randn(B, 512, device='cuda')], graph=graphs)
+            torch.cuda.synchronize()
+            assert not cv._side['pending'] and not launched          # every fork was joined
+            out.append([t.clone() for t in (tr.g_flat.flat, tr.d_flat.flat, tr.g_optim.m, tr.d_optim.v, tr.losses['d'], tr.losses['g'])])
+        finally:
+            cv._OVERLAP_OFF = True
+    assert cv._side['stream'] is not None                            # the overlapped run did use the side stream
+    cv._OVERLAP_OFF = True                                           # (the default: measured slower, see op/conv.py)
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
