@@ -130,18 +130,27 @@ extern "C" int rick_conv_pack_weight(const float *w, int64_t s_co, int64_t s_ci,
 // descriptor d with blk_begin[d] <= b < blk_begin[d+1]; a thread owns one (co, ci) of a 128 x 32 tile and
 // walks the tap slices (contiguous in memory for [O, I, kh, kw] parameters).
 #define PK_NS_MAX 16      // tap slices staged through LDS (RICK_MAX_TAPS); more: the per-thread tap walk
-#define PK_GRP 4          // descriptor blocks (8 rows x 32 k each, 16 per 128 x 32 tile) served by one launched block
-#define PK_GRP_NS 9       // ... when the layer has at most this many tap slices (36 KB of LDS)
-
-// One descriptor block: 8 rows x 32 k x nslices (see the comments inside).  `sw`: >= 256 * nslices floats.
-__device__ __forceinline__ void pack_block8(const rick_pack_desc &ds, int blk, int nchunks, float pscale, int split, float *sw,
-                                            float &satm) {
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const rick_pack_desc *__restrict__ descs, int n, int split) {
+    __shared__ float sw[256 * PK_NS_MAX];
+    int d = 0;
+    for (int i = 1; i < n; i++)
+        if ((int)blockIdx.x >= descs[i].blk_begin) d = i;
+    const rick_pack_desc ds = descs[d];
+    cv_fp16_saturate();
+    const int nchunks = (ds.Ci + CV_CK - 1) / CV_CK;
+    const float pscale =
+        reinterpret_cast<const float *>((const unsigned char *)ds.packed + packed_tile_bytes(ds.Co, ds.Ci, ds.nslices))[1];
+    const int blk = (int)blockIdx.x - ds.blk_begin;      // 16 blocks per 128 x 32 tile: 8 rows x 32 k each
+    float satm = 0.f;
     if (ds.nslices <= PK_NS_MAX) {
         // A block's 8 rows x 32 k x nslices values are read in MEMORY order (coalesced runs of 32 * nslices floats for a
         // [O, I, kh, kw] parameter, 8 * nslices for its transposed view) into LDS as [r][k][slice]; then one thread per
         // (slice, row, 16-byte granule) converts 8 consecutive k and writes the granule's hi and lo halves as two 16-byte
         // stores.  (One thread per (row, k) walking the slices read 4 bytes of every 36 per lane and wrote 2-byte pieces:
         // 203 us per network.)  Same value per element — w * scale * 2^e, same conversion — so the image is byte-identical.
+        // (Round 5: four of these blocks per launched block — 32 rows staged at once, 4 x longer runs, a quarter of the blocks —
+        // measured SLOWER, same box: 171 / 158 us against 146 / 137 us for the generator / discriminator; the launch lives on
+        // having many small blocks in flight.  Not kept.)
         const int ns = ds.nslices, tile = blk >> 4, rg = blk & 15;
         const int chunk = tile % nchunks, cot = tile / nchunks;
         const int co0 = cot * CV_BM + rg * 8, ci0 = chunk * CV_CK;
@@ -173,6 +182,7 @@ __device__ __forceinline__ void pack_block8(const rick_pack_desc &ds, int blk, i
             *reinterpret_cast<uint4 *>(dst + CV_WTILE_BYTES) = make_uint4(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16),
                                                                           l[4] | ((unsigned)l[5] << 16), l[6] | ((unsigned)l[7] << 16));
         }
+        cv_sat_report(satm);
         return;
     }
     const int i = blk * 256 + threadIdx.x;   // over (cotile, chunk, r, k)
@@ -192,64 +202,6 @@ __device__ __forceinline__ void pack_block8(const rick_pack_desc &ds, int blk, i
         dst[(int64_t)sl * (CV_WSTEP_BYTES / 2)] = h;
         dst[(int64_t)sl * (CV_WSTEP_BYTES / 2) + CV_WTILE_BYTES / 2] = l;
     }
-}
-
-// A launched block serves PK_GRP consecutive descriptor blocks (they lie in one 128 x 32 tile of one layer: 16 per tile).  Layers
-// with <= 9 taps stage all 32 rows x 32 k x taps at once: memory runs of 4 x the length (288 contiguous floats even for the
-// transposed view), 2 KB contiguous per tap tile on the way out instead of 512 B, a quarter of the blocks (round 4: 21 K blocks
-// of 9 KB each for the discriminator, 207 us per network on average = 1.3 TB/s).  Same element -> same bytes.
-__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const rick_pack_desc *__restrict__ descs, int n, int split) {
-    __shared__ float sw[256 * PK_GRP * PK_GRP_NS > 256 * PK_NS_MAX ? 256 * PK_GRP * PK_GRP_NS : 256 * PK_NS_MAX];
-    const int b0 = (int)blockIdx.x * PK_GRP;
-    int d = 0;
-    for (int i = 1; i < n; i++)
-        if (b0 >= descs[i].blk_begin) d = i;
-    const rick_pack_desc ds = descs[d];
-    cv_fp16_saturate();
-    const int nchunks = (ds.Ci + CV_CK - 1) / CV_CK;
-    const float pscale =
-        reinterpret_cast<const float *>((const unsigned char *)ds.packed + packed_tile_bytes(ds.Co, ds.Ci, ds.nslices))[1];
-    const int blk0 = b0 - ds.blk_begin;      // 16 descriptor blocks per 128 x 32 tile: 8 rows x 32 k each
-    float satm = 0.f;
-    if (ds.nslices <= PK_GRP_NS) {
-        constexpr int RB = 8 * PK_GRP;       // rows of this launched block
-        const int ns = ds.nslices, tile = blk0 >> 4, rg = blk0 & 15;
-        const int chunk = tile % nchunks, cot = tile / nchunks;
-        const int co0 = cot * CV_BM + rg * 8, ci0 = chunk * CV_CK;
-        const bool k_fast = llabs(ds.s_ci) <= llabs(ds.s_co);
-        for (int e = threadIdx.x; e < RB * 32 * ns; e += 256) {
-            const int sl = e % ns, q = e / ns;
-            const int r = k_fast ? q >> 5 : q & (RB - 1), k = k_fast ? q & 31 : q / RB;
-            const int co = co0 + r, ci = ci0 + k;
-            float v = 0.f;
-            if (co < ds.Co && ci < ds.Ci) v = ds.w[co * ds.s_co + ci * ds.s_ci + sl * ds.s_t] * ds.scale * pscale;
-            sw[(r * 32 + k) * ns + sl] = v;
-        }
-        __syncthreads();
-        unsigned char *base = (unsigned char *)ds.packed + (int64_t)tile * ns * CV_WSTEP_BYTES;
-        for (int it = threadIdx.x; it < RB * 4 * ns; it += 256) {
-            const int sl = it / (RB * 4), r = (it >> 2) & (RB - 1), gq = it & 3;
-            const float *src = sw + (r * 32 + gq * 8) * ns + sl;
-            unsigned short h[8], l[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; jj++) {
-                const float v = src[jj * ns];
-                satm = fmaxf(satm, fabsf(v));
-                split1(v, h[jj], l[jj], split);
-            }
-            const int row = rg * 8 + r;
-            unsigned char *dst = base + (int64_t)sl * CV_WSTEP_BYTES + row * 64 + cv_swz(gq, row) * 16;
-            *reinterpret_cast<uint4 *>(dst) = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16),
-                                                         h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
-            *reinterpret_cast<uint4 *>(dst + CV_WTILE_BYTES) = make_uint4(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16),
-                                                                          l[4] | ((unsigned)l[5] << 16), l[6] | ((unsigned)l[7] << 16));
-        }
-    } else {
-        for (int sub = 0; sub < PK_GRP; sub++) {
-            if (sub) __syncthreads();
-            pack_block8(ds, blk0 + sub, nchunks, pscale, split, sw, satm);
-        }
-    }
     cv_sat_report(satm);
 }
 
@@ -259,8 +211,7 @@ extern "C" int rick_conv_pack_weights_multi(const rick_pack_desc *descs_device, 
                                             void *stream) {
     if (!descs_device || n < 1 || total_blocks < 1 || (split != 1 && split != 2)) return RICK_EINVAL;
     hipLaunchKernelGGL(pack_exponent_multi_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, descs_device);
-    if (total_blocks % PK_GRP) return RICK_EINVAL;      // (rick_conv_pack_blocks: 16 per tile)
-    hipLaunchKernelGGL(pack_weight_multi_kernel, dim3((unsigned)(total_blocks / PK_GRP)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(pack_weight_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
                        descs_device, n, split);
     RICK_LAUNCH_STATUS();
 }
