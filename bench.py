@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md
+HBM_LARGE_BYTES = 16 << 20
 
 
 def cpu_baseline(size=256, batch=2, timed=2):
@@ -323,10 +324,14 @@ def main():
         for kind, flops, e0, e1, tag, abytes in prof:
             dt = e0.elapsed_time(e1) * 1e-3
             if kind == 'hbm':           # HBM-bound launches (op.conv.hbm_launch): tag = kernel family, abytes = bytes to move once
-                h = hbm.setdefault(tag, [0.0, 0.0, 0])
+                h = hbm.setdefault(tag, [0.0, 0.0, 0, 0.0, 0.0, 0])
                 h[0] += abytes
                 h[1] += dt
                 h[2] += 1
+                if abytes >= HBM_LARGE_BYTES:       # launches long enough that the two bracketing events do not weigh
+                    h[3] += abytes
+                    h[4] += dt
+                    h[5] += 1
                 continue
             a = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
             a[0] += flops
@@ -397,8 +402,12 @@ def main():
             for (name, form), (fl, dt, n) in sorted(kv.items(), key=lambda kv_: -kv_[1][1])]
         out['hbm_kernels'] = [
             {'kernel': name, 'achieved': by / dt / 1e9, 'unit': 'GB/s', 'peak': 8000.0, 'frac': by / dt / 8e12, 'launches': n,
-             'ms_per_step': 1e3 * dt / 16, 'avg_launch_us': 1e6 * dt / n}
-            for name, (by, dt, n) in sorted(hbm.items(), key=lambda kv_: -kv_[1][1])]
+             'ms_per_step': 1e3 * dt / 16, 'avg_launch_us': 1e6 * dt / n,
+             # the same over the launches that move >= 16 MB: an event-bracketed 4 us launch reads 8-10 us (the < 16 MB launches
+             # of these families take 3-11 us on the device, profiles/r05_hbm_microbench.txt, and are latency-, not HBM-bound)
+             'large': ({'achieved': lby / ldt / 1e9, 'frac': lby / ldt / 8e12, 'launches': ln, 'ms_per_step': 1e3 * ldt / 16,
+                        'min_bytes': HBM_LARGE_BYTES} if ln else None)}
+            for name, (by, dt, n, lby, ldt, ln) in sorted(hbm.items(), key=lambda kv_: -kv_[1][1])]
         conv_s = sum(a[1] for a in agg.values()) / 16
         out['roofline']['conv_family_ms_per_step'] = 1e3 * conv_s
     if rank == 0 and not args.no_extras:
