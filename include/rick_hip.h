@@ -83,6 +83,16 @@ int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx, float *gb
                           const float *noise, int64_t rows, int C, int64_t rows_per_img,
                           int64_t noise_nb, int64_t noise_hw, float alpha, float scale,
                           float *partials, int accumulate, void *stream);
+/* ... and, from the same pass, the demodulation gradient of the modulated convolution the activation follows
+ * (model_probe_tune.py:246-252: y = act(d * conv(..) + noise + bias)):  gd[n, c] = (sum over the image's rows of gx * t) / divisor[n, c],
+ * t = the convolution's output reconstructed from `ref` (ref / scale for ref > 0, ref / (scale * alpha) otherwise, minus
+ * noise_w * noise and bias).  Needs rick_bias_act_bwd_dot_ok(): C % 4 == 0 and blocks that never straddle an image.
+ * dpartials: rick_bias_act_bwd_blocks() * C floats.  (round 5: replaces a second read of gx and ref, rick_hw_dot_act_f32) */
+int rick_bias_act_bwd_dot_ok(int64_t rows, int C, int64_t rows_per_img);
+int rick_bias_act_bwd_dot_f32(const float *g, const float *ref, float *gx, float *gb, float *gnw, const float *noise,
+                              int64_t rows, int C, int64_t rows_per_img, int64_t noise_nb, int64_t noise_hw, float alpha,
+                              float scale, float *partials, int accumulate, const float *bias, const float *noise_w,
+                              const float *divisor, float *gd, float *dpartials, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Convolution family (replaces the F.conv2d / F.conv_transpose2d calls of

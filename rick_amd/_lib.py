@@ -67,6 +67,9 @@ SIGNATURES = {
     'rick_bias_act_bwd_blocks': (c_int, [c_i64, c_int]),
     'rick_bias_act_bwd_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_i64, c_i64, c_i64,
                                       c_f, c_f, c_fp, c_int, c_fp]),
+    'rick_bias_act_bwd_dot_ok': (c_int, [c_i64, c_int, c_i64]),
+    'rick_bias_act_bwd_dot_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_i64, c_i64, c_i64,
+                                          c_f, c_f, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     'rick_amax_f32': (c_int, [c_fp, c_i64, c_fp, c_fp]),
     'rick_stream_capture_id': (c_int, [c_fp, ctypes.POINTER(ctypes.c_ulonglong)]),
     'rick_split_pack_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_i64, c_int, c_fp]),

@@ -119,13 +119,27 @@ struct BabSplit {
     const float *bound1;         // NULL, or the amax word that bounds image 1 by itself (then coef1 = 1)
 };
 
+// DOT (the generator's demodulated layers): the same pass also reduces sum_rows adjoint * t per channel and block, t = the
+// convolution's output reconstructed from the saved activation output (y / gain or y / (gain * slope), minus noise and bias) —
+// the demodulation gradient d/d(d) of y = act(d * conv + ...) is sum_hw adjoint * conv_out / d.  Round 4 read the adjoint and y
+// a second time for it (hw_dot_kernel<.., ACT>: 8 B per element, 0.23 ms per G step).  Blocks never straddle an image here (the
+// host checks), so the per-image sums are the column sums of the image's block range (bab_dot_reduce_kernel).
+struct BabDot {
+    float *dpart;                // NULL: off; else [blocks][C]
+    const float *bias;           // [C] or NULL
+    const float *noise_w;        // [1] or NULL (no noise term)
+    float inv_gain, inv_gain_slope;
+};
+
 template <bool VEC4, bool SPL = false>
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restrict__ g, const float *__restrict__ ref,
                                                            float *__restrict__ gx, const float *__restrict__ noise,
                                                            float *__restrict__ partials, int64_t rows, int C,
                                                            int64_t rows_per_img, int64_t noise_nb, int64_t noise_hw,
-                                                           float alpha, float scale, int want_gb, BabSplit sp) {
+                                                           float alpha, float scale, int want_gb, BabSplit sp, BabDot dot) {
     extern __shared__ float lds[];   // [256 * (VEC4 ? 4 : 1)] column partials + 4 for block_sum
+    const bool DOT = VEC4 && !SPL && dot.dpart != nullptr;
+    const float dot_nw = (DOT && dot.noise_w) ? dot.noise_w[0] : 0.f;
     float sc1 = 1.f, sc2 = 1.f, am1 = 0.f, am2 = 0.f;
     if (SPL) {
         const cv_split_hdr h1 = cv_split_header(sp.bound1 ? sp.bound1 : sp.bound, nullptr, sp.coef1);
@@ -171,6 +185,16 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restri
         const int rpb = 256 / cg;                                  // rows handled concurrently
         const int lane_c = threadIdx.x % cg, lane_r = threadIdx.x / cg;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float dacc[4] = {0.f, 0.f, 0.f, 0.f};
+        float4 dbias = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (DOT && dot.bias && lane_r < rpb) dbias = *reinterpret_cast<const float4 *>(dot.bias + (cbase + lane_c) * 4);
+        auto dot_add = [&](const float4 o, const float4 y, float nv) {
+            const float nb_ = dot_nw * nv;
+            dacc[0] += o.x * ((y.x > 0.f ? y.x * dot.inv_gain : y.x * dot.inv_gain_slope) - nb_ - dbias.x);
+            dacc[1] += o.y * ((y.y > 0.f ? y.y * dot.inv_gain : y.y * dot.inv_gain_slope) - nb_ - dbias.y);
+            dacc[2] += o.z * ((y.z > 0.f ? y.z * dot.inv_gain : y.z * dot.inv_gain_slope) - nb_ - dbias.z);
+            dacc[3] += o.w * ((y.w > 0.f ? y.w * dot.inv_gain : y.w * dot.inv_gain_slope) - nb_ - dbias.w);
+        };
         if (lane_r < rpb) {
             // noise index of row r = (image % noise_nb) * noise_hw + pixel, advanced incrementally (no division per row)
             int64_t r = r0 + lane_r;
@@ -215,6 +239,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restri
                         put(op + u * step, r + (int64_t)u * rpb, (cbase + lane_c) * 4, o, gv[u]);
                         acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
                         nsum += (o.x + o.y + o.z + o.w) * nv[u];
+                        if (DOT) dot_add(o, rv[u], nv[u]);
                     }
                     gp += 4 * step;
                     rp += 4 * step;
@@ -244,6 +269,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restri
                     put(op, r, (cbase + lane_c) * 4, o, gv);
                     acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
                     nsum += (o.x + o.y + o.z + o.w) * nv;
+                    if (DOT) dot_add(o, rv, nv);
                 } else {
                     const float o = gp[0] * (rp[0] > 0.f ? 1.f : alpha) * scale;
                     op[0] = o;
@@ -268,8 +294,20 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restri
                 }
             }
         }
+        if (DOT) {
+            __syncthreads();
+            for (int j = 0; j < W; j++) lds[threadIdx.x * W + j] = (lane_r < rpb) ? dacc[j] : 0.f;
+            __syncthreads();
+            if (threadIdx.x < cg) {
+                for (int j = 0; j < W; j++) {
+                    float s = 0.f;
+                    for (int rr = 0; rr < rpb; rr++) s += lds[(rr * cg + threadIdx.x) * W + j];
+                    dot.dpart[(int64_t)blockIdx.x * C + (cbase + threadIdx.x) * W + j] = s;
+                }
+            }
+        }
     }
-    if (noise) {
+    if (noise && partials) {     // (DOT passes the noise for its reconstruction even when no parameter gradient is wanted)
         const float tot = block_sum_256(nsum, lds + 256 * W);
         if (threadIdx.x == 0) pb[C] = tot;
     }
@@ -277,6 +315,35 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float *__restri
         cv_sat_check(am1, sc1);
         cv_sat_check(am2, sc2);
     }
+}
+
+// gd[n, c] = (sum of the image's block partials) / divisor[n, c]: block (8 columns, image), row groups summed by a fixed tree
+__global__ __launch_bounds__(256) void bab_dot_reduce_kernel(const float *__restrict__ dpart, const float *__restrict__ divisor,
+                                                             float *__restrict__ gd, int bpi, int C) {
+    constexpr int CPB = 8, G = 256 / CPB;
+    __shared__ float red[256];
+    const int cl = threadIdx.x % CPB, grp = threadIdx.x / CPB;
+    const int c = blockIdx.x * CPB + cl, n = blockIdx.y;
+    float s = 0.f;
+    if (c < C) {
+        const float *pp = dpart + (int64_t)n * bpi * C + c;
+        float s0 = 0.f, s1 = 0.f;
+        int b = grp;
+        for (; b + G < bpi; b += 2 * G) {
+            s0 += pp[(int64_t)b * C];
+            s1 += pp[(int64_t)(b + G) * C];
+        }
+        for (; b < bpi; b += G) s0 += pp[(int64_t)b * C];
+        s = s0 + s1;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+        if (grp < off) red[threadIdx.x] += red[threadIdx.x + off * CPB];
+        __syncthreads();
+    }
+    if (grp == 0 && c < C) gd[(int64_t)n * C + c] = red[cl] / divisor[(int64_t)n * C + c];
 }
 
 // Destination options of the column-sum stage: columns >= split go to out2 (the noise-strength gradient behind the C bias
@@ -342,7 +409,7 @@ static void launch_colsum(const float *partials, float *out, int nb, int stride,
 static int bias_act_bwd_run(const float *g, const float *ref, float *gx, float *gb, float *gnw,
                             const float *noise, int64_t rows, int C, int64_t rows_per_img,
                             int64_t noise_nb, int64_t noise_hw, float alpha, float scale,
-                            float *partials, int accumulate, void *stream, const BabSplit *sp);
+                            float *partials, int accumulate, void *stream, const BabSplit *sp, const BabDot *dotp = nullptr);
 
 // Several column sums in ONE launch (rick_colsum_multi_f32): the second stages of the bias / noise-strength gradients of a whole
 // backward pass, whose results nobody reads before the optimiser.  Each item is summed exactly as partial_colsum_kernel<8> (or <1>
@@ -424,6 +491,36 @@ extern "C" int rick_bias_act_bwd_f32(const float *g, const float *ref, float *gx
                             accumulate, stream, nullptr);
 }
 
+// 1 when the blocks of rick_bias_act_bwd_f32 never straddle an image of `rows_per_img` rows (needed by the _dot form)
+extern "C" int rick_bias_act_bwd_dot_ok(int64_t rows, int C, int64_t rows_per_img) {
+    if (rows <= 0 || C <= 0 || (C & 3) || rows_per_img <= 0 || rows % rows_per_img) return 0;
+    const int nb = rick_bias_act_bwd_blocks(rows, C);
+    const int64_t rpb = cdiv64(rows, nb);
+    return (rows % nb == 0 && rows_per_img % rpb == 0) ? 1 : 0;
+}
+
+// rick_bias_act_bwd_f32 that ALSO returns the demodulation gradient of the layer the activation belongs to, from the same pass:
+//   gd[n, c] = (sum over the image's rows of gx * t) / divisor[n, c],  t = unact(ref) - noise_w * noise - bias
+// (unact(y) = y / scale for y > 0, y / (scale * alpha) otherwise).  dpartials: rick_bias_act_bwd_blocks() * C floats.
+extern "C" int rick_bias_act_bwd_dot_f32(const float *g, const float *ref, float *gx, float *gb, float *gnw,
+                                         const float *noise, int64_t rows, int C, int64_t rows_per_img,
+                                         int64_t noise_nb, int64_t noise_hw, float alpha, float scale,
+                                         float *partials, int accumulate, const float *bias, const float *noise_w,
+                                         const float *divisor, float *gd, float *dpartials, void *stream) {
+    if (!divisor || !gd || !dpartials || scale == 0.f || alpha == 0.f || !rick_bias_act_bwd_dot_ok(rows, C, rows_per_img)) return RICK_EINVAL;
+    if (noise_w && !noise) return RICK_EINVAL;
+    if (((uintptr_t)g | (uintptr_t)ref | (uintptr_t)gx | (uintptr_t)(bias ? bias : g)) % 16) return RICK_EINVAL;
+    const BabDot dot = {dpartials, bias, noise_w, 1.f / scale, 1.f / (scale * alpha)};
+    const int rc = bias_act_bwd_run(g, ref, gx, gb, gnw, noise, rows, C, rows_per_img, noise_nb, noise_hw, alpha, scale, partials,
+                                    accumulate, stream, nullptr, &dot);
+    if (rc) return rc;
+    const int nb = rick_bias_act_bwd_blocks(rows, C);
+    const int N = (int)(rows / rows_per_img), bpi = nb / N;
+    hipLaunchKernelGGL(bab_dot_reduce_kernel, dim3((unsigned)cdiv(C, 8), (unsigned)N), dim3(256), 0, (hipStream_t)stream, dpartials,
+                       divisor, gd, bpi, C);
+    RICK_LAUNCH_STATUS();
+}
+
 extern "C" int rick_bias_act_bwd_split2_f32(const float *g, const float *ref, void *out1, float *hdr1, void *out2, float *hdr2,
                                             float mul2, const float *amax_g, const float *chan_scale, const float *bound1,
                                             float *out_f32, float *gb, float *gnw, const float *noise,
@@ -463,7 +560,7 @@ extern "C" int rick_bias_act_bwd_split2_f32(const float *g, const float *ref, vo
 static int bias_act_bwd_run(const float *g, const float *ref, float *gx, float *gb, float *gnw,
                             const float *noise, int64_t rows, int C, int64_t rows_per_img,
                             int64_t noise_nb, int64_t noise_hw, float alpha, float scale,
-                            float *partials, int accumulate, void *stream, const BabSplit *sp) {
+                            float *partials, int accumulate, void *stream, const BabSplit *sp, const BabDot *dotp) {
     if (!g || !ref || !gx || rows <= 0 || C <= 0 || ((gb || gnw) && !partials)) return RICK_EINVAL;
     if (gnw && !noise) return RICK_EINVAL;
     if (noise && (rows_per_img <= 0 || noise_nb <= 0 || noise_hw != rows_per_img)) return RICK_EINVAL;
@@ -471,19 +568,22 @@ static int bias_act_bwd_run(const float *g, const float *ref, float *gx, float *
     const int nb = rick_bias_act_bwd_blocks(rows, C);
     const bool vec = (C % 4 == 0) && (((uintptr_t)g | (uintptr_t)ref | (uintptr_t)gx) % 16 == 0);
     const size_t lds = (256 * 4 + 8) * sizeof(float);
-    const float *nz = gnw ? noise : nullptr;
+    const BabDot nodot = {nullptr, nullptr, nullptr, 1.f, 1.f};
+    const BabDot dot = dotp ? *dotp : nodot;
+    if (dot.dpart && (sp || !vec)) return RICK_EINVAL;
+    const float *nz = (gnw || (dot.dpart && dot.noise_w)) ? noise : nullptr;     // (the noise values: for gnw and for the reconstruction)
     const BabSplit none = {nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f, 1.f, nullptr, 1, nullptr, nullptr};
     if (sp && vec)
         hipLaunchKernelGGL((bias_act_bwd_kernel<true, true>), dim3(nb), dim3(256), lds, st, g, ref, gx, nz, partials, rows, C,
-                           rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0, *sp);
+                           rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0, *sp, nodot);
     else if (sp)
         return RICK_EINVAL;
     else if (vec)
         hipLaunchKernelGGL((bias_act_bwd_kernel<true, false>), dim3(nb), dim3(256), lds, st, g, ref, gx, nz, partials, rows, C,
-                           rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0, none);
+                           rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0, none, dot);
     else
         hipLaunchKernelGGL((bias_act_bwd_kernel<false, false>), dim3(nb), dim3(256), lds, st, g, ref, gx, nz, partials, rows, C,
-                           rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0, none);
+                           rows_per_img, noise_nb, noise_hw, alpha, scale, gb ? 1 : 0, none, nodot);
     // one second-stage launch for both parameter gradients; accumulate: gb / gnw are the parameters' .grad (gradient sink)
     if (accumulate & 2) RICK_LAUNCH_STATUS();      // the caller sums the partial rows later (rick_colsum_multi_f32)
     if (gb && gnw) launch_colsum(partials, gb, nb, C + 1, C + 1, 0, st, nullptr, accumulate & 1, gnw, C);

@@ -154,6 +154,43 @@ def defer_act_sums(part, nblk, c, gb, gw):
     return defer_colsum(part, gw, nblk, c + 1, 1, c)
 
 
+def act_adjoint_dot(g, y, noise, slope, scale, want_b, want_w, sink_b, sink_w, bias, noise_w, d):
+    """L* as in _ActAdjoint (first order only, no graph) that ALSO returns, from the same pass, the demodulation gradient of
+    the modulated convolution the activation follows: gd[n, c] = sum_hw gx * conv_out / d[n, c] (conv_out reconstructed from y,
+    rick_bias_act_bwd_dot_f32) — or None when the geometry has no fused form (the caller then takes the two-pass route).
+    -> (gx, gb, gnw, gd)"""
+    if g.ndim != 4 or noise is None and noise_w is not None:
+        return None
+    gr, rows, c, hw = _as_rows(g)
+    if not lib.rick_bias_act_bwd_dot_ok(rows, c, hw):
+        return None
+    yr, _, _, _ = _as_rows(y)
+    gx = torch.empty_like(gr)
+    want_w = want_w and noise is not None
+    nz, nb, nhw = _noise_args(noise, g) if noise is not None else (None, 1, 1)
+    if (want_b and sink_b is None) or (want_w and sink_w is None):
+        sink_b = sink_w = None
+    sunk = (want_b and sink_b is not None) or (want_w and sink_w is not None)
+    gb = (sink_b if sunk else torch.empty(c, device=g.device, dtype=g.dtype)) if want_b else None
+    gw = (sink_w if sunk else torch.empty(1, device=g.device, dtype=g.dtype)) if want_w else None
+    nblk = lib.rick_bias_act_bwd_blocks(rows, c)
+    part = torch.empty(nblk * (c + 1), device=g.device, dtype=g.dtype) if (want_b or want_w) else None
+    later = bool(part is not None and sunk and defer_act_sums(part, nblk, c, gb, gw))
+    dpart = torch.empty(nblk * c, device=g.device, dtype=g.dtype)
+    dc = d.contiguous()
+    gd = torch.empty_like(dc)
+    from .conv import hbm_launch
+    check(hbm_launch('bias_act_bwd', 12 * gr.numel(), lib.rick_bias_act_bwd_dot_f32, ptr(gr), ptr(yr), ptr(gx), ptr(gb), ptr(gw), ptr(nz),
+                     rows, c, hw, nb, nhw, slope, scale, ptr(part), int(sunk) | (2 if later else 0),
+                     ptr(bias.contiguous() if bias is not None else None), ptr(noise_w.contiguous() if noise_w is not None else None),
+                     ptr(dc), ptr(gd), ptr(dpart), stream_ptr()), 'rick_bias_act_bwd_dot_f32')
+    stats['adjoint_dot'] += 1
+    return gx, (None if sunk else gb), (None if sunk else gw), gd
+
+
+stats = {'adjoint_dot': 0}      # launches of the fused adjoint + demodulation-gradient pass (tests)
+
+
 class _ActAdjoint(Function):
     """L*: g -> (gx, gb, gnw) given the saved output y (and noise).  A gradient that is not wanted is None (not a zero
     tensor).  sink_b / sink_w: the parameters' .grad buffers — the reduction's second stage adds the sums into them and

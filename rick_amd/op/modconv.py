@@ -14,6 +14,7 @@ Two implementations with identical values:
                               family, differentiable to any order (used under op.second_order()).
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -35,6 +36,7 @@ from .misc import _chan_scale_raw, _hw_dot_raw, chan_scale
 _USE_SPLIT = bool(__import__('os').environ.get('RICK_GSPLIT'))
 
 
+_FUSE_ADJOINT_DOT = not os.environ.get('RICK_NO_ADJOINT_DOT')      # (A/B switch)
 stats = {'fprop': 0, 'dgrad': 0, 'wgrad': 0, 'produced': 0}     # launches that consumed / produced a split image (tests)
 
 
@@ -277,11 +279,20 @@ class _ModConvFused(Function):
             want_b, want_w = ctx.needs_input_grad[7], ctx.needs_input_grad[9]
             sink_b = param_sink(ctx.tail_params[0], O, ctx.sink and want_b)
             sink_w = param_sink(ctx.tail_params[1], 1, ctx.sink and want_w)
+            gd_fused = None
             if sup is not None and sup['dgrad']:
                 # the adjoint leaves as fp32 (the demodulation gradient reads it) AND as the image of d * adjoint
                 g, gpk, gb, gnw = _adjoint_with_image(g, y, noise, slope, gain, d, want_b, want_w, sink_b, sink_w)
             else:
-                g, gb, gnw = _ActAdjoint.apply(g, y, noise, slope, gain, want_b, want_w, sink_b, sink_w)
+                res = None
+                if _FUSE_ADJOINT_DOT and d is not None and ctx.needs_input_grad[3]:
+                    # ... and the demodulation gradient from the same pass over (g, y) instead of a second one
+                    from .fused_act import act_adjoint_dot
+                    res = act_adjoint_dot(g, y, noise, slope, gain, want_b, want_w, sink_b, sink_w, bias, nw, d)
+                if res is not None:
+                    g, gb, gnw, gd_fused = res
+                else:
+                    g, gb, gnw = _ActAdjoint.apply(g, y, noise, slope, gain, want_b, want_w, sink_b, sink_w)
         elif sup is not None and sup['dgrad']:
             from . import split as sp
             img = sp.taken(g_in, '_rick_split')    # written by the blur's adjoint (op/upfirdn2d.py) with THIS d folded in
@@ -320,7 +331,9 @@ class _ModConvFused(Function):
                 gw = _wgrad_launch(g, x, kh, kw, 1, kh // 2, wscale, ascale=d, bscale=s, out=sink)
         if d is not None and ctx.needs_input_grad[3]:
             # conv_out = d * y'  ->  sum g*y' = (sum g*conv_out) / d,  d > 0
-            if tail:
+            if tail and gd_fused is not None:
+                gd = gd_fused
+            elif tail:
                 gd = _hw_dot_act_raw(g, y, bias, noise, nw, slope, gain, divisor=d)
             else:
                 gd = _hw_dot_raw(g, y, divisor=d)

@@ -825,6 +825,44 @@ def test_discriminator_final_layers_run_the_linear_family():
         assert rel_err(res[True][1][k], res[False][1][k]) < 1e-5, k
 
 
+@pytest.mark.parametrize('n,c,r,sink', [(4, 512, 16, True), (2, 128, 64, False), (4, 512, 4, True), (1, 64, 32, False)])
+def test_activation_adjoint_with_fused_demodulation_gradient(n, c, r, sink):
+    """rick_bias_act_bwd_dot_f32: the activation adjoint of a generator layer and, from the same pass over (g, y), the layer's
+    demodulation gradient gd = sum_hw adjoint * conv_out / d — gx / gb / gnw bit-identical to the plain adjoint
+    (rick_bias_act_bwd_f32), gd equal to the two-pass route (rick_hw_dot_act_f32) to rounding and to the fp64 formula."""
+    from rick_amd.op import fused_act as fa
+    from rick_amd.op.modconv import _hw_dot_act_raw
+    gen = torch.Generator().manual_seed(n * 1000 + c + r)
+    def nhwc(*shape):
+        return torch.randn(*shape, generator=gen).to(DEV).contiguous(memory_format=torch.channels_last)
+    x, g = nhwc(n, c, r, r), nhwc(n, c, r, r)
+    bias = torch.randn(c, generator=gen).to(DEV)
+    noise = torch.randn(1, 1, r, r, generator=gen).to(DEV)
+    nw = torch.full((1,), 0.3, device=DEV)
+    d = (torch.rand(n, c, generator=gen) + 0.5).to(DEV)
+    slope, gain = 0.2, math.sqrt(2)
+    y = fa.fused_noise_bias_act(x, bias, noise, nw, slope, gain)
+    sb, sw = (torch.randn(c, device=DEV), torch.randn(1, device=DEV)) if sink else (None, None)
+    sb0, sw0 = (sb.clone(), sw.clone()) if sink else (None, None)
+    gx0, gb0, gnw0 = fa._ActAdjoint.apply(g, y, noise, slope, gain, True, True, sb0, sw0)
+    gd0 = _hw_dot_act_raw(gx0, y, bias, noise, nw, slope, gain, divisor=d)
+    res = fa.act_adjoint_dot(g, y, noise, slope, gain, True, True, sb, sw, bias, nw, d)
+    assert res is not None
+    gx, gb, gnw, gd = res
+    assert torch.equal(gx, gx0)
+    if sink:
+        assert gb is None and gnw is None and torch.equal(sb, sb0) and torch.equal(sw, sw0)
+    else:
+        assert torch.equal(gb, gb0) and torch.equal(gnw, gnw0)
+    assert rel_err(gd, gd0) < 2e-6
+    # fp64: conv_out = x (the pre-activation without noise and bias), gd = sum_hw gx * x / d
+    ref = (gx0.double() * x.double()).sum((2, 3)) / d.double()
+    assert rel_err(gd, ref) < 1e-5
+    # a frozen layer (conv1 of the generator under the G optimiser): no parameter gradient wanted, gd still is
+    gx2, gb2, gnw2, gd2 = fa.act_adjoint_dot(g, y, noise, slope, gain, False, False, None, None, bias, nw, d)
+    assert gb2 is None and gnw2 is None and torch.equal(gx2, gx0) and torch.equal(gd2, gd)
+
+
 def test_mapping_network_fast_path_equals_autograd_path():
     """Generator.style without autograd (the train steps' latents) runs the one-launch-per-layer kernels; with autograd
     (Fisher sweep, tests differentiating through the mapping network) the rocBLAS + fused-activation path.  Same values."""
