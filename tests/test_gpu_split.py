@@ -377,3 +377,32 @@ def test_fir_adjoint_fused_equals_two_passes():
         acc = torch.ones(c, device=DEV)
         _, none = dblock._fir_adjoint_split(g, flip, (1, 1, 1, 1), y, 0.2, math.sqrt(2), A, True, acc)
         assert none is None and float((acc - 1 - ref_gb).abs().max() / ref_gb.abs().max()) < 1e-5
+
+
+def test_hand_over_attributes_go_stale_after_an_in_place_write():
+    """`_rick_split` / `_rick_amax` / `_rick_bound` describe a tensor AS IT WAS when the producer attached them
+    (op/split.py hand / taken record the version counter and the address).  An in-place write in between — x.mul_(), autograd's
+    in-place accumulation, a hook — makes the consumer ignore the attribute and measure / pack again, instead of reading a stale
+    image or a maximum that is too small; a view_as alias of the unchanged tensor keeps it (op.torgb_fork)."""
+    from rick_amd.op import split as sp
+    x = torch.randn(2, 64, 8, 8, device=DEV).contiguous(memory_format=torch.channels_last)
+    img = sp.split_pack(x)
+    sp.hand(x, '_rick_split', img)
+    sp.hand(x, '_rick_amax', img.bound[0])
+    assert sp.taken(x, '_rick_split') is img
+    alias = x.view_as(x)
+    sp.rehand(x, alias)
+    assert sp.taken(alias, '_rick_split') is img and sp.taken(alias, '_rick_amax') is img.bound[0]
+    x.mul_(4.0)                                   # (alias shares the version counter)
+    assert sp.taken(x, '_rick_split') is None and sp.taken(x, '_rick_amax') is None and sp.taken(alias, '_rick_split') is None
+    # the consumer side: a discriminator block fed such a tensor packs it again — same result as for a tensor without attributes
+    from rick_amd import models
+    torch.manual_seed(4)
+    blk = models.ResBlock(64, 64).to(DEV)
+    x2 = torch.randn(2, 64, 32, 32, device=DEV).contiguous(memory_format=torch.channels_last)
+    ref = blk(x2.clone())
+    stale = sp.split_pack(x2 * 0.25)              # an image of OTHER values ...
+    x3 = x2.clone()
+    sp.hand(x3, '_rick_split', stale)
+    x3.add_(0.0)                                  # ... invalidated by an in-place write
+    assert torch.equal(blk(x3), ref)

@@ -429,3 +429,49 @@ def test_wgrad_overlap_leaves_every_value_unchanged(graphs):
     cv._OVERLAP_OFF = True                                           # (the default: measured slower, see op/conv.py)
     for a, b in zip(*out):
         assert torch.equal(a, b)
+
+
+def test_deferred_sums_with_a_module_applied_twice_and_from_a_second_thread():
+    """the items of one op.deferred_sums() flush run as blocks of ONE launch, each doing a plain read-add-write of its
+    destination — a FusedLeakyReLU applied twice in one backward (D called on real and fake separately, a shared bias) queues the same
+    .grad twice: the first item is launched before the second is queued, so the result equals the immediate path bit for bit.  And the
+    context is one-backward-at-a-time: a second thread that tries to open it while it is open gets a RuntimeError, not another
+    thread's sums."""
+    import threading
+    from rick_amd import op
+    torch.manual_seed(8)
+    act = op.FusedLeakyReLU(64).cuda()
+    with torch.no_grad():
+        act.bias.normal_()
+    xa = torch.randn(2, 64, 16, 16, device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xb = torch.randn(2, 64, 16, 16, device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    res = []
+    for deferred in (False, True):
+        act.bias.grad = torch.zeros_like(act.bias)
+        xa.grad = xb.grad = None
+        with op.grad_sink():
+            loss = (act(xa) * 1.5).sum() + (act(xb) * -0.5).sum()       # the same bias twice
+            if deferred:
+                with op.deferred_sums():
+                    loss.backward()
+            else:
+                loss.backward()
+        res.append((act.bias.grad.clone(), xa.grad.clone(), xb.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert float(res[0][0].abs().max()) > 0
+    err = []
+
+    def other():
+        try:
+            with op.deferred_sums():
+                pass
+        except RuntimeError as e:
+            err.append(e)
+    with op.deferred_sums():
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+    assert len(err) == 1 and 'another thread' in str(err[0])
+    with op.deferred_sums():            # and it is usable again afterwards
+        pass
