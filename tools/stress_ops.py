@@ -43,7 +43,7 @@ def aggressor(seconds):
     print(f'[aggressor] {n} G + D forward / backward passes', flush=True)
 
 
-def victim(reps, only=None):
+def victim(reps, only=None, size=32):
     """-> number of evaluations that differed from the first one (`only`: substrings selecting ops)."""
     import torch
     from rick_amd import op
@@ -51,7 +51,7 @@ def victim(reps, only=None):
     L = importlib.import_module('rick_amd.op.linear')
     torch.manual_seed(0)
     dev = 'cuda'
-    g, d = build(32)
+    g, d = build(size)
     z = torch.randn(2, 512, device=dev)
     with torch.no_grad():
         lat = g.style(z).unsqueeze(1).repeat(1, g.n_latent, 1).contiguous()
@@ -65,7 +65,7 @@ def victim(reps, only=None):
     bias = torch.randn(512, device=dev)
     xl, wl, gl = torch.randn(8, 8192, device=dev), torch.randn(512, 8192, device=dev), torch.randn(8, 512, device=dev)
     w3 = torch.randn(3, 512, device=dev)
-    img = torch.randn(4, 3, 32, 32, device=dev)
+    img = torch.randn(4, 3, size, size, device=dev)
 
     def cat(ts):
         return torch.cat([t.reshape(-1) for t in ts])
@@ -132,13 +132,14 @@ if __name__ == '__main__':
     ap.add_argument('--reps', type=int, default=2000)
     ap.add_argument('--seconds', type=float, default=90)
     ap.add_argument('--role', default='')
+    ap.add_argument('--size', type=int, default=32)
     args = ap.parse_args()
     if args.role == 'aggressor':
         aggressor(args.seconds)
         sys.exit(0)
     if args.role == 'victim':
-        sys.exit(1 if victim(args.reps) else 0)
-    me = [sys.executable, os.path.abspath(__file__), '--reps', str(args.reps), '--seconds', str(args.seconds)]
+        sys.exit(1 if victim(args.reps, size=args.size) else 0)
+    me = [sys.executable, os.path.abspath(__file__), '--reps', str(args.reps), '--seconds', str(args.seconds), '--size', str(args.size)]
     a = subprocess.Popen(me + ['--role', 'aggressor'])                 # (this parent never touches the GPU)
     time.sleep(20)
     v = subprocess.Popen(me + ['--role', 'victim'])
