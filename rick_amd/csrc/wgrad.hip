@@ -619,6 +619,279 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     }
 }
 
+// ==========================================================================================
+// The whole-tile split-image form on EIGHT waves (round 5; verdict round 4 item 4).  Same block (128 co x 9 taps x 32 ci), same
+// LDS images, same fragment reads and the same MFMA order per accumulator as conv_wgrad_kernel<.., PK = 3> — bit-identical
+// partial tiles — but a wave owns 32 co x 16 ci x 9 taps = 72 accumulator registers and half the staging items, so the kernel
+// fits 256 registers (230 / 246, no scratch) and TWO waves share a SIMD; the four-wave form sits at 472-512 registers, one wave
+// per SIMD, and hides its LDS / VMEM latencies by hand-placing staging items between MFMA groups.  Here the hardware
+// interleaves two waves: two LDS operand buffers, one barrier per tile, the registers of tile t + 1 copied into the other
+// buffer and the loads of tile t + 2 issued before the MFMAs of tile t.  Measured against the four-wave form (batch 8, both
+// operands split images, tools/bench_split.py, same box): stride 2 254 -> 224 us (128 x 256 @256^2), 247 -> 218 (256 x 512
+// @128^2), 138 -> 123 (512 x 512 @64^2) = +12..14 %; stride 1 394 -> 380 (256 x 256 @128^2), 411 -> 393 (128 x 128 @256^2),
+// 114 -> 110 (512 x 512 @32^2) = +3..4 %, and 385 -> 393 us (-2 %) on 512 x 512 @64^2.
+// PK = 3: both operands split images (`ascale` / `bscale` = their headers).  PK = 0: fp32 operands split on the fly — FAST = 2 with
+// per-(image, channel) scale tables (the generator's modulated layers: ascale = demodulation, bscale = style), FAST = 1 without;
+// one image per tile (every layer >= 8 x 8), so a tile's scale vectors live in registers.  The conversion work of one wave
+// (12 VALU per staged float4) now runs under the OTHER wave's MFMAs instead of between this wave's own.
+template <int NT, int PM8, int FAST, int PK>
+__global__ __launch_bounds__(512) void conv_wgrad8_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                          float *__restrict__ ws, const float *__restrict__ ascale,
+                                                          const float *__restrict__ bscale, const rick_conv_geom g,
+                                                          const ConvTiling t, int nsplit, int tiles_per_split) {
+    static_assert(PK == 0 || PK == 3, "both operands fp32, or both split images");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cv_fp16_saturate();
+    const int bufsz = 2 * WG_GY_BYTES + 2 * (t.NPP + 1) * 64;
+    unsigned *ptab = reinterpret_cast<unsigned *>(smem + 2 * bufsz);
+    float *sA = reinterpret_cast<float *>(ptab + ((t.NPP + 3) & ~3));   // [N][128 co] scales of gy (PK = 0)
+    float *sB = sA + g.N * CV_BM;                                        // [N][32 ci]  scales of x
+    build_patch_table(ptab, t);
+    int split, cc;
+    const int ncc = t.nchunks * t.ncot;
+    if ((nsplit & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, spx = nsplit >> 3;
+        split = xcd + 8 * (j % spx);
+        cc = j / spx;
+    } else if ((nsplit == 1 || nsplit == 2 || nsplit == 4) && ncc % (8 / nsplit) == 0) {
+        const int xps = 8 / nsplit, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        split = xcd / xps;
+        cc = (xcd % xps) * (ncc / xps) + j;
+    } else {
+        split = blockIdx.x / ncc;
+        cc = blockIdx.x % ncc;
+    }
+    const int chunk = cc % t.nchunks, cot = cc / t.nchunks;
+    const int ntiles = t.ntx * t.nty * t.ntn;
+    const int tile_begin = split * tiles_per_split;
+    const int tile_end = tile_begin + tiles_per_split < ntiles ? tile_begin + tiles_per_split : ntiles;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                     // wm: 32-co quarter, wn: 16-ci half
+    const int G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int tw_mask = (1 << t.tw_log2) - 1, th_mask = (1 << t.th_log2) - 1;
+    int a_row[2][2], a_key[2][2], pbase[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int r = kk * 32 + G * 8 + h * 4 + q;
+            a_row[kk][h] = r * 256;
+            a_key[kk][h] = wg_key(r) * 32;
+            const int px = r & tw_mask, py = (r >> t.tw_log2) & th_mask;
+            int nbi = r >> (t.tw_log2 + t.th_log2);
+            nbi = nbi < t.nbe ? nbi : t.nbe - 1;
+            pbase[kk][h] = (nbi * t.PH + py * g.is) * t.PW + (g.is == 2 ? px : px * g.is);
+        }
+    const int b_kg = wn * 2 + (p >> 1), b_sub = (p & 1) * 8;
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int tt = 0; tt < NT; tt++) acc[i][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging maps for 512 threads: 4 gy items (rows (tid >> 5) + 16 k), PM8 patch items (pixels (tid >> 3) + 64 k)
+    float4 gq[4], pq[PM8];
+    int g_rel[4], g_lds[4], p_rel[PM8], p_lds[PM8];
+    unsigned p_pyx[PM8];
+    const int gc4 = threadIdx.x & 31, pc4 = threadIdx.x & 7;
+    const int gco = cot * CV_BM + gc4 * 4, pci = chunk * CV_CK + pc4 * 4;
+    if constexpr (PK == 0) {
+        for (int i = threadIdx.x; i < g.N * CV_BM; i += 512) {
+            const int n = i >> 7, co = cot * CV_BM + (i & 127);
+            sA[i] = !ascale ? 1.f : co < g.Co ? ascale[(int64_t)n * g.Co + co] : 0.f;
+        }
+        for (int i = threadIdx.x; i < g.N * CV_CK; i += 512) {
+            const int n = i >> 5, ci = chunk * CV_CK + (i & 31);
+            sB[i] = !bscale ? 1.f : ci < g.Ci ? bscale[(int64_t)n * g.Ci + ci] : 0.f;
+        }
+    }
+    __syncthreads();                                             // patch table (and scale tables) complete
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int r = (threadIdx.x >> 5) + 16 * k;
+        const int px = r & tw_mask, py = (r >> t.tw_log2) & th_mask, nbi = r >> (t.tw_log2 + t.th_log2);
+        g_rel[k] = ((nbi * g.OH + py * g.os) * g.OW + px * g.os) * g.Co;
+        g_lds[k] = r * 256 + ((gc4 * 8) ^ (wg_key(r) * 32));
+    }
+#pragma unroll
+    for (int k = 0; k < PM8; k++) {
+        const int pix = (threadIdx.x >> 3) + 64 * k;
+        p_rel[k] = 0;
+        p_pyx[k] = 0xffffffffu;
+        const int slot = pix < t.NPP ? cv_patch_slot(pix, ptab[pix], t, g.is) : t.NPP;
+        p_lds[k] = slot * 64 + wg_pswz(pc4 >> 1, slot, t.pkb) * 16 + (pc4 & 1) * 8;
+        if (pix < t.NPP) {
+            const unsigned e = ptab[pix];
+            p_rel[k] = (((int)(e >> 20) * g.IH + (int)((e >> 10) & 1023)) * g.IW + (int)(e & 1023)) * g.Ci;
+            p_pyx[k] = e;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(gy), 0, (unsigned)((int64_t)g.N * g.OH * g.OW * g.Co * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x), 0, (unsigned)((int64_t)g.N * g.IH * g.IW * g.Ci * 4), 0x00020000);
+    int g_toff = 0, x_toff = 0, l_iy0 = 0, l_ix0 = 0, l_n0 = 0;
+    auto set_tile = [&](int tile) {
+        int pt = tile;
+        const int tx_i = pt % t.ntx;
+        pt /= t.ntx;
+        const int ty_i = pt % t.nty;
+        const int tn_i = pt / t.nty;
+        const int gx0 = tx_i << t.tw_log2, gy0 = ty_i << t.th_log2;
+        l_n0 = tn_i * t.nbe;
+        l_iy0 = gy0 * g.is + t.dymin;
+        l_ix0 = gx0 * g.is + t.dxmin;
+        g_toff = ((((l_n0 * g.OH + gy0 * g.os + g.oy0) * g.OW + gx0 * g.os + g.ox0) * g.Co) + gco) * 4;
+        x_toff = ((((l_n0 * g.IH + l_iy0) * g.IW + l_ix0) * g.Ci) + pci) * 4;
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) gq[k] = buf_load4(g_rsrc, (unsigned)(g_toff + g_rel[k] * 4));
+#pragma unroll
+        for (int k = 0; k < PM8; k++) {
+            const unsigned e = p_pyx[k];
+            const unsigned iy = (unsigned)(l_iy0 + (int)((e >> 10) & 1023)), ix = (unsigned)(l_ix0 + (int)(e & 1023));
+            const bool ok = (e != 0xffffffffu) & (iy < (unsigned)g.IH) & (ix < (unsigned)g.IW);
+            pq[k] = buf_load4(x_rsrc, ok ? (unsigned)(x_toff + p_rel[k] * 4) : 0xFFFFFFF0u);     // (beyond the range: zeros)
+        }
+    };
+    // ---- operand exponents (PK = 0; conv_common.h): amax of gy * ascale and x * bscale over 4 of the block's tiles x 2 staging
+    // items each, then 2^e is folded into the scale tables; split images bring theirs in the header
+    float punscale, xsa = 1.f, xsb = 1.f;
+    if constexpr (PK == 3) {
+        punscale = cv_uniform(ascale[1] * bscale[1]);
+    } else {
+        float ma = 0.f, mb = 0.f;
+        const int nt = tile_end - tile_begin;
+        if (nt > 0) {
+#pragma unroll
+            for (int sidx = 0; sidx < 4; sidx++) {
+                set_tile(tile_begin + (sidx * nt) / 4);
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++) {
+                    const int k = (sidx + 3 * kk + 1) & 3;
+                    float4 v = buf_load4(g_rsrc, (unsigned)(g_toff + g_rel[k] * 4));
+                    v = mul4(v, *reinterpret_cast<const float4 *>(sA + l_n0 * CV_BM + gc4 * 4));
+                    ma = amax4(ma, v);
+                    const int kp = (3 * sidx + 7 * kk + 2) % PM8;
+                    const unsigned e = p_pyx[kp];
+                    const unsigned iy = (unsigned)(l_iy0 + (int)((e >> 10) & 1023)), ix = (unsigned)(l_ix0 + (int)(e & 1023));
+                    const bool ok = (e != 0xffffffffu) & (iy < (unsigned)g.IH) & (ix < (unsigned)g.IW);
+                    float4 w = buf_load4(x_rsrc, ok ? (unsigned)(x_toff + p_rel[kp] * 4) : 0xFFFFFFF0u);
+                    w = mul4(w, *reinterpret_cast<const float4 *>(sB + l_n0 * CV_CK + pc4 * 4));
+                    mb = amax4(mb, w);
+                }
+            }
+        }
+        float *red = reinterpret_cast<float *>(smem);            // (operand buffers are not in use yet)
+        ma = block_amax(ma, red);
+        mb = block_amax(mb, red + 8);
+        float sa, ua, sb, ub;
+        cv_pow2_scale(ma, sa, ua);
+        cv_pow2_scale(mb, sb, ub);
+        punscale = cv_uniform(ua * ub);
+        xsa = cv_uniform(sa);
+        xsb = cv_uniform(sb);
+        __syncthreads();                                         // every thread has read `red`
+        for (int i = threadIdx.x; i < g.N * CV_BM; i += 512) sA[i] *= sa;
+        for (int i = threadIdx.x; i < g.N * CV_CK; i += 512) sB[i] *= sb;
+        __syncthreads();
+    }
+    float4 sa_cv = make_float4(1.f, 1.f, 1.f, 1.f), sb_cv = sa_cv;   // scale vectors of the tile whose registers are held
+    auto tile_scales = [&]() {
+        if constexpr (PK == 0 && FAST == 2) {
+            const int n = l_n0 < g.N ? l_n0 : 0;
+            sa_cv = *reinterpret_cast<const float4 *>(sA + n * CV_BM + gc4 * 4);
+            sb_cv = *reinterpret_cast<const float4 *>(sB + n * CV_CK + pc4 * 4);
+        }
+    };
+    auto store = [&](unsigned char *buf) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if constexpr (PK == 3) {                             // a split-image item IS {hi x 4 | lo x 4}
+                *reinterpret_cast<float2 *>(buf + g_lds[k]) = make_float2(gq[k].x, gq[k].y);
+                *reinterpret_cast<float2 *>(buf + WG_GY_BYTES + g_lds[k]) = make_float2(gq[k].z, gq[k].w);
+            } else {
+                uint2 hi, lo;
+                if constexpr (FAST == 2) split4v_mix<2>(gq[k], sa_cv, hi, lo);
+                else split4s_mix<2>(gq[k], xsa, hi, lo);
+                *reinterpret_cast<uint2 *>(buf + g_lds[k]) = hi;
+                *reinterpret_cast<uint2 *>(buf + WG_GY_BYTES + g_lds[k]) = lo;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PM8; k++) {
+            if constexpr (PK == 3) {
+                *reinterpret_cast<float2 *>(buf + 2 * WG_GY_BYTES + p_lds[k]) = make_float2(pq[k].x, pq[k].y);
+                *reinterpret_cast<float2 *>(buf + 2 * WG_GY_BYTES + (t.NPP + 1) * 64 + p_lds[k]) = make_float2(pq[k].z, pq[k].w);
+            } else {
+                uint2 hi, lo;
+                if constexpr (FAST == 2) split4v_mix<2>(pq[k], sb_cv, hi, lo);
+                else split4s_mix<2>(pq[k], xsb, hi, lo);
+                *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + p_lds[k]) = hi;
+                *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + (t.NPP + 1) * 64 + p_lds[k]) = lo;
+            }
+        }
+    };
+    if (tile_begin < tile_end) {
+        set_tile(tile_begin);
+        issue();
+        tile_scales();
+        store(smem);
+        set_tile(tile_begin + 1 < tile_end ? tile_begin + 1 : tile_end - 1);
+        issue();
+    }
+    __syncthreads();
+    for (int tile = tile_begin; tile < tile_end; tile++) {
+        const int cur = (tile - tile_begin) & 1;
+        const unsigned char *bgh = smem + cur * bufsz, *bgl = bgh + WG_GY_BYTES;
+        const unsigned char *bph = bgh + 2 * WG_GY_BYTES, *bpl = bph + (t.NPP + 1) * 64;
+        tile_scales();                                           // (l_n0 still belongs to tile + 1, whose registers are held)
+        store(smem + (cur ^ 1) * bufsz);
+        set_tile(tile + 2 < tile_end ? tile + 2 : tile_end - 1);
+        issue();                                                 // tile + 2
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            f16x8 ahi[2], alo[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int cb = (wm * 32 + i * 16 + p * 4) * 2;
+                const int o0 = a_row[kk][0] + (cb ^ a_key[kk][0]);
+                const int o1 = a_row[kk][1] + (cb ^ a_key[kk][1]);
+                ahi[i] = tr_read2(bgh, o0, o1);
+                alo[i] = tr_read2(bgl, o0, o1);
+            }
+#pragma unroll
+            for (int tt = 0; tt < NT; tt++) {
+                const int toff = (g.dy[tt] - t.dymin) * t.PW + cv_patch_col(g.dx[tt] - t.dxmin, t.PW, g.is);
+                const int pp0 = pbase[kk][0] + toff, pp1 = pbase[kk][1] + toff;
+                const int o0 = pp0 * 64 + wg_pswz(b_kg, pp0, t.pkb) * 16 + b_sub;
+                const int o1 = pp1 * 64 + wg_pswz(b_kg, pp1, t.pkb) * 16 + b_sub;
+                const f16x8 bhi = tr_read2(bph, o0, o1);
+                const f16x8 blo = tr_read2(bpl, o0, o1);
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[i], bhi, acc[i][tt], 0, 0, 0);
+                    acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], blo, acc[i][tt], 0, 0, 0);
+                    acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[i], bhi, acc[i][tt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *wsb = ws + (((int64_t)split * t.ncot + cot) * t.nchunks + chunk) * g.ntaps * (CV_BM * CV_CK);
+#pragma unroll
+    for (int tt = 0; tt < NT; tt++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int co = wm * 32 + i * 16 + G * 4;
+            const int ci = wn * 16 + (lane & 15);
+            *reinterpret_cast<float4 *>(wsb + (tt * CV_CK + ci) * CV_BM + co) =
+                make_float4(acc[i][tt][0] * punscale, acc[i][tt][1] * punscale, acc[i][tt][2] * punscale, acc[i][tt][3] * punscale);
+        }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ gw,
                                                            int64_t s_co, int64_t s_ci, int64_t s_t, int Co, int Ci,
                                                            int ncot, int nchunks, int ntaps, int nsplit, float alpha,
@@ -755,6 +1028,20 @@ static bool wgrad_fast(const rick_conv_geom *g, const ConvTiling &t, int NT) {
            !(g->GW & ((1 << t.tw_log2) - 1)) && !(g->N % t.nbe) && (t.nb == t.nbe);
 }
 
+static size_t wgrad8_lds_bytes(const rick_conv_geom *g, const ConvTiling &t) {
+    return 2 * (2 * WG_GY_BYTES + 2 * (size_t)(t.NPP + 1) * 64) + (size_t)((t.NPP + 3) & ~3) * 4 + (size_t)g->N * (CV_BM + CV_CK) * 4;
+}
+template <int NT, int PM8, int FAST, int PK>
+static void launch_wgrad8(const float *x, const float *gy, float *ws, const float *ascale, const float *bscale,
+                          const rick_conv_geom *g, const ConvTiling &t, int nsplit, int tps, hipStream_t st) {
+    if constexpr (NT == 9 || NT == 1) {
+        const unsigned nwg = (unsigned)(nsplit * t.ncot * t.nchunks);
+        (void)hipFuncSetAttribute((const void *)conv_wgrad8_kernel<NT, PM8, FAST, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((conv_wgrad8_kernel<NT, PM8, FAST, PK>), dim3(nwg), dim3(512), wgrad8_lds_bytes(g, t), st, x, gy, ws, ascale,
+                           bscale, *g, t, nsplit, tps);
+    }
+}
+
 template <int NT>
 static int launch_wgrad(const float *x, const float *gy, float *ws, const float *ascale, const float *bscale,
                         const rick_conv_geom *g, const ConvTiling &t, int nsplit, int tps, hipStream_t st, int pk = 0) {
@@ -763,8 +1050,15 @@ static int launch_wgrad(const float *x, const float *gy, float *ws, const float 
     const bool pipe = wgrad_use_pipe(g, t);
     const size_t lds = wgrad_lds_bytes(g, t, pipe);
     const bool fast = wgrad_fast(g, t, NT);
+    static const int wg8 = ablation_env("RICK_WGRAD8", 1);              // (A/B switch of the experiment build)
     if (pk) {   // split-image operands (`ascale` / `bscale` carry the headers): only the whole-tile form
         if (!fast || g->split != 2) return RICK_EINVAL;
+        if (pk == 3 && (NT == 9 || NT == 1) && wg8 && t.nbe == 1 && wgrad8_lds_bytes(g, t) <= 160 * 1024) {
+            // both operands split images: the eight-wave form
+            if (small) launch_wgrad8<NT, 2, 1, 3>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
+            else launch_wgrad8<NT, 6, 1, 3>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
+            return 0;
+        }
         if (small) {
             if (pk == 3) launch_wgrad_k<NT, 2, true, 4, true, 1, 3>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
             else if (pk == 2) launch_wgrad_k<NT, 2, true, 4, true, 1, 2>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
@@ -777,6 +1071,14 @@ static int launch_wgrad(const float *x, const float *gy, float *ws, const float 
         return 0;
     }
     const bool scaled = ascale != nullptr || bscale != nullptr;
+    if (fast && vec && g->split == 2 && (NT == 9 || NT == 1) && wg8 && t.nbe == 1 && wgrad8_lds_bytes(g, t) <= 160 * 1024) {
+        // fp32 operands, whole tiles, one image per tile: the eight-wave form (conversion under the other wave's MFMAs)
+        if (small && scaled) launch_wgrad8<NT, 2, 2, 0>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
+        else if (small) launch_wgrad8<NT, 2, 1, 0>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
+        else if (scaled) launch_wgrad8<NT, 6, 2, 0>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
+        else launch_wgrad8<NT, 6, 1, 0>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, st);
+        return 0;
+    }
     // ONE chain: exactly one kernel per call
     if (g->split == 1 && vec) launch_wgrad_k<NT, 1, true, 12, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);
     else if (!vec) launch_wgrad_k<NT, 2, false, 12, false>(x, gy, ws, ascale, bscale, g, t, nsplit, tps, lds, st);

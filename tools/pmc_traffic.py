@@ -46,7 +46,7 @@ fetch, write = collect(sys.argv[1], 'FETCH_SIZE'), collect(sys.argv[2], 'WRITE_S
 out = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over 16 eager bench iterations, batch 4, 256 px',
        'kernel_source_sha16': kernel_source_hash(),
        'units': 'bytes per launch; reads = 2 x FETCH_SIZE x 1024 (gfx950 correction), writes = WRITE_SIZE x 1024', 'kernels': {}}
-fam = {'conv_igemm': ['conv_igemm_kernel', 'conv_igemm_multi_kernel', 'convt2_kernel'], 'conv_wgrad': ['conv_wgrad_kernel']}
+fam = {'conv_igemm': ['conv_igemm_kernel', 'conv_igemm_multi_kernel', 'convt2_kernel'], 'conv_wgrad': ['conv_wgrad_kernel', 'conv_wgrad8_kernel']}
 for k in sorted(set(fetch) | set(write)):
     n = max(fetch[k][0], write[k][0], 1)
     rd = 2.0 * 1024 * fetch[k][1] / max(fetch[k][0], 1)
