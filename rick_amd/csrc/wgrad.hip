@@ -629,7 +629,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 // buffer and the loads of tile t + 2 issued before the MFMAs of tile t.  Measured against the four-wave form (batch 8, both
 // operands split images, tools/bench_split.py, same box): stride 2 254 -> 224 us (128 x 256 @256^2), 247 -> 218 (256 x 512
 // @128^2), 138 -> 123 (512 x 512 @64^2) = +12..14 %; stride 1 394 -> 380 (256 x 256 @128^2), 411 -> 393 (128 x 128 @256^2),
-// 114 -> 110 (512 x 512 @32^2) = +3..4 %, and 385 -> 393 us (-2 %) on 512 x 512 @64^2.
+// 114 -> 110 (512 x 512 @32^2) = +3..4 %, and 385 -> 393 us (-2 %) on 512 x 512 @64^2.  fp32 operands (the conversion then runs
+// under the partner wave's MFMAs): 530 -> 480, 486 -> 420, 501 -> 426, 146 -> 123 us stride 1, 312 -> 271, 308 -> 254, 172 -> 139
+// us stride 2 (+10..24 %); 1 x 1: 136 -> 96 / 93 -> 81 us (fp32 / images, 128 x 256 @128^2).  In situ (bench.py, same box,
+// experiment build with RICK_WGRAD8 = 0 / 1): 165.5 -> 169.4 images/s.  Measured and not kept: the two waves of a SIMD taking
+// the staging and the MFMA half of a tile period in opposite order (w < 4 stage first, w >= 4 multiply first): stride-1 fp32
+// 474 -> 564, 407 -> 435 us, the rest unchanged — the hardware's own interleaving of two in-phase waves does better.
 // PK = 3: both operands split images (`ascale` / `bscale` = their headers).  PK = 0: fp32 operands split on the fly — FAST = 2 with
 // per-(image, channel) scale tables (the generator's modulated layers: ascale = demodulation, bscale = style), FAST = 1 without;
 // one image per tile (every layer >= 8 x 8), so a tile's scale vectors live in registers.  The conversion work of one wave
