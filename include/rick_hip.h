@@ -272,6 +272,15 @@ typedef struct {
  * (an operand ~8 000 x above the sampled block maximum: the hardware's sticky OVERFLOW status, read once per wave).  Every
  * event means a finite but wrong product somewhere: 0 in every test and in tools/stability.py. */
 int rick_saturation_count(unsigned *count, int reset);
+/* Kernel-form switches (process-wide, host side; every form computes the same convolution — the eight-wave igemm is
+ * bit-identical to the four-wave one on split images and differs by per-block operand exponents, 2^-22, on fp32 operands).
+ * Used by the parity tests and the same-process A/B micro-benchmarks; returns the previous value, -1 for an unknown key.
+ *   RICK_TUNE_IGEMM_W8: 3x3 stride-1 launches with >= RICK_TUNE_IGEMM_W8_MINBLK (default 192) blocks of 128 co x 256
+ *   positions run the eight-wave form (conv.hip, igemm_body NW = 8) — 0 (default): never (four-wave 128 x 128 blocks: equal or
+ *   faster end to end, conv.hip igemm_w8_plan); 1: fp32 operands with Ci >= 512; 2: wherever the form exists. */
+#define RICK_TUNE_IGEMM_W8 0
+#define RICK_TUNE_IGEMM_W8_MINBLK 1
+int rick_conv_tuning(int key, int value);
 /* Producers.  rick_upfirdn2d_f32 / rick_upfirdn2d_act_f32 (tail may be NULL) with the extended result handling, channels-last
  * only; `out` may be NULL with ex->no_f32.  The activation adjoint (rick_bias_act_bwd_f32) leaving as split images:
  * out1 = g * (ref > 0 ? 1 : alpha) * scale and, when out2 != NULL, out2 = g * mul2 (the same gradient entering a parallel linear

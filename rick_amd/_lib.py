@@ -78,6 +78,7 @@ SIGNATURES = {
     'rick_conv_wgrad_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, ctypes.POINTER(ConvGeom), c_int,
                                           c_fp, c_fp]),
     'rick_saturation_count': (c_int, [ctypes.POINTER(ctypes.c_uint), c_int]),
+    'rick_conv_tuning': (c_int, [c_int, c_int]),
     'rick_upfirdn2d_ex_f32': (c_int, [c_fp, c_fp, c_fp, c_i64] + [c_int] * 13 + [ctypes.POINTER(ConvEpilogue),
                                                                                  ctypes.POINTER(SplitOut), c_fp]),
     'rick_bias_act_bwd_split_f32': (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_i64,
@@ -168,6 +169,13 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here == missing export
     _fn.restype = _res
     _fn.argtypes = _args
+# kernel-form experiments (same-box A/B of bench.py, tools/ab_env2.sh): RICK_TUNE="key=value,..." -> rick_conv_tuning; never silent
+if os.environ.get('RICK_TUNE'):
+    import warnings
+    warnings.warn(f"rick_amd: RICK_TUNE={os.environ['RICK_TUNE']} changes kernel-form selection", RuntimeWarning)
+    for _kv in os.environ['RICK_TUNE'].split(','):
+        _k, _v = _kv.split('=')
+        assert lib.rick_conv_tuning(int(_k), int(_v)) >= 0, f'RICK_TUNE: unknown key {_k}'
 
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)

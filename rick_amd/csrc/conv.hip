@@ -216,6 +216,10 @@ extern "C" int rick_conv_pack_weights_multi(const rick_pack_desc *descs_device, 
     RICK_LAUNCH_STATUS();
 }
 
+#define IG_PMAX 10        // non-DEEP: patch float4 per thread prefetched in registers (NPP <= 320 pixels)
+#define IG_PSET_DEEP 6     // DEEP: two register sets of 6 (NPP <= 192 pixels), chunks prefetched two ahead
+#define IG_DEEP_NPP (32 * IG_PSET_DEEP)
+
 // Stride-2 inputs need a patch of ~4x the position tile; a 64-position block (each wave 64 co x 32 positions)
 // keeps it at ~37 KB so two blocks still fit per CU.
 static size_t igemm_lds_bytes(const ConvTiling &t, bool has_iscale) {
@@ -225,6 +229,39 @@ static size_t igemm_lds_bytes(const ConvTiling &t, bool has_iscale) {
 }
 
 static int igemm_tile_positions(const rick_conv_geom *g) { return (g->is >= 2 && g->ntaps > 1) ? 64 : CV_BN; }
+
+// Eight-wave form (igemm_body, NW = 8): 3x3 stride-1 geometries whose 16 x 16 position tiles fill the chip by themselves.
+// LDS: 4 weight slots + two patch buffers + tables (one block per CU).
+#define IG_W8_POS 256
+static size_t igemm_w8_lds_bytes(const ConvTiling &t) {
+    return 4 * CV_WSTEP_BYTES + 4 * (size_t)(t.NPP + 1) * 64 + (size_t)((t.NPP + 3) & ~3) * 4 + (size_t)t.nbe * t.cps * CV_CK * 4 + 64;
+}
+static int g_tune[2] = {0, 192};      // rick_conv_tuning (include/rick_hip.h)
+extern "C" int rick_conv_tuning(int key, int value) {
+    if (key < 0 || key >= (int)(sizeof(g_tune) / sizeof(g_tune[0]))) return -1;
+    const int prev = g_tune[key];
+    g_tune[key] = value;
+    return prev;
+}
+// Measured and NOT the default (round 6, profiles/r06_w8_microbench.txt, batch 8, both forms interleaved in one process): the
+// eight-wave block gains only where the K loop is long AND the operands are converted in the kernel — 512 -> 512 @64^2 fp32
+// operands +4.7 % forward / +4.2 % data gradient, 512 -> 256 +6.1 % — TIES on split images (470.3 vs 469.9 TFLOP/s) and LOSES on
+// short K loops (128 -> 128 @256^2: -10 ... -15 %; 256 -> 256 @128^2: -2.4 ... +0.9 %): one block per CU has no neighbour block
+// to cover its prologue and its 128 KB epilogue.  The counters say why the tie (profiles/r06_w8_pmc.txt, 512 -> 512 @64^2 split
+// image): four-wave 72.1 % MFMA-busy at 1.74 GHz, eight-wave 64.3 % at 1.84 GHz — the chip trades clock against matrix-pipe
+// occupancy at constant power, so a schedule that keeps the pipe fuller buys nothing.  In bench.py mode 1 (fp32 operands with
+// >= 16 channel chunks) measured 168.80 vs 168.79 images/s.  Mode 0 ships; the form stays behind rick_conv_tuning with its
+// parity tests (tests/test_gpu_ops.py: fp64 at 2e-6, bit-equal to the four-wave form on split images).
+static bool igemm_w8_plan(const rick_conv_geom *g, ConvTiling *t, bool pkx) {
+    const int w8 = g_tune[RICK_TUNE_IGEMM_W8], w8_minblk = g_tune[RICK_TUNE_IGEMM_W8_MINBLK];
+    if (w8 == 1 && (pkx || g->Ci < 16 * CV_CK)) return false;
+    if (!w8 || g->split != 2 || g->ntaps != 9 || g->is != 1 || (g->Ci & 3) || g->GH < 16 || g->GW < 16) return false;
+    if (make_tiling(g, IG_W8_POS, t)) return false;
+    if (t->nb != 1 || t->NPP > 64 * IG_PSET_DEEP || t->nchunks < 4) return false;
+    if (t->ntx * t->nty * t->ntn * t->ncot < w8_minblk) return false;     // (short grids keep the 128-position blocks and split-K)
+    if ((int64_t)g->N * g->IH * g->IW * g->Ci * 4 >= (1LL << 32) - 256) return false;   // (32-bit byte offsets into the input)
+    return igemm_w8_lds_bytes(*t) <= 160 * 1024 && t->PH <= 1023 && t->PW <= 1023;
+}
 
 // Split-K plan for launches with too few blocks to fill 256 CUs (the 4x4..64x64 layers with few output tiles but a
 // long K = Ci x taps).  Two blocks are resident per CU, so the chip runs the grid in "waves" of 512 blocks; the
@@ -252,10 +289,8 @@ static void igemm_plan_split(ConvTiling *t, int ntaps) {
 
 // ==========================================================================================
 // Forward / data-gradient kernel.
-#define IG_PMAX 10        // non-DEEP: patch float4 per thread prefetched in registers (NPP <= 320 pixels)
-#define IG_PSET_DEEP 6     // DEEP: two register sets of 6 (NPP <= 192 pixels), chunks prefetched two ahead
-#define IG_DEEP_NPP (32 * IG_PSET_DEEP)
 
+typedef unsigned int igemm_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) unsigned char cv_lds_u8;
 typedef __attribute__((address_space(1))) const unsigned char cv_gbl_u8;
 
@@ -271,7 +306,13 @@ __device__ __forceinline__ void cv_lds_barrier() {   // raw barrier: no vmcnt(0)
 
 // PKX: the input is a split image (conv_common.h): `iscale` points at its header {2^e, 2^-e, ..}, per-channel input scales
 // are already folded in by the producer, a staging item is the 16 bytes {hi x 4 | lo x 4} of 4 channels, copied to LDS as it is.
-template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, int WDMA = 0, bool PKX = false>
+// NW = 8 (WDMA = 4): the eight-wave form of the straight-line 3x3 stride-1 loop — 512 threads on a 128 co x 256 position block,
+// waves 2 (co) x 4 (positions), ONE block per CU (two waves per SIMD like two of the four-wave blocks, but one weight tile serves
+// all eight waves, the 16 x 16 tile's 18 x 18 patch replaces two 10 x 18 ones, and the LDS this frees holds a fourth weight slot
+// and a SECOND patch buffer: the B fragments and the first A row of k-step ks + 1 are read from LDS during k-step ks, so the
+// MFMAs behind a barrier start at once instead of behind an LDS round trip).  Same MFMA order per accumulator as the four-wave
+// form (bit-identical on split images).
+template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, int WDMA = 0, bool PKX = false, int NW = 4>
 __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const unsigned char *__restrict__ wpk,
                                            float *__restrict__ out, const float *__restrict__ iscale,
                                            const float *__restrict__ oscale, float *__restrict__ ws,
@@ -279,12 +320,16 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                                            const rick_conv_epilogue &epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cv_fp16_saturate();
+    constexpr int NTHR = NW * 64;
+    static_assert(NW == 4 || (NW == 8 && WDMA == 4 && NJ == 4 && NT == 9 && SPLIT == 2 && VEC && !DEEP), "eight-wave form");
+    static_assert((WDMA == 4) == (NW == 8), "the 4-slot ring belongs to the eight-wave form");
     unsigned char *wbuf = smem;                               // [2][16 KB]
-    unsigned char *ph = smem + (WDMA == 3 ? 3 : 2) * CV_WSTEP_BYTES;   // [NPP + 1][64 B]  (WDMA = 3: a ring of 3 weight tiles)
+    unsigned char *ph = smem + (WDMA >= 3 ? WDMA : 2) * CV_WSTEP_BYTES;   // [NPP + 1][64 B]  (WDMA = 3 / 4: a ring of 3 / 4 weight tiles)
     unsigned char *pl = ph + (t.NPP + 1) * 64;                // (+1: spare row for out-of-patch items)
-    unsigned *ptab = reinterpret_cast<unsigned *>(pl + (t.NPP + 1) * 64);             // [NPP]
+    const int pbuf_bytes = 2 * (t.NPP + 1) * 64;              // WDMA = 4: two patch buffers [hi | lo], buffer b at ph + b * pbuf_bytes
+    unsigned *ptab = reinterpret_cast<unsigned *>(pl + (t.NPP + 1) * 64 + (WDMA == 4 ? pbuf_bytes : 0));   // [NPP]
     float *sct = reinterpret_cast<float *>(ptab + ((t.NPP + 3) & ~3));                // [nbe][cps * 32] input scales
-    build_patch_table(ptab, t);
+    build_patch_table(ptab, t, NTHR);
 
     const int lid = xcd_remap(bid, nwg);
     const int npos_tiles = t.ntx * t.nty * t.ntn;
@@ -318,7 +363,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     // round trip and no branch per patch item
     static_assert(!PKX || (SPLIT == 2 && VEC), "split-image input: fp16x3, vector path");
     if (!PKX && iscale) {
-        for (int i = threadIdx.x; i < t.nbe * cspan; i += 256) {
+        for (int i = threadIdx.x; i < t.nbe * cspan; i += NTHR) {
             const int nbi = i / cspan, c = c_begin * CV_CK + (i - nbi * cspan);
             sct[i] = (n0 + nbi < g.N && c < g.Ci) ? iscale[(int64_t)(n0 + nbi) * g.Ci + c] : 0.f;
         }
@@ -329,7 +374,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     float satm = 0.f;          // largest |scaled operand| this thread converts (cv_sat_report)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = NW == 8 ? wave >> 2 : wave >> 1, wn = NW == 8 ? wave & 3 : wave & 1;
     const int l15 = lane & 15, kg = lane >> 4;
 
     int a_off[4];
@@ -355,17 +400,18 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     // last only 1-4 k-steps): the IG_PMAX register slots form TWO sets of 5 and chunks are prefetched two
     // ahead, so a load has two chunks' worth of MFMAs to land instead of one.
     // register prefetch slots per set: the unrolled 128-position form only serves patches of <= 192 pixels
+    // (eight waves: 64 pixels per item round, 6 rounds cover the 18 x 18 patch of a 16 x 16 tile)
     constexpr int PSET = (DEEP || (NT > 0 && NJ == 4)) ? IG_PSET_DEEP : IG_PMAX;
     constexpr int PREGS = DEEP ? 2 * IG_PSET_DEEP : PSET;
     const int p_items = t.NPP * 8;
-    const int c4 = threadIdx.x & 7;                      // 256 % 8 == 0: same channel quad for all items
+    const int c4 = threadIdx.x & 7;                      // NTHR % 8 == 0: same channel quad for all items
     const float *xt = x + (((int64_t)n0 * g.IH + iy0) * g.IW + ix0) * g.Ci + c4 * 4;
     int p_rel[PSET], p_lds[PSET], p_sc[PSET];
     unsigned p_ok = 0;
     float4 pq[PREGS];
 #pragma unroll
     for (int k = 0; k < PSET; k++) {
-        const int pix = (threadIdx.x >> 3) + 32 * k;
+        const int pix = (threadIdx.x >> 3) + (NTHR / 8) * k;
         p_rel[k] = 0;
         p_sc[k] = 0;
         // items past the patch land in a spare row behind it, so the LDS writes need no guard
@@ -423,7 +469,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         else items(std::false_type{});
         if (!DEEP && !PKX) {
             // patches larger than IG_PMAX*32 pixels (stride-2 geometry): remaining items, synchronously
-            for (int it = threadIdx.x + 256 * PSET; it < p_items; it += 256) {
+            for (int it = threadIdx.x + NTHR * PSET; it < p_items; it += NTHR) {
                 const int pix = it >> 3;
                 const unsigned e = ptab[pix];
                 const int n = n0 + (int)(e >> 20), iy = iy0 + (int)((e >> 10) & 1023), ix = ix0 + (int)(e & 1023);
@@ -499,7 +545,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         // packed-weight exponent (trailer of the packed image)
         unscale = cv_uniform(xu * *reinterpret_cast<const float *>(wpk + (int64_t)t.ncot * t.nchunks * g.nslices * CV_WSTEP_BYTES));
         if (iscale) {                   // fold 2^e into the scale table
-            for (int i = threadIdx.x; i < t.nbe * cspan; i += 256) sct[i] *= xscale;
+            for (int i = threadIdx.x; i < t.nbe * cspan; i += NTHR) sct[i] *= xscale;
             __syncthreads();
         }
     };
@@ -535,7 +581,150 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         }                                                               \
     } while (0)
 
-    if constexpr (NT > 0) {
+    if constexpr (WDMA == 4) {
+        // ---- eight-wave form (NW = 8): 4-slot weight ring by LDS-DMA, two patch buffers, fragments prefetched across the barrier.
+        // State at the top of k-step ks (behind its barrier): weight tiles ks and ks + 1 have landed, tile ks + 2 is in flight;
+        // the patch of the current chunk is complete in buffer (chunk - c_begin) & 1; the fragments of the FIRST quadrant of
+        // k-step ks (A rows 0-1, B columns 0-1: 8 of its 16 ds_read_b128) are in registers, read during k-step ks - 1.
+        // K-step ks then
+        //   issues the DMA of tile ks + 3 into the slot of tile ks - 1 (its last reader finished before the barrier),
+        //   issues one patch item of the NEXT chunk (taps 0..5) and converts / stores the one issued two k-steps ago (taps 2..7)
+        //     into the OTHER patch buffer — the next chunk is complete before the barrier that opens tap 8, whose prefetch reads it,
+        //   walks the wave's 4 x 4 MFMA tiles as four quadrants (rows 0-1 | 2-3) x (columns 0-1 | 2-3) in the order
+        //     Q00 Q01 Q11 Q10, reading one operand half ahead of each (B columns 2-3 under Q00, A rows 2-3 under Q01, the first
+        //     quadrant of k-step ks + 1 under Q10): at most 64 fragment registers live, like the four-wave form, and the 12 MFMAs
+        //     behind a barrier never wait for LDS,
+        //   waits for tile ks + 2 (counted vmcnt) and joins the barrier.
+        static_assert(NT >= 3 && PSET + 2 < NT, "patch items: issued at taps 0 .. PSET-1, stored at taps 2 .. PSET+1 < NT-1");
+        // patch items without per-item registers: item k of this thread is patch pixel (tid >> 3) + 64 k, whose LDS offset is the
+        // item-0 offset + 4096 k (64 pixels on: same swizzle key) and whose source offset comes from the pixel table in LDS
+        const int pix0 = threadIdx.x >> 3;
+        const int lds0 = pix0 * 64 + cv_swz(c4 >> 1, pix0) * 16 + (c4 & 1) * 8;
+        const int lds_spare = t.NPP * 64 + cv_swz(c4 >> 1, t.NPP) * 16 + (c4 & 1) * 8;
+        auto item_lds = [&](int k) { return pix0 + 64 * k < t.NPP ? lds0 + 4096 * k : lds_spare; };
+        // loads through a buffer descriptor over the whole input with range-checked 32-bit byte offsets: an item in the zero
+        // padding takes an offset beyond the descriptor and the hardware returns zeros (no branch, no 64-bit address arithmetic)
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(x), 0, (unsigned)((int64_t)g.N * g.IH * g.IW * g.Ci * 4), 0x00020000);
+        const unsigned xt_bytes = (unsigned)((((n0 * g.IH + iy0) * g.IW + ix0) * g.Ci + c4 * 4) * 4);   // (modular: may lie "before" x)
+        auto issue_item = [&](auto KC, int chunk) {
+            constexpr int K = decltype(KC)::value;
+            const int pix = pix0 + 64 * K;
+            const unsigned e = ptab[pix < t.NPP ? pix : 0];                             // (one image per tile: nbi = 0)
+            const unsigned rel = (unsigned)(((int)((e >> 10) & 1023) * g.IW + (int)(e & 1023)) * g.Ci * 4);
+            const bool ok = (cur_ok[0] >> K) & 1u;
+            const igemm_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (xt_bytes + rel + (unsigned)chunk * (CV_CK * 4)) | (ok ? 0u : 0xfffffff0u), 0, 0);   // (OR, not a select of the sum: hipcc would sink the table read into a branch)
+            pq[K] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        };
+        auto issue_wdma8 = [&](int wchunk, int wtap, int slot) {
+            const unsigned char *src = wbase + ((int64_t)wchunk * g.nslices + g.wt[wtap]) * CV_WSTEP_BYTES;
+            unsigned char *dst = wbuf + slot * CV_WSTEP_BYTES;
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                __builtin_amdgcn_global_load_lds((cv_gbl_u8 *)(src + (q * NTHR + threadIdx.x) * 16),
+                                                 (cv_lds_u8 *)(dst + (q * NTHR + wave * 64) * 16), 16, 0, 0);
+        };
+        const int plo = (t.NPP + 1) * 64;                    // lo half of a patch buffer
+        struct Frag2 { f16x8 h[2], l[2]; };                  // two 16-row fragments, hi and lo
+        auto read_a = [&](const unsigned char *wb, int half) {
+            Frag2 f;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                f.h[i] = *reinterpret_cast<const f16x8 *>(wb + a_off[half * 2 + i]);
+                f.l[i] = *reinterpret_cast<const f16x8 *>(wb + CV_WTILE_BYTES + a_off[half * 2 + i]);
+            }
+            return f;
+        };
+        auto read_b = [&](const unsigned char *pbase, int tap, int half) {
+            Frag2 f;
+            const int toff = (g.dy[tap] - t.dymin) * t.PW + (g.dx[tap] - t.dxmin);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int pp = pb[half * 2 + j] + toff;
+                const int off = pp * 64 + cv_swz(kg, pp) * 16;
+                f.h[j] = *reinterpret_cast<const f16x8 *>(pbase + off);
+                f.l[j] = *reinterpret_cast<const f16x8 *>(pbase + plo + off);
+            }
+            return f;
+        };
+        auto quad = [&](const Frag2 &a, const Frag2 &b, auto IH, auto JH) {
+            constexpr int i0 = decltype(IH)::value * 2, j0 = decltype(JH)::value * 2;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l[i], b.h[j], acc[i0 + i][j0 + j], 0, 0, 0);
+                    acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h[i], b.l[j], acc[i0 + i][j0 + j], 0, 0, 0);
+                    acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h[i], b.h[j], acc[i0 + i][j0 + j], 0, 0, 0);
+                }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        auto mainloop = [&](auto ISC) {
+            auto commit_item = [&](auto KC, int chunk, unsigned char *pbase) {
+                constexpr int K = decltype(KC)::value;
+                unsigned char *dh = pbase + item_lds(K);
+                if constexpr (PKX) {      // the item already IS {hi x 4 | lo x 4}
+                    const float4 pv = pq[K];
+                    *reinterpret_cast<float2 *>(dh) = make_float2(pv.x, pv.y);
+                    *reinterpret_cast<float2 *>(dh + plo) = make_float2(pv.z, pv.w);
+                } else {
+                    uint2 hi, lo;
+                    if constexpr (decltype(ISC)::value)
+                        split4v<SPLIT>(pq[K], *reinterpret_cast<const float4 *>(sct + c4 * 4 + (chunk - c_begin) * CV_CK), hi, lo, satm);
+                    else split4s<SPLIT>(pq[K], xscale, hi, lo, satm);
+                    *reinterpret_cast<uint2 *>(dh) = hi;
+                    *reinterpret_cast<uint2 *>(dh + plo) = lo;
+                }
+            };
+            // prologue: tiles 0..2, the first chunk's patch (all items at once: the block exponent needs them), first quadrant of k-step 0
+            issue_wdma8(c_begin, 0, 0);
+            issue_wdma8(c_begin, 1, 1);
+            issue_wdma8(c_begin, 2, 2);
+            issue_patch(c_begin, S0{});
+            block_exponent();
+            static_for<0, PSET>([&](auto KC) { commit_item(KC, c_begin, ph); });
+            cv_wait_vm<0>();
+            cv_lds_barrier();
+            Frag2 a0 = read_a(wbuf, 0), b0 = read_b(ph, 0, 0);
+            int ks0 = 0;
+            for (int chunk = c_begin; chunk < c_end; chunk++, ks0 += NT) {
+                const int cnext = chunk + 1 < c_end ? chunk + 1 : chunk;
+                const int lb = (chunk - c_begin) & 1;
+                unsigned char *pcur = ph + lb * pbuf_bytes, *pnxt = ph + (lb ^ 1) * pbuf_bytes;
+                auto kstep = [&](auto TC) {
+                    constexpr int tap = decltype(TC)::value;
+                    const int ks = ks0 + tap;
+                    issue_wdma8(tap + 3 < NT ? chunk : cnext, (tap + 3) % NT, (ks + 3) & 3);
+                    asm volatile("" ::: "memory");       // (keeps the VM queue in source order: the counted wait below relies on it)
+                    if constexpr (tap == 0) cur_ok[0] = cnext * CV_CK + c4 * 4 < g.Ci ? p_ok : 0u;
+                    if constexpr (tap < PSET) issue_item(std::integral_constant<int, tap < PSET ? tap : 0>{}, cnext);
+                    if constexpr (tap >= 2 && tap - 2 < PSET) commit_item(std::integral_constant<int, tap >= 2 ? tap - 2 : 0>{}, cnext, pnxt);
+                    const unsigned char *wb = wbuf + (ks & 3) * CV_WSTEP_BYTES;
+                    const unsigned char *wbn = wbuf + ((ks + 1) & 3) * CV_WSTEP_BYTES;
+                    const Frag2 b1 = read_b(pcur, tap, 1);
+                    quad(a0, b0, I0{}, I0{});
+                    const Frag2 a1 = read_a(wb, 1);
+                    quad(a0, b1, I0{}, I1{});
+                    quad(a1, b1, I1{}, I1{});
+                    const Frag2 na = read_a(wbn, 0);
+                    const Frag2 nb = read_b(tap + 1 < NT ? pcur : pnxt, (tap + 1) % NT, 0);
+                    quad(a1, b0, I1{}, I0{});
+                    a0 = na;
+                    b0 = nb;
+                    // tile ks + 2 (issued at the top of k-step ks - 1) has landed when at most the VM operations issued behind
+                    // it are outstanding: that k-step's patch item, this k-step's two DMA instructions and patch item
+                    constexpr int n1 = (tap >= 1 && tap - 1 < PSET) ? 1 : 0, n0 = tap < PSET ? 1 : 0;
+                    cv_wait_vm<2 + n0 + n1>();
+                    cv_lds_barrier();
+                };
+                static_for<0, NT>(kstep);
+            }
+            cv_wait_vm<0>();       // (the ring runs three tiles ahead: nothing may land in LDS after the block has left)
+        };
+        if (!PKX && iscale) mainloop(std::true_type{});
+        else mainloop(std::false_type{});
+    } else if constexpr (NT > 0) {
         // ---- straight-line form for a compile-time tap count (the 3x3 layers that carry the FLOPs).  One channel
         // chunk = NT fully unrolled k-steps; every k-step loads the next weight tile and a slice of the NEXT chunk's
         // patch items, unconditionally (past the end of the range the last chunk is staged again and never used).
@@ -862,14 +1051,14 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     if (epi.amax && t.nsplit == 1) cv_amax_publish(out_amax, epi.amax, reinterpret_cast<float *>(smem));     // (split-K: the second stage measures)
 }
 
-template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, int WDMA = 0, bool PKX = false>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const float *__restrict__ x,
+template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, int WDMA = 0, bool PKX = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void conv_igemm_kernel(const float *__restrict__ x,
                                                             const unsigned char *__restrict__ wpk,
                                                             float *__restrict__ out, const float *__restrict__ iscale,
                                                             const float *__restrict__ oscale, float *__restrict__ ws,
                                                             const rick_conv_geom g, const ConvTiling t,
                                                             const rick_conv_epilogue epi) {
-    igemm_body<SPLIT, VEC, DEEP, NJ, NT, WDMA, PKX>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x, epi);
+    igemm_body<SPLIT, VEC, DEEP, NJ, NT, WDMA, PKX, NW>(x, wpk, out, iscale, oscale, ws, g, t, blockIdx.x, gridDim.x, epi);
 }
 
 // Several geometries (the output-parity classes of a transposed convolution) in ONE launch: block ranges
@@ -992,18 +1181,20 @@ static void launch_splitk_reduce(const float *ws, float *out, const float *oscal
 extern "C" int64_t rick_conv_igemm_workspace_bytes(const rick_conv_geom *g) {
     if (check_geom(g)) return -1;
     ConvTiling t;
+    // (the four-wave plan's need, whatever rick_conv_tuning says now: callers cache this per geometry; the eight-wave form uses none)
     if (make_tiling(g, igemm_tile_positions(g), &t)) return -1;
     igemm_plan_split(&t, g->ntaps);
     return t.nsplit > 1 ? (int64_t)t.nsplit * g->N * g->GH * g->GW * g->Co * 4 : 0;
 }
 
-template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT = 0, int WDMA = 0, bool PKX = false>
+template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT = 0, int WDMA = 0, bool PKX = false, int NW = 4>
 static void launch_igemm_k(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
                            const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
                            const ConvTiling &t, const rick_conv_epilogue &epi) {
-    (void)hipFuncSetAttribute((const void *)conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT, WDMA, PKX>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT, WDMA, PKX>), dim3(nwg), dim3(256), lds + (WDMA == 3 ? CV_WSTEP_BYTES : 0), st,
+    static const bool attr_set = hipFuncSetAttribute((const void *)conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT, WDMA, PKX, NW>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;   // once per variant
+    (void)attr_set;
+    hipLaunchKernelGGL((conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT, WDMA, PKX, NW>), dim3(nwg), dim3(NW * 64), lds + (WDMA == 3 ? CV_WSTEP_BYTES : 0), st,
                        x, wp, out, iscale, oscale, ws, *g, t, epi);
 }
 
@@ -1079,6 +1270,7 @@ extern "C" int rick_conv_igemm_split_f32(const void *x_split, const float *x_hdr
 extern "C" int rick_conv_igemm_split_supported(const rick_conv_geom *g) {
     if (check_geom(g) || (g->Ci & 31) || g->split != 2) return 0;
     ConvTiling t;
+    if (igemm_w8_plan(g, &t, true)) return 1;
     if (make_tiling(g, igemm_tile_positions(g), &t)) return 0;
     igemm_plan_split(&t, g->ntaps);
     const size_t lds = igemm_lds_bytes(t, false);
@@ -1105,6 +1297,15 @@ static int igemm_run(const float *x, const void *packed_w, float *out, const flo
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed_w | (uintptr_t)(iscale ? iscale : x) | (uintptr_t)(oscale ? oscale : x)) % 16)
         return RICK_EINVAL;
     ConvTiling t;
+    hipStream_t st = (hipStream_t)stream;
+    if (igemm_w8_plan(g, &t, pkx)) {          // eight-wave 128 co x 256 position blocks (igemm_body, NW = 8)
+        const int64_t nwg8 = (int64_t)t.ntx * t.nty * t.ntn * t.ncot;
+        const size_t lds8 = igemm_w8_lds_bytes(t);
+        const unsigned char *wp8 = (const unsigned char *)packed_w;
+        if (pkx) launch_igemm_k<2, true, false, 4, 9, 4, true, 8>((unsigned)nwg8, lds8, st, x, wp8, out, iscale, oscale, nullptr, g, t, epi);
+        else launch_igemm_k<2, true, false, 4, 9, 4, false, 8>((unsigned)nwg8, lds8, st, x, wp8, out, iscale, oscale, nullptr, g, t, epi);
+        RICK_LAUNCH_STATUS();
+    }
     if (make_tiling(g, igemm_tile_positions(g), &t)) return RICK_EINVAL;
     igemm_plan_split(&t, g->ntaps);
     if (t.nsplit > 1 && (!workspace || ((uintptr_t)workspace % 16))) return RICK_EINVAL;
@@ -1113,7 +1314,6 @@ static int igemm_run(const float *x, const void *packed_w, float *out, const flo
     if (lds > 160 * 1024 || t.PH > 1023 || t.PW > 1023) return RICK_EINVAL;
     const int64_t nwg = (int64_t)t.ntx * t.nty * t.ntn * t.ncot * t.nsplit;
     if (nwg > 0x7fffffff) return RICK_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
     const unsigned char *wp = (const unsigned char *)packed_w;
     const bool vec = (g->Ci & 3) == 0;

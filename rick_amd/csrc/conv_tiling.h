@@ -80,9 +80,9 @@ static int make_tiling(const rick_conv_geom *g, int tile_positions, ConvTiling *
 
 // Patch pixel -> (image-in-tile, row, col) table, built once per block so the staging loops need no
 // integer divisions: entry = nbi << 20 | py << 10 | px.
-__device__ __forceinline__ void build_patch_table(unsigned *ptab, const ConvTiling &t) {
+__device__ __forceinline__ void build_patch_table(unsigned *ptab, const ConvTiling &t, int nthr = 256) {
     const int phw = t.PH * t.PW;
-    for (int pix = threadIdx.x; pix < t.NPP; pix += 256) {
+    for (int pix = threadIdx.x; pix < t.NPP; pix += nthr) {
         const int nbi = pix / phw;
         const int rem = pix - nbi * phw;
         const int py = rem / t.PW, px = rem - py * t.PW;

@@ -177,6 +177,76 @@ def test_conv2d_vs_fp64(case):
     assert rel_err(gg[1], ggr[1]) < 5e-6, 'second-order d/dw'
 
 
+@contextlib.contextmanager
+def _conv_tuning(**kv):
+    """rick_conv_tuning (include/rick_hip.h) for the duration of a test: which kernel FORM a launch takes, never its values."""
+    from rick_amd._lib import lib
+    keys = {'igemm_w8': 0, 'igemm_w8_minblk': 1}
+    prev = {k: lib.rick_conv_tuning(keys[k], v) for k, v in kv.items()}
+    try:
+        yield
+    finally:
+        for k, v in prev.items():
+            lib.rick_conv_tuning(keys[k], v)
+
+
+@pytest.mark.parametrize('case', [('ragged_co', 2, 128, 192, 32, 32), ('ragged_tiles', 1, 160, 128, 40, 24),
+                                  ('three_images', 3, 256, 128, 16, 48)], ids=lambda c: c[0])
+def test_igemm_eight_wave_form_vs_fp64(case):
+    """The eight-wave 128 co x 256 position igemm block (conv.hip, igemm_body NW = 8: 4-slot LDS-DMA weight ring, two patch
+    buffers, fragments read across the barrier), forced onto small geometries: forward with modulation scales, plain forward
+    and the stride-1 data gradient (model_probe_tune.py:122,278-282) against torch CPU fp64 at the four-wave form's
+    tolerance — ragged co tiles, position tiles hanging over the image, channel counts that are no multiple of 32."""
+    from rick_amd.op import conv as cv
+    tag, n, ci, co, h, w = case
+    x = synth_tensor(f'w8/{tag}/x', (n, ci, h, w)) * torch.exp2(torch.randint(-6, 3, (n, ci, 1, 1), generator=torch.Generator().manual_seed(1)).float())
+    wt = synth_tensor(f'w8/{tag}/w', (co, ci, 3, 3))
+    si, so = synth_tensor(f'w8/{tag}/si', (n, ci)).abs() + 0.5, synth_tensor(f'w8/{tag}/so', (n, co)).abs() + 0.5
+    gy = synth_tensor(f'w8/{tag}/gy', (n, co, h, w)) * 1e-4
+    ref = F.conv2d(x.double() * si.double()[:, :, None, None], wt.double(), padding=1) * so.double()[:, :, None, None]
+    ref0 = F.conv2d(x.double(), wt.double(), padding=1)
+    refT = F.conv_transpose2d(gy.double(), wt.double(), padding=1)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    gd = gy.to(DEV).contiguous(memory_format=torch.channels_last)
+    wp, wpT = cv._pack(wt.to(DEV), 1.0), cv._pack(wt.to(DEV).transpose(0, 1), 1.0)
+    with _conv_tuning(igemm_w8=2, igemm_w8_minblk=1):
+        y = cv._conv_launch(xd, wp, co, 3, 3, 1, 1, iscale=si.to(DEV), oscale=so.to(DEV))
+        y0 = cv._conv_launch(xd, wp, co, 3, 3, 1, 1)
+        gx = cv._convT_launch(gd, wpT, ci, 3, 3, 1, 1, (h, w))
+        torch.cuda.synchronize()
+    assert rel_err(y, ref) < 2e-6, 'modulated forward'
+    assert rel_err(y0, ref0) < 2e-6, 'plain forward'
+    assert rel_err(gx, refT) < 2e-6, 'data gradient'
+
+
+def test_igemm_eight_wave_form_bit_equal_on_split_images():
+    """Same MFMA order per accumulator as the four-wave blocks: on split images (one exponent per tensor, no per-block
+    sampling) the two forms agree bit for bit — forward and stride-1 data gradient on a geometry that fills the chip with
+    four-wave blocks (no split-K there, so both forms sum the channel chunks in one chain); the fused bias + noise +
+    LeakyReLU tail included.  On fp32 operands they differ by the per-block operand exponents only."""
+    from rick_amd.op import conv as cv, split as sp
+    n, ci, co, r = 4, 128, 128, 128
+    x = (torch.randn(n, ci, r, r, device=DEV, generator=torch.Generator(DEV).manual_seed(5))).contiguous(memory_format=torch.channels_last)
+    gy = (torch.randn(n, co, r, r, device=DEV, generator=torch.Generator(DEV).manual_seed(6)) * 1e-3).contiguous(memory_format=torch.channels_last)
+    wt = synth_tensor('w8/eq/w', (co, ci, 3, 3)).to(DEV)
+    bias, so = synth_tensor('w8/eq/b', (co,)).to(DEV), synth_tensor('w8/eq/so', (n, co)).abs().to(DEV) + 0.5
+    noise, nw = synth_tensor('w8/eq/noise', (1, 1, r, r)).to(DEV), torch.full((1,), 0.3, device=DEV)
+    wp, wpT = cv._pack(wt, 1.0), cv._pack(wt.transpose(0, 1), 1.0)
+    xs, gs = sp.split_pack(x), sp.split_pack(gy)
+    epi = cv._epilogue(bias, noise, nw, 0.2, 2 ** 0.5)
+    outs = {}
+    for mode in (0, 2):
+        with _conv_tuning(igemm_w8=mode):
+            outs[mode] = (cv._conv_launch(None, wp, co, 3, 3, 1, 1, oscale=so, epi=epi, x_split=xs),
+                          cv._convT_launch(None, wpT, ci, 3, 3, 1, 1, (r, r), x_split=gs),
+                          cv._conv_launch(x, wp, co, 3, 3, 1, 1))
+            torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[2][0]), 'forward on a split image'
+    assert torch.equal(outs[0][1], outs[2][1]), 'data gradient on a split image'
+    assert rel_err(outs[2][2], outs[0][2]) < 2e-6, 'fp32 operands: per-block exponents only'
+    assert not torch.equal(outs[0][2], torch.zeros_like(outs[0][2]))
+
+
 @pytest.mark.parametrize('ci,co', [(512, 256), (64, 96)], ids=['tile_stage', 'element_stage'])
 def test_wgrad_accumulates_into_both_parameter_layouts(ci, co):
     """rick_conv_wgrad_f32 with accumulate = 1 (the trainer's gradient sink): [O, I, kh, kw] and the transposed-conv
