@@ -277,9 +277,13 @@ int rick_saturation_count(unsigned *count, int reset);
  * Used by the parity tests and the same-process A/B micro-benchmarks; returns the previous value, -1 for an unknown key.
  *   RICK_TUNE_IGEMM_W8: 3x3 stride-1 launches with >= RICK_TUNE_IGEMM_W8_MINBLK (default 192) blocks of 128 co x 256
  *   positions run the eight-wave form (conv.hip, igemm_body NW = 8) — 0 (default): never (four-wave 128 x 128 blocks: equal or
- *   faster end to end, conv.hip igemm_w8_plan); 1: fp32 operands with Ci >= 512; 2: wherever the form exists. */
+ *   faster end to end, conv.hip igemm_w8_plan); 1: fp32 operands with Ci >= 512; 2: wherever the form exists.
+ *   RICK_TUNE_SPLITK_FUSED (default 0: measured 8 - 17 us per launch SLOWER than the second-stage launch, conv.hip): 1 = igemm
+ *   split-K launches sum their partial tiles inside the launch — the block that arrives last for an output tile (one atomic
+ *   ticket per tile) adds the partials in split order, exactly the sums of igemm_splitk_reduce_kernel. */
 #define RICK_TUNE_IGEMM_W8 0
 #define RICK_TUNE_IGEMM_W8_MINBLK 1
+#define RICK_TUNE_SPLITK_FUSED 2
 int rick_conv_tuning(int key, int value);
 /* Producers.  rick_upfirdn2d_f32 / rick_upfirdn2d_act_f32 (tail may be NULL) with the extended result handling, channels-last
  * only; `out` may be NULL with ex->no_f32.  The activation adjoint (rick_bias_act_bwd_f32) leaving as split images:

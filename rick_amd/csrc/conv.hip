@@ -236,13 +236,6 @@ static int igemm_tile_positions(const rick_conv_geom *g) { return (g->is >= 2 &&
 static size_t igemm_w8_lds_bytes(const ConvTiling &t) {
     return 4 * CV_WSTEP_BYTES + 4 * (size_t)(t.NPP + 1) * 64 + (size_t)((t.NPP + 3) & ~3) * 4 + (size_t)t.nbe * t.cps * CV_CK * 4 + 64;
 }
-static int g_tune[2] = {0, 192};      // rick_conv_tuning (include/rick_hip.h)
-extern "C" int rick_conv_tuning(int key, int value) {
-    if (key < 0 || key >= (int)(sizeof(g_tune) / sizeof(g_tune[0]))) return -1;
-    const int prev = g_tune[key];
-    g_tune[key] = value;
-    return prev;
-}
 // Measured and NOT the default (round 6, profiles/r06_w8_microbench.txt, batch 8, both forms interleaved in one process): the
 // eight-wave block gains only where the K loop is long AND the operands are converted in the kernel — 512 -> 512 @64^2 fp32
 // operands +4.7 % forward / +4.2 % data gradient, 512 -> 256 +6.1 % — TIES on split images (470.3 vs 469.9 TFLOP/s) and LOSES on
@@ -253,7 +246,7 @@ extern "C" int rick_conv_tuning(int key, int value) {
 // >= 16 channel chunks) measured 168.80 vs 168.79 images/s.  Mode 0 ships; the form stays behind rick_conv_tuning with its
 // parity tests (tests/test_gpu_ops.py: fp64 at 2e-6, bit-equal to the four-wave form on split images).
 static bool igemm_w8_plan(const rick_conv_geom *g, ConvTiling *t, bool pkx) {
-    const int w8 = g_tune[RICK_TUNE_IGEMM_W8], w8_minblk = g_tune[RICK_TUNE_IGEMM_W8_MINBLK];
+    const int w8 = rick_internal_tune(RICK_TUNE_IGEMM_W8), w8_minblk = rick_internal_tune(RICK_TUNE_IGEMM_W8_MINBLK);
     if (w8 == 1 && (pkx || g->Ci < 16 * CV_CK)) return false;
     if (!w8 || g->split != 2 || g->ntaps != 9 || g->is != 1 || (g->Ci & 3) || g->GH < 16 || g->GW < 16) return false;
     if (make_tiling(g, IG_W8_POS, t)) return false;
@@ -286,6 +279,37 @@ static void igemm_plan_split(ConvTiling *t, int ntaps) {
     t->nsplit = cdiv(t->nchunks, best_cps);
 }
 
+
+// ==========================================================================================
+// Second stage of a split-K launch, one float4 (4 consecutive output channels of one pixel): alpha, output scale and the fused
+// bias / noise / LeakyReLU tail on the summed partials.  ONE definition for the stand-alone reduce kernel and the in-launch
+// fix-up (the block that arrives last for a tile, cv_splitk_arrive): both forms produce the same bits.
+__device__ __forceinline__ float4 splitk_finish4(float4 s, unsigned n, unsigned co, unsigned gy, unsigned gx, const rick_conv_geom &g,
+                                                 const float *__restrict__ oscale, const rick_conv_epilogue &epi, float nwv) {
+    float4 sc = make_float4(g.alpha, g.alpha, g.alpha, g.alpha);
+    if (oscale) {
+        const float4 os4 = *reinterpret_cast<const float4 *>(oscale + (size_t)n * g.Co + co);
+        sc = make_float4(os4.x, os4.y, os4.z, os4.w);
+        s.x *= g.alpha; s.y *= g.alpha; s.z *= g.alpha; s.w *= g.alpha;
+    }
+    float4 v = make_float4(s.x * sc.x, s.y * sc.y, s.z * sc.z, s.w * sc.w);
+    if (epi.bias) {
+        const float4 bv = *reinterpret_cast<const float4 *>(epi.bias + co);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    }
+    if (epi.noise) {
+        const float nv = nwv * epi.noise[(size_t)(epi.noise_nb == 1 ? 0 : n) * g.OH * g.OW +
+                                         (size_t)(gy * g.os + g.oy0) * g.OW + gx * g.os + g.ox0];
+        v.x += nv; v.y += nv; v.z += nv; v.w += nv;
+    }
+    if (epi.act) {
+        v.x = (v.x > 0.f ? v.x : v.x * epi.slope) * epi.gain;
+        v.y = (v.y > 0.f ? v.y : v.y * epi.slope) * epi.gain;
+        v.z = (v.z > 0.f ? v.z : v.z * epi.slope) * epi.gain;
+        v.w = (v.w > 0.f ? v.w : v.w * epi.slope) * epi.gain;
+    }
+    return v;
+}
 
 // ==========================================================================================
 // Forward / data-gradient kernel.
@@ -350,6 +374,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     }
     const int c_begin = split * t.cps;
     const int c_end = c_begin + t.cps < t.nchunks ? c_begin + t.cps : t.nchunks;
+    const int pt_lin = pt;
     const int tx_i = pt % t.ntx;
     pt /= t.ntx;
     const int ty_i = pt % t.nty;
@@ -943,6 +968,8 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         if (bid == 0 && threadIdx.x == 0) *reinterpret_cast<cv_split_hdr *>(epi.split_hdr) = h;
         so_scale = cv_uniform(h.scale);
     }
+    const __amdgpu_buffer_rsrc_t ws_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        ws, 0, t.nsplit > 1 ? (unsigned)((int64_t)t.nsplit * g.N * g.GH * g.GW * g.Co * 4) : 0u, 0x00020000);
     auto epilogue = [&](auto HAS_OS, auto HAS_EP) {
         constexpr bool OS = decltype(HAS_OS)::value;
         constexpr bool EP = decltype(HAS_EP)::value;   // fused bias (+ noise) + LeakyReLU tail (rick_conv_epilogue)
@@ -959,7 +986,11 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                     const int co = cot * CV_BM + wm * 64 + i * 16 + kg * 4;
                     if (co >= g.Co) continue;
                     // (partial sums leave the block without its operand exponents: blocks of one output tile may differ)
-                    if (covec) {
+                    if (covec && t.tickets) {      // in-launch fix-up: WRITE-THROUGH (sc1) stores, so that no block pays a release fence
+                        const f32x4 pv = {acc[i][j][0] * unscale, acc[i][j][1] * unscale, acc[i][j][2] * unscale, acc[i][j][3] * unscale};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(igemm_u32x4, pv), ws_rsrc,
+                                                               (unsigned)((wrow + co - ws) * 4), 0, 16 /* sc1 */);
+                    } else if (covec) {
                         *reinterpret_cast<float4 *>(wrow + co) =
                             make_float4(acc[i][j][0] * unscale, acc[i][j][1] * unscale, acc[i][j][2] * unscale, acc[i][j][3] * unscale);
                     } else {
@@ -1049,6 +1080,46 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     cv_sat_report(satm);
     if (epi.split_out) cv_sat_check(so_amax, so_scale);
     if (epi.amax && t.nsplit == 1) cv_amax_publish(out_amax, epi.amax, reinterpret_cast<float *>(smem));     // (split-K: the second stage measures)
+    if (VEC && t.nsplit > 1 && t.tickets) {
+        // ---- split-K fix-up inside the launch (rick_conv_tuning RICK_TUNE_SPLITK_FUSED; host: Co % 4 == 0, 16-byte aligned
+        // buffers).  The block that arrives last for this output tile sums the nsplit partial tiles in split order — the order
+        // and arithmetic of igemm_splitk_reduce_kernel — and applies the second stage; 8 positions x 32 float4 of the 128-channel
+        // tile per pass (512-byte runs per position).  MEASURED SLOWER than the second-stage launch and switched off (round 6,
+        // profiles/r06_splitk_fused.txt): with a release fence per block +7 ... +36 us per launch (every block writes back its
+        // XCD's L2), with write-through stores and no release still +8 (4^2) ... +17 us (8^2, 16^2): ONE block reads the tile's
+        // nsplit partial tiles (0.5 - 1 MB) at the 60 - 100 GB/s a single block gets across XCDs, where the second-stage kernel
+        // spreads the same bytes over the chip in 6 us.
+        if (cv_splitk_arrive<true>(t.tickets + cot * npos_tiles + pt_lin, t.nsplit, reinterpret_cast<unsigned *>(smem))) {
+            const size_t per4 = (size_t)g.N * g.GH * g.GW * g.Co / 4;
+            const float4 *ws4 = reinterpret_cast<const float4 *>(ws);
+            float ram = 0.f;
+            for (int it = threadIdx.x; it < NJ * 32 * 32; it += NTHR) {
+                const int pos = it >> 5, co = cot * CV_BM + (it & 31) * 4;
+                const int px = pos & tw_mask, py = (pos >> t.tw_log2) & th_mask, nbi = pos >> (t.tw_log2 + t.th_log2);
+                const int n = n0 + nbi, gy = gy0 + py, gx = gx0 + px;
+                if (co >= g.Co || nbi >= t.nbe || n >= g.N || gy >= g.GH || gx >= g.GW) continue;
+                const float4 *src = ws4 + ((((size_t)n * g.GH + gy) * g.GW + gx) * g.Co + co) / 4;
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                int sp = 0;
+                for (; sp + 4 <= t.nsplit; sp += 4) {          // four loads in flight, added in split order
+                    const float4 v0 = src[(size_t)sp * per4], v1 = src[(size_t)(sp + 1) * per4], v2 = src[(size_t)(sp + 2) * per4],
+                                 v3 = src[(size_t)(sp + 3) * per4];
+                    s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+                    s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+                    s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+                    s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+                }
+                for (; sp < t.nsplit; sp++) {
+                    const float4 v0 = src[(size_t)sp * per4];
+                    s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+                }
+                const float4 v = splitk_finish4(s, (unsigned)n, (unsigned)co, (unsigned)gy, (unsigned)gx, g, oscale, epi, nwv);
+                *reinterpret_cast<float4 *>(out + (((int64_t)n * g.OH + gy * g.os + g.oy0) * g.OW + gx * g.os + g.ox0) * g.Co + co) = v;
+                ram = amax4(ram, v);
+            }
+            if (epi.amax) cv_amax_publish(ram, epi.amax, reinterpret_cast<float *>(smem) + 16);
+        }
+    }
 }
 
 template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT, int WDMA = 0, bool PKX = false, int NW = 4>
@@ -1122,28 +1193,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float *_
                 const float4 v = src[(size_t)sp * (per / 4)];
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
-            float4 sc = make_float4(g.alpha, g.alpha, g.alpha, g.alpha);
-            if (oscale) {
-                const float4 os4 = *reinterpret_cast<const float4 *>(oscale + (size_t)n * g.Co + co);
-                sc = make_float4(os4.x, os4.y, os4.z, os4.w);
-                s.x *= g.alpha; s.y *= g.alpha; s.z *= g.alpha; s.w *= g.alpha;
-            }
-            float4 v = make_float4(s.x * sc.x, s.y * sc.y, s.z * sc.z, s.w * sc.w);
-            if (epi.bias) {
-                const float4 bv = *reinterpret_cast<const float4 *>(epi.bias + co);
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            }
-            if (epi.noise) {
-                const float nv = nwv * epi.noise[(size_t)(epi.noise_nb == 1 ? 0 : n) * g.OH * g.OW +
-                                                 (size_t)(gy * g.os + g.oy0) * g.OW + gx * g.os + g.ox0];
-                v.x += nv; v.y += nv; v.z += nv; v.w += nv;
-            }
-            if (epi.act) {
-                v.x = (v.x > 0.f ? v.x : v.x * epi.slope) * epi.gain;
-                v.y = (v.y > 0.f ? v.y : v.y * epi.slope) * epi.gain;
-                v.z = (v.z > 0.f ? v.z : v.z * epi.slope) * epi.gain;
-                v.w = (v.w > 0.f ? v.w : v.w * epi.slope) * epi.gain;
-            }
+            const float4 v = splitk_finish4(s, n, co, gy, gx, g, oscale, epi, nwv);
             *reinterpret_cast<float4 *>(out + o) = v;
             if (AMAX) ram = amax4(ram, v);
         } else {
@@ -1317,6 +1367,8 @@ static int igemm_run(const float *x, const void *packed_w, float *out, const flo
     float *ws = (float *)workspace;
     const unsigned char *wp = (const unsigned char *)packed_w;
     const bool vec = (g->Ci & 3) == 0;
+    if (t.nsplit > 1 && (g->Co & 3) == 0 && vec && (int64_t)t.nsplit * g->N * g->GH * g->GW * g->Co * 4 < (1LL << 32))   // second stage inside the launch?
+        t.tickets = rick_internal_tickets(t.ntx * t.nty * t.ntn * t.ncot, stream);     // (NULL unless rick_conv_tuning switched it on)
     int rc;
     if (g->split == 2) {
         if (vec) rc = launch_igemm<2, true>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi, pkx);
@@ -1326,7 +1378,7 @@ static int igemm_run(const float *x, const void *packed_w, float *out, const flo
         else rc = launch_igemm<1, false>((unsigned)nwg, lds, st, x, wp, out, iscale, oscale, ws, g, t, epi, pkx);
     }
     if (rc) return rc;
-    if (t.nsplit > 1) launch_splitk_reduce(ws, out, oscale, g, t.nsplit, st, epi);
+    if (t.nsplit > 1 && !t.tickets) launch_splitk_reduce(ws, out, oscale, g, t.nsplit, st, epi);
     RICK_LAUNCH_STATUS();
 }
 

@@ -300,6 +300,41 @@ __device__ __forceinline__ void cv_amax_publish(float m, float *word, float *cv_
         if (bits > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(w, bits);
     }
 }
+// ---- in-launch split-K fix-up: arrival ticket (split.hip: rick_internal_tickets) -----------------------------------------------
+// Called by every thread of a block AFTER it has stored its partial tile with plain stores.  Returns true in every thread of
+// the block that arrives LAST for this tile; that block may then read all partial tiles with plain loads.  The hand-off is the
+// placement-independent counter form of the guide (cdna_hip_programming.md, Projection GEMM item 2): every storing wave drains
+// its stores, the block's barrier, ONE agent-scope release by lane 0 (+ an explicit vmcnt(0): ROCm 7.2 can drop the fence's own),
+// a relaxed agent-scope add; the last arriver: one agent-scope acquire + vmcnt(0), then the barrier that lets the other waves
+// load.  The counter goes back to 0 for the next launch that is handed this range (stream order makes that store visible).
+// `flag`: 4 bytes of LDS nobody else uses until the block ends.
+extern "C" unsigned *rick_internal_tickets(int n, void *stream);
+extern "C" int rick_internal_tune(int key);          // current value of a rick_conv_tuning key (split.hip)
+// WT: the partial tile was stored WRITE-THROUGH (sc1 stores: every byte of it) — the bytes are in memory once the storing
+// wave's vmcnt has drained, and no release fence (an L2 write-back per block: measured +13 ... +43 us on a 64 ... 512-block
+// launch, profiles/r06_splitk_fused.txt) is needed; the acquire of the last arriver stays.
+template <bool WT = false>
+__device__ __forceinline__ bool cv_splitk_arrive(unsigned *counter, int nsplit, unsigned *flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (!WT) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned last = old == (unsigned)(nsplit - 1) ? 1u : 0u;
+        if (last) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    return *flag != 0u;
+}
+
 #define CV_DEFINE_SAT_ACCESSOR(fn)                                                                    \
     extern "C" int fn(unsigned *count, int reset) {                                                   \
         unsigned *p = nullptr, v = 0, z = 0;                                                          \

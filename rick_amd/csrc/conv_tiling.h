@@ -16,6 +16,7 @@ struct ConvTiling {
     int nsplit, cps;            // igemm split-K over channel chunks: splits, chunks per split
     int pkb;                    // wgrad: bit of the patch pixel index that keys the slot swizzle
     int debug;                  // ablation switches for tools/bench_conv.py (RICK_CONV_DEBUG); 0 in production
+    unsigned *tickets;          // igemm split-K: arrival counters, one per output tile (NULL: partial sums only, second-stage launch)
 };
 
 // Ablation switches (tools/bench_conv.py) exist only in builds made with -DRICK_ABLATION; the production library never
@@ -74,6 +75,7 @@ static int make_tiling(const rick_conv_geom *g, int tile_positions, ConvTiling *
     t->cps = t->nchunks;
     t->pkb = (g->is <= 2 && tw == 4) ? 3 : (g->is == 2 && tw == 3) ? 5 : 2;   // (tools/lds_sim.py)
     t->debug = ablation_env("RICK_CONV_DEBUG", 0);
+    t->tickets = nullptr;
     return 0;
 }
 

@@ -61,6 +61,59 @@ __global__ __launch_bounds__(256) void split_unpack_kernel(const unsigned char *
     }
 }
 
+// ---- kernel-form switches (include/rick_hip.h: rick_conv_tuning) -------------------------------------------------------------------
+static int g_tune[3] = {0, 192, 0};
+extern "C" int rick_conv_tuning(int key, int value) {
+    if (key < 0 || key >= (int)(sizeof(g_tune) / sizeof(g_tune[0]))) return -1;
+    const int prev = g_tune[key];
+    g_tune[key] = value;
+    return prev;
+}
+extern "C" int rick_internal_tune(int key) { return g_tune[key]; }
+
+// ---- arrival tickets of the in-launch split-K fix-up (conv_common.h: cv_splitk_arrive) ------------------------------------------
+// One zero-initialised, SELF-RESETTING 32-bit counter per output tile of a split-K launch: the block whose add returns
+// nsplit - 1 is the last to arrive, sums the partial tiles in split order and puts the counter back to 0.  The counters live in
+// one device buffer per GPU, zeroed once when it is created; a launch takes a range that no other launch in flight can hold:
+//   * launches issued into a CAPTURING stream keep their range for the life of the process (graph replays re-use it; replays of
+//     one node are ordered) — a bump allocator over the lower half that never wraps;
+//   * eager launches take theirs from a ring over the upper half (2^19 counters: more than 8 000 launches in flight).
+// NULL (no buffer yet while a capture is running, range exhausted, any runtime error): the caller runs its second-stage kernel.
+#define TK_TOTAL (1u << 20)
+#define TK_MAXDEV 16
+static unsigned *g_tk_buf[TK_MAXDEV];
+static unsigned g_tk_perm[TK_MAXDEV], g_tk_ring[TK_MAXDEV];
+extern "C" unsigned *rick_internal_tickets(int n, void *stream) {
+    int dev = 0;
+    if (!g_tune[RICK_TUNE_SPLITK_FUSED] || n < 1 || n > (int)(TK_TOTAL / 4) || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TK_MAXDEV) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    const bool capturing = cs != hipStreamCaptureStatusNone;
+    if (!g_tk_buf[dev]) {
+        if (capturing) return nullptr;          // (allocation is not a capturable operation: the first eager launch creates the buffer)
+        unsigned *p = nullptr;
+        if (hipMalloc((void **)&p, TK_TOTAL * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, TK_TOTAL * sizeof(unsigned)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        g_tk_buf[dev] = p;
+    }
+    const unsigned n32 = ((unsigned)n + 31u) & ~31u;      // whole 128-byte lines per launch
+    if (capturing) {
+        if (g_tk_perm[dev] + n32 > TK_TOTAL / 2) return nullptr;
+        unsigned *r = g_tk_buf[dev] + g_tk_perm[dev];
+        g_tk_perm[dev] += n32;
+        return r;
+    }
+    if (g_tk_ring[dev] + n32 > TK_TOTAL / 2) g_tk_ring[dev] = 0;
+    unsigned *r = g_tk_buf[dev] + TK_TOTAL / 2 + g_tk_ring[dev];
+    g_tk_ring[dev] += n32;
+    return r;
+}
+
 CV_DEFINE_SAT_ACCESSOR(rick_sat_split)
 extern "C" int rick_sat_upfirdn2d(unsigned *, int);
 extern "C" int rick_sat_elementwise(unsigned *, int);

@@ -181,7 +181,7 @@ def test_conv2d_vs_fp64(case):
 def _conv_tuning(**kv):
     """rick_conv_tuning (include/rick_hip.h) for the duration of a test: which kernel FORM a launch takes, never its values."""
     from rick_amd._lib import lib
-    keys = {'igemm_w8': 0, 'igemm_w8_minblk': 1}
+    keys = {'igemm_w8': 0, 'igemm_w8_minblk': 1, 'splitk_fused': 2}
     prev = {k: lib.rick_conv_tuning(keys[k], v) for k, v in kv.items()}
     try:
         yield
@@ -245,6 +245,37 @@ def test_igemm_eight_wave_form_bit_equal_on_split_images():
     assert torch.equal(outs[0][1], outs[2][1]), 'data gradient on a split image'
     assert rel_err(outs[2][2], outs[0][2]) < 2e-6, 'fp32 operands: per-block exponents only'
     assert not torch.equal(outs[0][2], torch.zeros_like(outs[0][2]))
+
+
+@pytest.mark.parametrize('case', [('s1_4', 4, 512, 512, 4, 3, 1, 1), ('s1_8', 4, 512, 512, 8, 3, 1, 1), ('s1_16', 8, 512, 512, 16, 3, 1, 1),
+                                  ('s2_17', 4, 512, 512, 17, 3, 2, 0), ('k1_8', 8, 512, 512, 8, 1, 1, 0), ('ragged', 3, 160, 200, 9, 3, 1, 1)],
+                         ids=lambda c: c[0])
+def test_splitk_fixup_inside_the_launch_equals_second_stage_kernel(case):
+    """Split-K launches of the igemm family (the 4^2 ... 16^2 layers, model_probe_tune.py:400-410): the block that arrives last
+    for an output tile sums the partial tiles in split order and applies alpha / demodulation / the fused tail — bit-equal to
+    the stand-alone second-stage kernel (rick_conv_tuning RICK_TUNE_SPLITK_FUSED = 0), three launches in a row on the same
+    self-resetting tickets; and both within 2e-6 of fp64."""
+    from rick_amd.op import conv as cv
+    tag, n, ci, co, r, k, s, p = case
+    x = synth_tensor(f'skf/{tag}/x', (n, ci, r, r)).to(DEV).contiguous(memory_format=torch.channels_last)
+    wt = synth_tensor(f'skf/{tag}/w', (co, ci, k, k)).to(DEV)
+    si, so = synth_tensor(f'skf/{tag}/si', (n, ci)).abs().to(DEV) + 0.5, synth_tensor(f'skf/{tag}/so', (n, co)).abs().to(DEV) + 0.5
+    bias = synth_tensor(f'skf/{tag}/b', (co,)).to(DEV)
+    ro = (r + 2 * p - k) // s + 1
+    noise, nw = synth_tensor(f'skf/{tag}/noise', (1, 1, ro, ro)).to(DEV), torch.full((1,), 0.3, device=DEV)
+    wp = cv._pack(wt, 0.05)
+    epi = cv._epilogue(bias, noise, nw, 0.2, 2 ** 0.5) if co % 4 == 0 else None
+    outs = {}
+    for fused in (0, 1):
+        with _conv_tuning(splitk_fused=fused):
+            outs[fused] = [(cv._conv_launch(x, wp, co, k, k, s, p, iscale=si, oscale=so, alpha=0.05, epi=epi), cv._conv_launch(x, wp, co, k, k, s, p))
+                           for _ in range(3)]
+            torch.cuda.synchronize()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(outs[1][0][0], outs[1][2][0])
+    ref = F.conv2d(x.double().cpu(), wt.double().cpu() * 0.05, stride=s, padding=p)
+    assert rel_err(outs[1][0][1], ref) < 2e-6
 
 
 @pytest.mark.parametrize('ci,co', [(512, 256), (64, 96)], ids=['tile_stage', 'element_stage'])
