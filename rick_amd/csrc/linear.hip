@@ -155,13 +155,15 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float *__restri
         }
 }
 
-// rows of W per block: enough blocks to fill the chip (>= ~512), at least 8 rows each
+// rows of W per block: enough blocks to cover the chip (>= ~256), at least 32 rows each — every row slice writes and the second
+// stage re-reads B x K partial sums, so 8-row slices moved 2 x 16 MB of partials next to the 16 MB weight stream of the
+// 8192 -> 512 layer at B = 8; 32 rows: 2 x 4 MB
 static int ln_dgrad_rows(int K, int O) {
     const int kb = cdiv(K, 1024);
-    int slices = 512 / kb;
+    int slices = 256 / kb;
     if (slices < 1) slices = 1;
     int R = cdiv(O, slices);
-    if (R < 8) R = 8;
+    if (R < 32) R = 32;
     if (R > 256) R = 256;
     return R;
 }

@@ -764,6 +764,13 @@ __global__ __launch_bounds__(512) void conv_wgrad8_kernel(const float *__restric
     // ---- operand exponents (PK = 0; conv_common.h): amax of gy * ascale and x * bscale over 4 of the block's tiles x 2 staging
     // items each, then 2^e is folded into the scale tables; split images bring theirs in the header
     float punscale, xsa = 1.f, xsb = 1.f;
+    [[maybe_unused]] float thr_a8 = 3.0e38f, thr_b8 = 3.0e38f;      // (RICK_ABLATION: saturation thresholds, see the exponent block)
+    [[maybe_unused]] unsigned long long sat_bits8 = 0;
+#ifdef RICK_ABLATION
+#define WG_TRACK8(v, thr) sat_bits8 |= __builtin_amdgcn_ballot_w64(fmaxf(fmaxf(fabsf((v).x), fabsf((v).y)), fmaxf(fabsf((v).z), fabsf((v).w))) > (thr))
+#else
+#define WG_TRACK8(v, thr) (void)0
+#endif
     if constexpr (PK == 3) {
         punscale = cv_uniform(ascale[1] * bscale[1]);
     } else {
@@ -799,8 +806,18 @@ __global__ __launch_bounds__(512) void conv_wgrad8_kernel(const float *__restric
         xsa = cv_uniform(sa);
         xsb = cv_uniform(sb);
         __syncthreads();                                         // every thread has read `red`
+#ifdef RICK_ABLATION
+        // saturation tracking like the four-wave kernel's (WG_TRACK above; experiment build only — tools/stability.py runs on it):
+        // thr = 65504 / (largest scale x exponent of the block's table); a converted item above it sets the wave's SGPR mask
+        float ta = 0.f, tb = 0.f;
+        for (int i = threadIdx.x; i < g.N * CV_BM; i += 512) ta = fmaxf(ta, fabsf(sA[i] *= sa));
+        for (int i = threadIdx.x; i < g.N * CV_CK; i += 512) tb = fmaxf(tb, fabsf(sB[i] *= sb));
+        thr_a8 = cv_uniform(65504.f / fmaxf(block_amax(ta, red), 1e-30f));
+        thr_b8 = cv_uniform(65504.f / fmaxf(block_amax(tb, red + 8), 1e-30f));
+#else
         for (int i = threadIdx.x; i < g.N * CV_BM; i += 512) sA[i] *= sa;
         for (int i = threadIdx.x; i < g.N * CV_CK; i += 512) sB[i] *= sb;
+#endif
         __syncthreads();
     }
     float4 sa_cv = make_float4(1.f, 1.f, 1.f, 1.f), sb_cv = sa_cv;   // scale vectors of the tile whose registers are held
@@ -819,6 +836,7 @@ __global__ __launch_bounds__(512) void conv_wgrad8_kernel(const float *__restric
                 *reinterpret_cast<float2 *>(buf + WG_GY_BYTES + g_lds[k]) = make_float2(gq[k].z, gq[k].w);
             } else {
                 uint2 hi, lo;
+                WG_TRACK8(gq[k], thr_a8);
                 if constexpr (FAST == 2) split4v_mix<2>(gq[k], sa_cv, hi, lo);
                 else split4s_mix<2>(gq[k], xsa, hi, lo);
                 *reinterpret_cast<uint2 *>(buf + g_lds[k]) = hi;
@@ -832,6 +850,7 @@ __global__ __launch_bounds__(512) void conv_wgrad8_kernel(const float *__restric
                 *reinterpret_cast<float2 *>(buf + 2 * WG_GY_BYTES + (t.NPP + 1) * 64 + p_lds[k]) = make_float2(pq[k].z, pq[k].w);
             } else {
                 uint2 hi, lo;
+                WG_TRACK8(pq[k], thr_b8);
                 if constexpr (FAST == 2) split4v_mix<2>(pq[k], sb_cv, hi, lo);
                 else split4s_mix<2>(pq[k], xsb, hi, lo);
                 *reinterpret_cast<uint2 *>(buf + 2 * WG_GY_BYTES + p_lds[k]) = hi;
@@ -895,6 +914,9 @@ __global__ __launch_bounds__(512) void conv_wgrad8_kernel(const float *__restric
             *reinterpret_cast<float4 *>(wsb + (tt * CV_CK + ci) * CV_BM + co) =
                 make_float4(acc[i][tt][0] * punscale, acc[i][tt][1] * punscale, acc[i][tt][2] * punscale, acc[i][tt][3] * punscale);
         }
+#ifdef RICK_ABLATION
+    if (sat_bits8 != 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_cv_sat, 1u);
+#endif
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ gw,

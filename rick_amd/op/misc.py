@@ -298,8 +298,12 @@ class _ToRGBFork(Function):
         c = w.shape[1]
         gw, gs, gb = _torgb_param_grads(ctx, g, x, w, s)
         # In place only into a buffer its producer marked as exclusively owned (autograd's contract forbids modifying a
-        # gradient input that somebody else may hold: a tensor hook, retain_grad() on the forked activation, a backward that
-        # returns one tensor for two inputs).  The mark is consumed; anything else is copied first.
+        # gradient input that somebody else may hold: retain_grad() on the forked activation, a backward that returns one
+        # tensor for two inputs — neither carries the mark).  The mark is consumed; anything else is copied first (ADVICE
+        # round 4).  NOT covered: a tensor hook registered on the forked activation receives this same marked
+        # tensor before the node runs; a hook that KEEPS its argument (instead of reading or replacing it) then sees the ToRGB
+        # contribution added into it.  Nothing in the package registers such a hook (rick_amd.dist hooks parameters, whose
+        # gradients never pass here); a caller who does must clone in the hook.
         ok = (gx_next.__dict__.pop('_rick_owned', False) and gx_next.dtype == torch.float32
               and tuple(gx_next.shape) == (n, c, h, wd) and gx_next.data_ptr() % 16 == 0
               and gx_next.is_contiguous(memory_format=torch.channels_last))

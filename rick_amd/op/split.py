@@ -76,6 +76,8 @@ class SplitImage:
 def hand(t, name, value):
     """Attach a hand-over attribute (`_rick_split`, `_rick_amax`, `_rick_bound`) to tensor `t` together with what it
     describes: the tensor's version counter and address at this moment."""
+    if t.is_inference():        # inference tensors track no version counter (torch.inference_mode()): nothing is handed over,
+        return                  # the consumer measures / packs again (ADVICE round 5)
     setattr(t, name, (value, t._version, t.data_ptr()))
 
 
@@ -87,6 +89,8 @@ def taken(t, name):
     if ent is None:
         return None
     value, version, address = ent
+    if t.is_inference():
+        return None
     return value if (t._version == version and t.data_ptr() == address) else None
 
 

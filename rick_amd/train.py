@@ -495,7 +495,7 @@ class RickTrainer:
     def _style_stamp(self):
         """What the pooled rows are valid for: the mapping network's weights as loaded (load_state_dict copies in place and
         bumps _version; the optimiser never touches them)."""
-        return tuple((p._version, p.data_ptr()) for p in self.g.style.parameters())
+        return tuple((None if p.is_inference() else p._version, p.data_ptr()) for p in self.g.style.parameters())
 
     def _fill_latent_pool(self, ent):
         with torch.no_grad():

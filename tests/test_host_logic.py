@@ -349,3 +349,22 @@ def test_data_parallel_world4_buckets_and_uneven_fisher_shards():
                 assert np.array_equal(o[1][k], ref[1][k])
             assert o[2].keys() == ref[2].keys() and all(np.array_equal(o[2][k], ref[2][k]) for k in ref[2])
             assert o[3].keys() == ref[3].keys() and all(np.array_equal(o[3][k], ref[3][k]) for k in ref[3])
+
+
+def test_hand_over_attributes_under_inference_mode():
+    """op/split.py hand() / taken() read tensor._version, which inference tensors do not have: under
+    torch.inference_mode() nothing is attached and nothing is returned — the consumer measures again — instead of a crash."""
+    import torch
+    from rick_amd.op import split as sp
+    with torch.inference_mode():
+        t = torch.zeros(4)
+        sp.hand(t, '_rick_amax', 1.0)
+        assert sp.taken(t, '_rick_amax') is None
+        u = torch.ones(4)
+        sp.rehand(t, u)
+        assert sp.taken(u, '_rick_amax') is None
+    v = torch.zeros(4)
+    sp.hand(v, '_rick_amax', 2.0)
+    assert sp.taken(v, '_rick_amax') == 2.0
+    v.add_(1)
+    assert sp.taken(v, '_rick_amax') is None
