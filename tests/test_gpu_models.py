@@ -2,6 +2,7 @@
 Fisher estimate and one optimiser step against goldens captured from the reference modules
 (tests/golden/*.npz) and against the CPU oracle.  Run with `-m gpu`."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -269,6 +270,154 @@ def test_trainer_steps_match_oracle():
     assert rel(pen, pen_ref.detach()) < 2e-4
     assert rel(tr.mean_path_length, mean_ref) < 1e-4
     tr.ema_step()
+
+
+def test_teacher_forced_steps_256_batch4_match_oracle():
+    """BASELINE config 2's shapes (256 px, batch 4, path batch 2), every step type of the loop body teacher-forced: before each of
+    the D step, the R1 step, the G step and the path-length step (train_dynamic_update_prune.py:401-589) the DEVICE's current
+    weights are loaded into the fp64 CPU oracle, so each comparison sees ONE step's error — the cumulative `rick256.npz` test
+    (test_rick_loop_body_256_batch4_vs_reference) has to allow for two beta1 = 0 Adam trajectories drifting apart at
+    noise-level gradient signs, this one does not.  Asserted: losses 1e-4, R1 value 1e-3, path penalty / mean path length 1e-3,
+    per-key gradient L2 2e-4 for the D and G steps, 5e-4 for R1, 3e-3 for the path-length step (noise-strength scalars 1e-2),
+    the fused mask + Adam kernel 2e-6 against the restated torch.optim.Adam on the device's own gradients and moments (second
+    Adam step of each optimiser included), freeze / prune masks on.  Measured on MI355X (round 6): worst per-key gradient L2
+    3.5e-5 (D), 1.0e-4 (R1), 1.0e-5 (G), 1.4e-3 (path length: convs.9 / convs.10 weights, where the two second-order terms
+    nearly cancel; its noise-strength scalar 4.3e-3).  Oracle passes: fp64, 32 host threads, 14-27 s each."""
+    import time
+    from oracle.model_ref import discriminator_ref, generator_ref
+    from oracle.train_ref import (adam_step_ref, d_logistic_loss_ref, d_r1_loss_ref, g_nonsaturating_loss_ref,
+                                  g_path_regularize_ref)
+    from rick_amd.train import RickTrainer, TrainConfig, build_mask, d_optim_filter, g_optim_filter
+    size, B = 256, 4
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(32, max(1, (os.cpu_count() or 8))))
+    try:
+        cfg = TrainConfig(size=size, batch=B, warmup_iter=0)
+        pb = max(1, B // cfg.path_batch_shrink)
+        g, d = build(size)
+        g_ema, d_ema = build(size)
+        tr = RickTrainer(cfg, g, d, g_ema, d_ema)
+        z = synth_latents(B, seed=11)
+        real = synth_reals(B, size=size, seed=11)
+        sg0 = synth_state_dict(generator_shapes(size))
+        noises = [sg0[f'noises.noise_{i}'].double() for i in range(g.num_layers)]
+        dev_noises = [n.float().to(DEV) for n in noises]
+        pl_noise = synth_tensor('plnoise/teacher256', (pb, 3, size, size))
+        freeze_d = {'convs.1.conv1.0.weight': np.array([1, 5]), 'convs.1.conv1.1.bias': np.array([1, 5])}
+        zero_d = {'convs.2.skip.1.weight': np.array([0, 3])}
+        tr.d_optim.set_mask(build_mask(tr.d_flat, freeze_d, zero_d))
+        freeze_g = {'convs.0.conv.weight': np.array([2, 7])}
+        zero_g = {'convs.1.conv.modulation.weight': np.array([4]), 'convs.1.conv.modulation.bias': np.array([4])}
+        tr.g_optim.set_mask(build_mask(tr.g_flat, freeze_g, zero_g))
+        timing, worst = {}, {}
+
+        def oracle_sd(module, grad_keys):
+            sd = {k: v.detach().double().cpu() for k, v in module.state_dict().items()}
+            for k in grad_keys:
+                sd[k].requires_grad_(True)
+            return sd
+
+        def masked(p, gr, k, freeze, zero):
+            p, gr = p.clone(), gr.clone()
+            for tab, kill_p in ((freeze, False), (zero, True)):
+                if k in tab:
+                    sl = (slice(None), tab[k]) if p.ndim == 5 else (tab[k],)
+                    gr[sl] = 0
+                    if kill_p:
+                        p[sl] = 0
+            return p, gr
+
+        def check_step(tag, flat, opt, state, ref_grads, keys, lr, b2, step, freeze, zero, module, gtol):
+            """device gradients vs the oracle's; then the fused mask + Adam kernel vs the restated Adam on the DEVICE's gradients
+            and the moments the device held before the step (`state`)."""
+            after = dict(module.named_parameters())
+            errs = []
+            for k in keys:
+                lo, hi = flat.segment(k)
+                p0, g_ref = masked(state['p'][k], ref_grads[k], k, freeze, zero)
+                g_dev = flat.grad[lo:hi].view(p0.shape).double().cpu()
+                errs.append((l2rel(g_dev, g_ref) / (gtol if g_ref.numel() >= 16 else 1e-2), l2rel(g_dev, g_ref), k))   # scalars: cancellation
+                m0, v0 = state['m'][lo:hi].view(p0.shape), state['v'][lo:hi].view(p0.shape)
+                exp, _, _ = adam_step_ref(p0, g_dev, m0, v0, step, lr, 0.0, b2)
+                assert rel(after[k], exp) < 2e-6, (tag, 'adam', k)
+            errs.sort(reverse=True)
+            worst[tag] = [(k, f'{e:.2e}') for _, e, k in errs[:3]]
+            assert errs[0][0] < 1.0, (tag, 'per-key gradient L2 beyond its bound', worst[tag])
+
+        def snapshot(module, opt, keys):
+            named = dict(module.named_parameters())
+            return {'p': {k: named[k].detach().double().cpu().clone() for k in keys},
+                    'm': opt.m.detach().double().cpu().clone(), 'v': opt.v.detach().double().cpu().clone()}
+
+        dkeys = [k for k, _ in d.named_parameters() if d_optim_filter(k)]
+        gkeys = [k for k, _ in g.named_parameters() if g_optim_filter(k)]
+        d_lr, d_b2 = cfg.lr * 16 / 17, 0.99 ** (16 / 17)
+        g_lr, g_b2 = cfg.lr * 4 / 5, 0.99 ** (4 / 5)
+
+        # ---- D step (train...:401-440)
+        t0 = time.time()
+        sg = oracle_sd(g, [])
+        sd = oracle_sd(d, dkeys)
+        with torch.no_grad():
+            fake, _ = generator_ref(sg, [z.double()], size=size, noise=noises)
+        fp, _ = discriminator_ref(sd, fake, size=size)
+        rp, _ = discriminator_ref(sd, real.double(), size=size)
+        dl = d_logistic_loss_ref(rp, fp)
+        gd = dict(zip(dkeys, torch.autograd.grad(dl, [sd[k] for k in dkeys])))
+        timing['d oracle'] = time.time() - t0
+        st = snapshot(d, tr.d_optim, dkeys)
+        d_loss = tr.d_step(real.to(DEV), [z.to(DEV)], g_noise=dev_noises)
+        assert rel(d_loss, dl.detach()) < 1e-4, ('d_loss', float(d_loss), float(dl))
+        check_step('d', tr.d_flat, tr.d_optim, st, gd, dkeys, d_lr, d_b2, 1, freeze_d, zero_d, d, 2e-4)
+        del fp, rp, dl, gd, fake
+
+        # ---- R1 step (:462-493) on the discriminator the device now holds
+        t0 = time.time()
+        sd = oracle_sd(d, dkeys)
+        rr = real.double().requires_grad_(True)
+        rp, _ = discriminator_ref(sd, rr, size=size)
+        r1_ref = d_r1_loss_ref(rp, rr)
+        gr1 = dict(zip(dkeys, torch.autograd.grad(cfg.r1 / 2 * r1_ref * cfg.d_reg_every + 0 * rp[0].sum(), [sd[k] for k in dkeys])))
+        timing['r1 oracle'] = time.time() - t0
+        st = snapshot(d, tr.d_optim, dkeys)
+        r1 = tr.r1_step(real.to(DEV))
+        assert rel(r1, r1_ref.detach()) < 1e-3, ('r1', float(r1), float(r1_ref))
+        check_step('r1', tr.d_flat, tr.d_optim, st, gr1, dkeys, d_lr, d_b2, 2, freeze_d, zero_d, d, 5e-4)
+        del rp, r1_ref, gr1, rr
+
+        # ---- G step (:495-541) against the twice-updated discriminator
+        t0 = time.time()
+        sd = oracle_sd(d, [])
+        sg = oracle_sd(g, gkeys)
+        fake, _ = generator_ref(sg, [z.double()], size=size, noise=noises)
+        fp, _ = discriminator_ref(sd, fake, size=size)
+        gl = g_nonsaturating_loss_ref(fp)
+        gg = dict(zip(gkeys, torch.autograd.grad(gl, [sg[k] for k in gkeys])))
+        timing['g oracle'] = time.time() - t0
+        st = snapshot(g, tr.g_optim, gkeys)
+        g_loss = tr.g_step([z.to(DEV)], g_noise=dev_noises)
+        assert rel(g_loss, gl.detach()) < 1e-4, ('g_loss', float(g_loss), float(gl))
+        check_step('g', tr.g_flat, tr.g_optim, st, gg, gkeys, g_lr, g_b2, 1, freeze_g, zero_g, g, 2e-4)
+        del fake, fp, gl, gg
+
+        # ---- path-length step (:546-589), path batch 2
+        t0 = time.time()
+        sg = oracle_sd(g, [k for k, _ in g.named_parameters()])      # (the latents must carry a graph: mapping network included)
+        img, lat = generator_ref(sg, [z[:pb].double()], size=size, return_latents=True, noise=noises)
+        pen_ref, mean_ref, _ = g_path_regularize_ref(img, lat, 0, pl_noise.double())
+        gpl = dict(zip(gkeys, torch.autograd.grad(cfg.path_regularize * cfg.g_reg_every * pen_ref + 0 * img[0, 0, 0, 0],
+                                                  [sg[k] for k in gkeys], allow_unused=True)))
+        gpl = {k: (v if v is not None else torch.zeros_like(sg[k])) for k, v in gpl.items()}
+        timing['plr oracle'] = time.time() - t0
+        st = snapshot(g, tr.g_optim, gkeys)
+        pen = tr.plr_step([z[:pb].to(DEV)], pl_noise=pl_noise.to(DEV), g_noise=dev_noises)
+        assert rel(pen, pen_ref.detach()) < 1e-3, ('path penalty', float(pen), float(pen_ref))
+        assert rel(tr.mean_path_length, mean_ref) < 1e-3
+        check_step('plr', tr.g_flat, tr.g_optim, st, gpl, gkeys, g_lr, g_b2, 2, freeze_g, zero_g, g, 3e-3)
+        print('teacher-forced 256 px: oracle seconds', {k: round(v, 1) for k, v in timing.items()},
+              'worst per-key gradient L2', worst)
+    finally:
+        torch.set_num_threads(nthreads)
 
 
 def _key_samples(key, n, count=64):
