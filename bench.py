@@ -439,10 +439,60 @@ def main():
         torch.cuda.synchronize()
         out['eval_sampling'] = {'images_per_s': n / (time.perf_counter() - t0), 'batch': 25, 'images': n,
                                 'note': 'g_ema inference loop of gan_training/eval.py:34-41, images kept on device'}
+    if rank == 0 and world == 1 and not args.no_extras and use_graphs:
+        # The data-parallel code path on ONE GPU: the same loop through DataParallelGrads(force=True) on a single-rank RCCL
+        # ('nccl') group — forward/backward graph, ncclAvg per 32 MiB bucket on RCCL's stream, optimiser graph deferred behind
+        # the next step's head.  With one rank the exchange is the identity, so the ratio to the plain loop is the pipeline's
+        # non-wire overhead — the only part of N-GPU efficiency that one GPU can measure.
+        try:
+            import socket
+            s_ = socket.socket()
+            s_.bind(('127.0.0.1', 0))
+            port = s_.getsockname()[1]
+            s_.close()
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+            dist.init_process_group('nccl', rank=0, world_size=1)
+            torch.manual_seed(1)
+            g2 = Generator(cfg.size, cfg.latent, cfg.n_mlp, cfg.channel_multiplier).to(dev)
+            d2 = Discriminator(cfg.size, cfg.channel_multiplier).to(dev)
+            g2e = Generator(cfg.size, cfg.latent, cfg.n_mlp, cfg.channel_multiplier).to(dev)
+            d2e = Discriminator(cfg.size, cfg.channel_multiplier).to(dev)
+            dp1 = DataParallelGrads(force=True)
+            tr2 = RickTrainer(cfg, g2, d2, g2e, d2e, dp=dp1)
+            if not args.no_fisher:
+                tr2.fisher_sweep(*fisher_in, first=True)
+            tr2.enable_graphs(True)
+            tr2.prepare_graphs(reals[0])
+
+            def timed(trn, n):
+                for k in range(args.warmup):
+                    trn.iteration(i0 + k, reals[k % len(reals)])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for k in range(n):
+                    trn.iteration(i0 + args.warmup + k, reals[k % len(reals)])
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / n
+            tr.enable_graphs(True)
+            plain_s = timed(tr, args.steps)
+            forced_s = timed(tr2, args.steps)
+            out['dp1_forced'] = {'images_per_s': cfg.batch / forced_s, 'plain_images_per_s': cfg.batch / plain_s, 'ratio': plain_s / forced_s,
+                                 'buckets': {'g': len(dp1._state[id(tr2.g_flat)]['buckets']), 'd': len(dp1._state[id(tr2.d_flat)]['buckets'])},
+                                 'bucket_mib': 32,
+                                 'note': 'same loop through DataParallelGrads(force=True) on a single-rank RCCL group (collectives, stream '
+                                         'waits, three graphs per step, deferred optimiser step), timed back to back with the plain loop'}
+            dist.destroy_process_group()
+        except Exception as e:                             # noqa: BLE001 — an extra must not cost the measurement
+            out['dp1_forced'] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg.size)
     if rank == 0:
-        print(json.dumps(out))
+        # RCCL prints a version banner through C stdio (buffered until exit when stdout is a pipe): flush it first, so that
+        # the JSON line is the LAST line of the output whatever the backend wrote
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

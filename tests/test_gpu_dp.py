@@ -298,7 +298,7 @@ def test_bench_self_launch_two_ranks_one_gpu():
     assert out['ranks']['backend'] == 'gloo' and out['ranks']['rccl_ranks'] == 0
 
 
-def _nccl_worker(q, direct_steps=False):
+def _nccl_worker(q, direct_steps=False, size=32, B=2, bucket_bytes=256 * 1024, iters=9):
     """Single rank, backend 'nccl' (= RCCL): the data-parallel code path — bucket launches with ncclAvg, work.wait() stream
     semantics around replayed step graphs, the deferred optimiser graph with the generator forward running while the D
     gradients are "on the wire" — on the one GPU this box has.  With one rank the exchange is the identity, so the result
@@ -313,7 +313,7 @@ def _nccl_worker(q, direct_steps=False):
     from tests.shapes import discriminator_shapes, generator_shapes
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1)
-    size, B, dev = 32, 2, 'cuda:0'
+    dev = 'cuda:0'
 
     def build():
         g = Generator(size, 512, 8, channel_multiplier=2)
@@ -329,7 +329,7 @@ def _nccl_worker(q, direct_steps=False):
         torch.manual_seed(3)
         g, d = build()
         g_ema, d_ema = build()
-        dp = DataParallelGrads(bucket_bytes=256 * 1024, force=True) if mode == 'rccl' else None
+        dp = DataParallelGrads(bucket_bytes=bucket_bytes, force=True) if mode == 'rccl' else None
         tr = RickTrainer(TrainConfig(size=size, batch=B, warmup_iter=0), g, d, g_ema, d_ema, dp=dp)
         if dp is not None:
             assert dp.active and dist.get_backend() == 'nccl' and len(dp._state[id(tr.d_flat)]['buckets']) >= 3
@@ -347,7 +347,7 @@ def _nccl_worker(q, direct_steps=False):
                 assert tr._pending is not None and tr._pending[1] is tr.g_flat
             tr.ema_step()
         else:
-            for i in range(16, 16 + 9):                  # i = 16: R1 + path length; captures happen on each step type's 3rd call
+            for i in range(16, 16 + iters):              # i = 16: R1 + path length; captures happen on each step type's 3rd call
                 tr.iteration(i, reals[i % 3])
         if dp is not None:
             assert tr._gs['g']['graphs'][0] is not None and tr._gs['g']['graphs'][2] is not None    # head | fwd/bwd | optimiser
@@ -355,7 +355,8 @@ def _nccl_worker(q, direct_steps=False):
         torch.cuda.synchronize()
         out[mode] = [t.detach().clone() for t in (tr.g_flat.flat, tr.d_flat.flat, tr.g_ema_flat.flat, tr.d_ema_flat.flat)]
         out[mode].append(float(tr.losses['g']))
-    res = {'equal': [bool(torch.equal(a, b)) for a, b in zip(out['plain'][:4], out['rccl'][:4])],
+    res = {'buckets': (len(dp._state[id(tr.g_flat)]['buckets']), len(dp._state[id(tr.d_flat)]['buckets'])),
+           'equal': [bool(torch.equal(a, b)) for a, b in zip(out['plain'][:4], out['rccl'][:4])],
            'finite': [bool(torch.isfinite(a).all()) for a in out['rccl'][:4]],
            'g_loss': (out['plain'][4], out['rccl'][4])}
     dist.destroy_process_group()
@@ -378,6 +379,26 @@ def test_rccl_code_path_single_rank_pipelined_graphs():
     out = _get(q, [p], 600)
     p.join(60)
     assert p.exitcode == 0
+    assert all(out['equal']) and all(out['finite']), out
+    assert out['g_loss'][0] == out['g_loss'][1]
+
+
+def test_rccl_code_path_single_rank_256px_batch4_default_buckets():
+    """The same at BASELINE config 3's PER-RANK shapes (256 px, batch 4) with the default 32 MiB buckets: 3 collectives for the
+    generator's gradients (95 MB) and 4 for the discriminator's behind the replayed 256-px step graphs, R1 and path-length
+    steps included (i = 16), nine iterations; parameters, EMA weights and the last loss equal the plain trainer's bit for bit."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    p = ctx.Process(target=_nccl_worker, args=((q, port), False, 256, 4, 32 << 20, 9))
+    p.start()
+    out = _get(q, [p], 900)
+    p.join(60)
+    assert p.exitcode == 0
+    assert out['buckets'][0] >= 3 and out['buckets'][1] >= 3, out['buckets']
     assert all(out['equal']) and all(out['finite']), out
     assert out['g_loss'][0] == out['g_loss'][1]
 
