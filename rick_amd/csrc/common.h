@@ -10,6 +10,19 @@
         return e__ == hipSuccess ? 0 : 1000 + (int)e__;        \
     } while (0)
 
+// Kernels that need more than the default 64 KB of dynamic LDS: raise the function's limit to the CU's 160 KB ONCE per kernel
+// (template instantiation) and device — the call is a driver round trip (~1 us), harmless under graph replay but paid per launch
+// in eager issue.  The static flags belong to the expansion site, i.e. to one kernel variant.
+#define RICK_LDS160_ONCE(kernel_ptr)                                                                         \
+    do {                                                                                                     \
+        static bool done__[16];                                                                              \
+        int dev__ = 0;                                                                                       \
+        if (hipGetDevice(&dev__) != hipSuccess || dev__ < 0 || dev__ >= 16 || !done__[dev__]) {              \
+            (void)hipFuncSetAttribute((const void *)(kernel_ptr), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (dev__ >= 0 && dev__ < 16) done__[dev__] = true;                                              \
+        }                                                                                                    \
+    } while (0)
+
 __host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

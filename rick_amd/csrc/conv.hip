@@ -1099,20 +1099,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 const int n = n0 + nbi, gy = gy0 + py, gx = gx0 + px;
                 if (co >= g.Co || nbi >= t.nbe || n >= g.N || gy >= g.GH || gx >= g.GW) continue;
                 const float4 *src = ws4 + ((((size_t)n * g.GH + gy) * g.GW + gx) * g.Co + co) / 4;
-                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-                int sp = 0;
-                for (; sp + 4 <= t.nsplit; sp += 4) {          // four loads in flight, added in split order
-                    const float4 v0 = src[(size_t)sp * per4], v1 = src[(size_t)(sp + 1) * per4], v2 = src[(size_t)(sp + 2) * per4],
-                                 v3 = src[(size_t)(sp + 3) * per4];
-                    s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
-                    s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
-                    s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
-                    s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
-                }
-                for (; sp < t.nsplit; sp++) {
-                    const float4 v0 = src[(size_t)sp * per4];
-                    s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
-                }
+                const float4 s = cv_sum_splits4(src, (int64_t)per4, t.nsplit);
                 const float4 v = splitk_finish4(s, (unsigned)n, (unsigned)co, (unsigned)gy, (unsigned)gx, g, oscale, epi, nwv);
                 *reinterpret_cast<float4 *>(out + (((int64_t)n * g.OH + gy * g.os + g.oy0) * g.OW + gx * g.os + g.ox0) * g.Co + co) = v;
                 ram = amax4(ram, v);
@@ -1187,12 +1174,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float *_
         const unsigned co = cq * W;
         const int64_t o = (((int64_t)n * g.OH + gy * g.os + g.oy0) * g.OW + gx * g.os + g.ox0) * g.Co + co;
         if (VEC4) {
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 *src = reinterpret_cast<const float4 *>(ws) + iw;
-            for (int sp = 0; sp < nsplit; sp++) {
-                const float4 v = src[(size_t)sp * (per / 4)];
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            }
+            const float4 s = cv_sum_splits4(reinterpret_cast<const float4 *>(ws) + iw, (int64_t)(per / 4), nsplit);
             const float4 v = splitk_finish4(s, n, co, gy, gx, g, oscale, epi, nwv);
             *reinterpret_cast<float4 *>(out + o) = v;
             if (AMAX) ram = amax4(ram, v);
@@ -1241,9 +1223,7 @@ template <int SPLIT, bool VEC, bool DEEP, int NJ, int NT = 0, int WDMA = 0, bool
 static void launch_igemm_k(unsigned nwg, size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
                            const float *iscale, const float *oscale, float *ws, const rick_conv_geom *g,
                            const ConvTiling &t, const rick_conv_epilogue &epi) {
-    static const bool attr_set = hipFuncSetAttribute((const void *)conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT, WDMA, PKX, NW>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;   // once per variant
-    (void)attr_set;
+    RICK_LDS160_ONCE((conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT, WDMA, PKX, NW>));
     hipLaunchKernelGGL((conv_igemm_kernel<SPLIT, VEC, DEEP, NJ, NT, WDMA, PKX, NW>), dim3(nwg), dim3(NW * 64), lds + (WDMA == 3 ? CV_WSTEP_BYTES : 0), st,
                        x, wp, out, iscale, oscale, ws, *g, t, epi);
 }
@@ -1425,8 +1405,7 @@ extern "C" int64_t rick_conv_igemm_multi_workspace_bytes(const rick_conv_geom *g
 template <int SPLIT, bool VEC>
 static void launch_igemm_multi(size_t lds, hipStream_t st, const float *x, const unsigned char *wp, float *out,
                                const float *iscale, const float *oscale, float *ws, const IgemmMulti &m) {
-    (void)hipFuncSetAttribute((const void *)conv_igemm_multi_kernel<SPLIT, VEC>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    RICK_LDS160_ONCE((conv_igemm_multi_kernel<SPLIT, VEC>));
     hipLaunchKernelGGL((conv_igemm_multi_kernel<SPLIT, VEC>), dim3((unsigned)m.blk_end[m.ncls - 1]), dim3(256), lds, st, x,
                        wp, out, iscale, oscale, ws, m);
 }

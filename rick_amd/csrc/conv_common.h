@@ -300,6 +300,41 @@ __device__ __forceinline__ void cv_amax_publish(float m, float *word, float *cv_
         if (bits > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(w, bits);
     }
 }
+// Sum of the nsplit partial float4 at p[sp * stride], sp = 0 .. nsplit-1, added IN SPLIT ORDER (the second-stage kernels'
+// fixed summation order: results do not depend on the unrolling) with up to eight independent 16-byte loads in flight — the
+// plain `for (sp) s += p[sp * stride]` loop is a chain of dependent round trips (runtime trip count: hipcc waits for each load
+// before the next), which is what the 6 - 13 us of these launches were made of (round 6).
+__device__ __forceinline__ float4 cv_sum_splits4(const float4 *__restrict__ p, int64_t stride, int nsplit) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int sp = 0;
+    for (; sp + 8 <= nsplit; sp += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p[(int64_t)(sp + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    if (sp + 4 <= nsplit) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = p[(int64_t)(sp + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        sp += 4;
+    }
+    if (sp + 2 <= nsplit) {
+        const float4 v0 = p[(int64_t)sp * stride], v1 = p[(int64_t)(sp + 1) * stride];
+        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+        s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+        sp += 2;
+    }
+    if (sp < nsplit) {
+        const float4 v0 = p[(int64_t)sp * stride];
+        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+    }
+    return s;
+}
+
 // ---- in-launch split-K fix-up: arrival ticket (split.hip: rick_internal_tickets) -----------------------------------------------
 // Called by every thread of a block AFTER it has stored its partial tile with plain stores.  Returns true in every thread of
 // the block that arrives LAST for this tile; that block may then read all partial tiles with plain loads.  The hand-off is the

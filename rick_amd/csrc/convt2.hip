@@ -393,11 +393,7 @@ __global__ __launch_bounds__(256) void convt2_reduce_kernel(const float *__restr
     float am = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 *src = reinterpret_cast<const float4 *>(ws) + i;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int sp = 0; sp < nsplit; sp++) {
-            const float4 v = src[(int64_t)sp * n4];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
+        float4 s = cv_sum_splits4(src, n4, nsplit);
         float4 sc = make_float4(alpha, alpha, alpha, alpha);
         if (oscale) {
             const int64_t n = i / per_img4;
@@ -578,7 +574,7 @@ static int convt2_run(const float *x, const void *packed_w, float *out, const fl
     auto launch = [&](auto kern, int item0, int64_t nwg) {
         if (nwg <= 0) return;
         p.item0 = item0;
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        RICK_LDS160_ONCE(kern);         // (generic lambda: one set of flags per kernel variant)
         hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(CT_THREADS), lds, st, x, (const unsigned char *)packed_w, out, iscale,
                            oscale, (float *)workspace, p);
     };

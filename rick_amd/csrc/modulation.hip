@@ -144,7 +144,7 @@ extern "C" int rick_demod_bwd_s_f32(const float *s, const float *wsq, const floa
     if (!s || !wsq || !d || !gd || !gs || B <= 0 || B > MOD_MAXB || I <= 0 || O <= 0) return RICK_EINVAL;
     const size_t lds = ((size_t)B * O + DBS_WAVES * (size_t)B * 64) * sizeof(float);
     if (lds > 160 * 1024) return RICK_EINVAL;
-    (void)hipFuncSetAttribute((const void *)demod_bwd_s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    RICK_LDS160_ONCE(demod_bwd_s_kernel);
     hipLaunchKernelGGL(demod_bwd_s_kernel, dim3(cdiv(I, 64)), dim3(64 * DBS_WAVES), lds, (hipStream_t)stream, s, wsq, d, gd, gs,
                        B, I, O);
     RICK_LAUNCH_STATUS();
@@ -373,7 +373,7 @@ extern "C" int rick_demod_bwd_s_multi_f32(const float *s_flat, const float *d_fl
         return RICK_EINVAL;
     const size_t lds = ((size_t)B * max_O + DBS_WAVES * (size_t)B * 64) * sizeof(float);
     if (lds > 160 * 1024) return RICK_EINVAL;
-    (void)hipFuncSetAttribute((const void *)demod_bwd_s_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    RICK_LDS160_ONCE(demod_bwd_s_multi_kernel);
     hipLaunchKernelGGL(demod_bwd_s_multi_kernel, dim3((unsigned)total_blocks), dim3(64 * DBS_WAVES), lds, (hipStream_t)stream, s_flat,
                        d_flat, gd_flat, gs_flat, descs_device, n, B);
     RICK_LAUNCH_STATUS();

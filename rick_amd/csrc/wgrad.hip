@@ -965,11 +965,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float *__r
     for (int row = threadIdx.x >> 3; row < ntaps * 8; row += 32) {
         const int tt = row >> 3, kl = row & 7;
         const float4 *p = src + ((int64_t)(tt * CV_CK + pk * 8 + kl) * CV_BM + pc * 32) / 4 + c4;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int sp = 0; sp < nsplit; sp++) {
-            const float4 v = p[sp * split4];
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-        }
+        const float4 a = cv_sum_splits4(p, split4, nsplit);
         const int sl = g.wt[tt];
         if (!TR) {
             float *d = wr_tile + (c4 * 4) * pitch + kl * nsl + sl;
@@ -1031,8 +1027,7 @@ template <int NT, int SPLIT, bool VEC, int PMAX, bool PIPE, int FAST = 0, int PK
 static void launch_wgrad_k(const float *x, const float *gy, float *ws, const float *ascale, const float *bscale,
                            const rick_conv_geom *g, const ConvTiling &t, int nsplit, int tps, size_t lds, hipStream_t st) {
     const unsigned nwg = (unsigned)(nsplit * t.ncot * t.nchunks);
-    (void)hipFuncSetAttribute((const void *)conv_wgrad_kernel<NT, SPLIT, VEC, PMAX, PIPE, FAST, PK>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    RICK_LDS160_ONCE((conv_wgrad_kernel<NT, SPLIT, VEC, PMAX, PIPE, FAST, PK>));
     hipLaunchKernelGGL((conv_wgrad_kernel<NT, SPLIT, VEC, PMAX, PIPE, FAST, PK>), dim3(nwg), dim3(256), lds, st, x, gy, ws, ascale,
                        bscale, *g, t, nsplit, tps);
 }
@@ -1063,7 +1058,7 @@ static void launch_wgrad8(const float *x, const float *gy, float *ws, const floa
                           const rick_conv_geom *g, const ConvTiling &t, int nsplit, int tps, hipStream_t st) {
     if constexpr (NT == 9 || NT == 1) {
         const unsigned nwg = (unsigned)(nsplit * t.ncot * t.nchunks);
-        (void)hipFuncSetAttribute((const void *)conv_wgrad8_kernel<NT, PM8, FAST, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        RICK_LDS160_ONCE((conv_wgrad8_kernel<NT, PM8, FAST, PK>));
         hipLaunchKernelGGL((conv_wgrad8_kernel<NT, PM8, FAST, PK>), dim3(nwg), dim3(512), wgrad8_lds_bytes(g, t), st, x, gy, ws, ascale,
                            bscale, *g, t, nsplit, tps);
     }
