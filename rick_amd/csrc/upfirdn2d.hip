@@ -183,12 +183,16 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_kernel(const float *__rest
 // decimation are all 4x4 kernels with up == 1 and down in {1, 2} on >= 64 channels.  Compile-time tile,
 // tap count and strides: 16 unrolled fmaf per output float4, y-outer / x-inner exactly like the generic
 // kernel and the C oracle (bit-identical results).
-template <int DOWN, int TOH, int TOW, bool TAIL, bool XO = false>
+// CB4: float4 per pixel of the block's channel slab (16: 64 channels, 8 x 8 tile; 8: 32 channels — still whole 128-byte lines per
+// pixel — on a 16 x 16 tile, round 6: the 3-pixel halo then costs 19^2 / 16^2 = 1.41 input pixels per output instead of
+// 11^2 / 8^2 = 1.89, and it is the L2 -> CU side of this kernel, (halo + 1) x the algorithmic bytes, that runs at its limit).
+template <int DOWN, int TOH, int TOW, bool TAIL, bool XO = false, int CB4 = 16>
 __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__restrict__ in,
                                                                 const float *__restrict__ kern,
                                                                 float *__restrict__ out, UfdParams p,
                                                                 rick_conv_epilogue tail, rick_split_out xo) {
-    constexpr int TIH = (TOH - 1) * DOWN + 4, TIW = (TOW - 1) * DOWN + 4, CB4 = 16;
+    constexpr int TIH = (TOH - 1) * DOWN + 4, TIW = (TOW - 1) * DOWN + 4;
+    constexpr int PG = 256 / CB4;                 // pixel groups: threads that share a channel quad walk pixels PG apart
     __shared__ float4 sx[TIH * TIW * CB4];
     float sscale = 1.f, am = 0.f, ams = 0.f;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
     int tile = blockIdx.x;
     if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int tile_x = tile % p.tiles_x, tile_y = tile / p.tiles_x;
-    const int c0 = blockIdx.y * 64;
+    const int c0 = blockIdx.y * (CB4 * 4);
     const int64_t n = blockIdx.z;
     const int oy0 = tile_y * TOH, ox0 = tile_x * TOW;
     const int iy_lo = oy0 * DOWN - p.pad_y0, ix_lo = ox0 * DOWN - p.pad_x0;
@@ -210,15 +214,16 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
 #pragma unroll
     for (int i = 0; i < 16; i++) kr[i] = kern[i];
     const float *src = in + n * (int64_t)p.in_h * p.in_w * p.minor + c0;
-    const int c4 = threadIdx.x & 15;
+    const int c4 = threadIdx.x & (CB4 - 1);
+    const int pgrp = threadIdx.x / CB4;
     // stage the input tile: all of a thread's 16-byte loads are issued first (clamped addresses, no branch),
     // then written to LDS — one HBM round trip per block instead of one per staged pixel
-    constexpr int NLD = (TIH * TIW + 15) / 16;
+    constexpr int NLD = (TIH * TIW + PG - 1) / PG;
     float4 stage[NLD];
     unsigned okm = 0;
 #pragma unroll
     for (int k = 0; k < NLD; k++) {
-        const int pix = (threadIdx.x >> 4) + 16 * k;
+        const int pix = pgrp + PG * k;
         const int r = pix / TIW, c = pix - r * TIW;
         const int iy = iy_lo + r, ix = ix_lo + c;
         const bool ok = pix < TIH * TIW && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
@@ -227,43 +232,48 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
     }
 #pragma unroll
     for (int k = 0; k < NLD; k++) {
-        const int pix = (threadIdx.x >> 4) + 16 * k;
+        const int pix = pgrp + PG * k;
         if (pix < TIH * TIW) sx[pix * CB4 + c4] = ((okm >> k) & 1u) ? stage[k] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     // Outputs of a thread.  down == 1: four vertically adjacent pixels of one column, so the 7 x 4 input window is read
     // from LDS once (28 ds_read_b128 instead of 64) — every output still accumulates its 16 taps y-outer / x-inner.
-    constexpr int NOUT = TOH * TOW / 16;
-    constexpr bool COLUMN = DOWN == 1 && TOH == 8 && TOW == 8;
+    constexpr int NOUT = TOH * TOW / PG;
+    constexpr bool COLUMN = DOWN == 1 && (TOH % 4) == 0 && ((TOH / 4) * TOW) % PG == 0;
+    constexpr int NCG = COLUMN ? (TOH / 4) * TOW / PG : 1;        // column groups (4 vertically adjacent outputs) per thread
+    static_assert(!COLUMN || NOUT == 4 * NCG, "column groups cover the tile");
     float4 acc[NOUT];
 #pragma unroll
     for (int j = 0; j < NOUT; j++) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (COLUMN) {
-        const int pg = threadIdx.x >> 4;
-        const float4 *xr = sx + (((pg >> 3) * 4) * TIW + (pg & 7)) * CB4 + c4;
 #pragma unroll
-        for (int r = 0; r < 7; r++) {
-            float4 xv[4];
+        for (int q = 0; q < NCG; q++) {
+            const int cg = pgrp + PG * q;
+            const float4 *xr = sx + (((cg / TOW) * 4) * TIW + (cg % TOW)) * CB4 + c4;
 #pragma unroll
-            for (int x = 0; x < 4; x++) xv[x] = xr[(r * TIW + x) * CB4];
+            for (int r = 0; r < 7; r++) {
+                float4 xv[4];
 #pragma unroll
-            for (int o = 0; o < 4; o++) {
-                const int y = r - o;
-                if (y < 0 || y > 3) continue;
+                for (int x = 0; x < 4; x++) xv[x] = xr[(r * TIW + x) * CB4];
 #pragma unroll
-                for (int x = 0; x < 4; x++) {
-                    const float kv = kr[(3 - y) * 4 + (3 - x)];
-                    acc[o].x = __builtin_fmaf(xv[x].x, kv, acc[o].x);
-                    acc[o].y = __builtin_fmaf(xv[x].y, kv, acc[o].y);
-                    acc[o].z = __builtin_fmaf(xv[x].z, kv, acc[o].z);
-                    acc[o].w = __builtin_fmaf(xv[x].w, kv, acc[o].w);
+                for (int o = 0; o < 4; o++) {
+                    const int y = r - o;
+                    if (y < 0 || y > 3) continue;
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        const float kv = kr[(3 - y) * 4 + (3 - x)];
+                        acc[q * 4 + o].x = __builtin_fmaf(xv[x].x, kv, acc[q * 4 + o].x);
+                        acc[q * 4 + o].y = __builtin_fmaf(xv[x].y, kv, acc[q * 4 + o].y);
+                        acc[q * 4 + o].z = __builtin_fmaf(xv[x].z, kv, acc[q * 4 + o].z);
+                        acc[q * 4 + o].w = __builtin_fmaf(xv[x].w, kv, acc[q * 4 + o].w);
+                    }
                 }
             }
         }
     } else {
 #pragma unroll
         for (int j = 0; j < NOUT; j++) {
-            const int pix = (threadIdx.x >> 4) + 16 * j;
+            const int pix = pgrp + PG * j;
             const int ty = pix / TOW, tx = pix % TOW;
             const float4 *xr = sx + ((ty * DOWN) * TIW + tx * DOWN) * CB4 + c4;
 #pragma unroll
@@ -281,9 +291,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
     }
 #pragma unroll
     for (int j = 0; j < NOUT; j++) {
-        const int pg = threadIdx.x >> 4;
-        const int ty = COLUMN ? (pg >> 3) * 4 + j : (pg + 16 * j) / TOW;
-        const int tx = COLUMN ? (pg & 7) : (pg + 16 * j) % TOW;
+        const int cg = pgrp + PG * (j >> 2);          // (COLUMN: output j = column group j / 4, row j % 4 of it)
+        const int ty = COLUMN ? (cg / TOW) * 4 + (j & 3) : (pgrp + PG * j) / TOW;
+        const int tx = COLUMN ? (cg % TOW) : (pgrp + PG * j) % TOW;
         const int oy = oy0 + ty, ox = ox0 + tx;
         float4 v = acc[j];
         if (oy < p.out_h && ox < p.out_w) {
@@ -310,15 +320,15 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__r
         }
     }
     if (XO) {
-        if (xo.adj_partials) {     // per-channel sums of the block's tile (the bias gradient's first stage): 16 pixel rows -> 1
+        if (xo.adj_partials) {     // per-channel sums of the block's tile (the bias gradient's first stage): PG pixel rows -> 1
             __syncthreads();
-            sx[threadIdx.x] = bsum;                      // [pixel group 0..15][c4 0..15]
+            sx[threadIdx.x] = bsum;                      // [pixel group 0..PG-1][c4 0..CB4-1]
             __syncthreads();
-            if (threadIdx.x < 16) {
+            if (threadIdx.x < CB4) {
                 float4 t = sx[threadIdx.x];
 #pragma unroll
-                for (int r = 1; r < 16; r++) {
-                    const float4 u = sx[r * 16 + threadIdx.x];
+                for (int r = 1; r < PG; r++) {
+                    const float4 u = sx[r * CB4 + threadIdx.x];
                     t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
                 }
                 const int64_t row = n * gridDim.x + tile;
@@ -338,6 +348,9 @@ static int tile_in_extent(int tile_out, int down, int k, int up) {
 static int upfirdn2d_impl(const float *input, const float *kernel, float *out, int64_t major, int in_h, int in_w, int minor,
                           int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
                           int pad_y1, const rick_conv_epilogue *tail, void *stream, const rick_split_out *xo = nullptr);
+
+// 16 x 16 output tiles for the 4x4 up = 1 down = 1 form (rick_conv_tuning RICK_TUNE_UFD_TILE16; outputs of >= 32 x 32)
+static bool ufd_tile16(int out_h, int out_w) { return rick_internal_tune(RICK_TUNE_UFD_TILE16) && out_h >= 32 && out_w >= 32; }
 
 extern "C" int rick_upfirdn2d_f32(const float *input, const float *kernel, float *out,
                                   int64_t major, int in_h, int in_w, int minor, int kh, int kw,
@@ -396,7 +409,15 @@ static int upfirdn2d_impl(const float *input, const float *kernel, float *out, i
             if (tail->noise && (!tail->noise_w || (tail->noise_nb != 1 && tail->noise_nb != major))) return RICK_EINVAL;
             if (tail->bias && ((uintptr_t)tail->bias % 16)) return RICK_EINVAL;
         }
-        if (down_x == 1) {
+        if (down_x == 1 && ufd_tile16(p.out_h, p.out_w)) {        // 16 x 16 tile on 32-channel slabs (see the kernel's comment)
+            if (2 * (int64_t)(minor / 64) > 65535) return RICK_EINVAL;
+            p.tiles_x = cdiv(p.out_w, 16);
+            dim3 grid(p.tiles_x * cdiv(p.out_h, 16), minor / 32, (unsigned)major);
+            if (xo && tail) hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<1, 16, 16, true, true, 8>), grid, dim3(256), 0, st, input, kernel, out, p, *tail, *xo);
+            else if (xo) hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<1, 16, 16, false, true, 8>), grid, dim3(256), 0, st, input, kernel, out, p, none, *xo);
+            else if (tail) hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<1, 16, 16, true, false, 8>), grid, dim3(256), 0, st, input, kernel, out, p, *tail, kNoSplitOut);
+            else hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<1, 16, 16, false, false, 8>), grid, dim3(256), 0, st, input, kernel, out, p, none, kNoSplitOut);
+        } else if (down_x == 1) {
             p.tiles_x = cdiv(p.out_w, 8);
             dim3 grid(p.tiles_x * cdiv(p.out_h, 8), minor / 64, (unsigned)major);
             if (xo && tail) hipLaunchKernelGGL((upfirdn2d_nhwc_k4_kernel<1, 8, 8, true, true>), grid, dim3(256), 0, st, input, kernel, out, p, *tail, *xo);
@@ -472,5 +493,6 @@ planar_like:
 CV_DEFINE_SAT_ACCESSOR(rick_sat_upfirdn2d)
 
 extern "C" int64_t rick_upfirdn2d_adjoint_rows(int64_t major, int out_h, int out_w) {
-    return major * cdiv(out_w, 8) * cdiv(out_h, 8);
+    const int tile = ufd_tile16(out_h, out_w) ? 16 : 8;
+    return major * cdiv(out_w, tile) * cdiv(out_h, tile);
 }

@@ -181,13 +181,37 @@ def test_conv2d_vs_fp64(case):
 def _conv_tuning(**kv):
     """rick_conv_tuning (include/rick_hip.h) for the duration of a test: which kernel FORM a launch takes, never its values."""
     from rick_amd._lib import lib
-    keys = {'igemm_w8': 0, 'igemm_w8_minblk': 1, 'splitk_fused': 2}
+    keys = {'igemm_w8': 0, 'igemm_w8_minblk': 1, 'splitk_fused': 2, 'ufd_tile16': 3}
     prev = {k: lib.rick_conv_tuning(keys[k], v) for k, v in kv.items()}
     try:
         yield
     finally:
         for k, v in prev.items():
             lib.rick_conv_tuning(keys[k], v)
+
+
+@pytest.mark.parametrize('cfg', [(1, 1, 2, 64, 64, 64), (2, 2, 1, 128, 65, 40), (1, 1, 3, 192, 33, 129)])
+def test_upfirdn2d_nhwc_tile16_equals_tile8_and_c_oracle(cfg):
+    """The 4x4 FIR's 16 x 16 x 32-channel tile (round 6; model_probe_tune.py:609-629, op/upfirdn2d_kernel.cu:107-207 are what
+    it replaces) against the 8 x 8 x 64-channel tile and the scalar C oracle: every output accumulates its 16 taps y-outer /
+    x-inner either way — bit-equal, ragged edge tiles and 3 x 64 channels included; backward (the adjoint FIR) too."""
+    from oracle import c_ref
+    from rick_amd.op import upfirdn2d
+    p0, p1, n, c, h, w = cfg
+    k = upfirdn_kernel(4, 1)
+    x = synth_tensor(f'ufd16/{cfg}', (n, c, h, w))
+    outs = {}
+    for mode in (0, 1):
+        with _conv_tuning(ufd_tile16=mode):
+            xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            y = upfirdn2d(xd, k.to(DEV), up=1, down=1, pad=(p0, p1))
+            gy = synth_tensor(f'ufd16/{cfg}/gy', y.shape).to(DEV).contiguous(memory_format=torch.channels_last)
+            (gx,) = torch.autograd.grad(y, xd, gy)
+            torch.cuda.synchronize()
+            outs[mode] = (y.detach(), gx)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    yc = c_ref.upfirdn2d_c(x.numpy(), k.numpy(), (1, 1), (1, 1), (p0, p1, p0, p1))
+    assert np.array_equal(outs[1][0].cpu().numpy(), yc)
 
 
 @pytest.mark.parametrize('case', [('ragged_co', 2, 128, 192, 32, 32), ('ragged_tiles', 1, 160, 128, 40, 24),
