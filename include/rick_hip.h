@@ -284,7 +284,7 @@ int rick_saturation_count(unsigned *count, int reset);
 #define RICK_TUNE_IGEMM_W8 0
 #define RICK_TUNE_IGEMM_W8_MINBLK 1
 #define RICK_TUNE_SPLITK_FUSED 2
-#define RICK_TUNE_UFD_TILE16 3      /* (default 1) 4x4 FIR, up = down = 1, outputs >= 32 x 32: 16 x 16 tiles on 32-channel slabs; 0: 8 x 8 x 64 */
+#define RICK_TUNE_UFD_TILE16 3      /* (default 0: measured 0.5 % slower end to end) 1 = 4x4 FIR, up = down = 1, outputs >= 32 x 32: 16 x 16 tiles on 32-channel slabs instead of 8 x 8 x 64 */
 int rick_conv_tuning(int key, int value);
 /* Producers.  rick_upfirdn2d_f32 / rick_upfirdn2d_act_f32 (tail may be NULL) with the extended result handling, channels-last
  * only; `out` may be NULL with ex->no_f32.  The activation adjoint (rick_bias_act_bwd_f32) leaving as split images:

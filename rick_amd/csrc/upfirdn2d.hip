@@ -183,9 +183,12 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_kernel(const float *__rest
 // decimation are all 4x4 kernels with up == 1 and down in {1, 2} on >= 64 channels.  Compile-time tile,
 // tap count and strides: 16 unrolled fmaf per output float4, y-outer / x-inner exactly like the generic
 // kernel and the C oracle (bit-identical results).
-// CB4: float4 per pixel of the block's channel slab (16: 64 channels, 8 x 8 tile; 8: 32 channels — still whole 128-byte lines per
-// pixel — on a 16 x 16 tile, round 6: the 3-pixel halo then costs 19^2 / 16^2 = 1.41 input pixels per output instead of
-// 11^2 / 8^2 = 1.89, and it is the L2 -> CU side of this kernel, (halo + 1) x the algorithmic bytes, that runs at its limit).
+// CB4: float4 per pixel of the block's channel slab (16: 64 channels, 8 x 8 tile — the default; 8: 32 channels — still whole
+// 128-byte lines per pixel — on a 16 x 16 tile, round 6: the 3-pixel halo then costs 19^2 / 16^2 = 1.41 input pixels per output
+// instead of 11^2 / 8^2 = 1.89).  MEASURED (tools/r6_ufd_eval.sh, profiles/r06_ufd_tile16.txt): the hypothesis that the L2 -> CU side
+// ((halo + 1) x the algorithmic bytes) limits this kernel is wrong — pad-(1,1) blur 55.0 vs 51.6 us at 128 ch @256^2, 24.8 vs 23.4
+// at 512 ch @64^2, pad-(2,2) 52.4 vs 55.8 / 17.8 vs 16.3; bench.py 169.4 vs 170.2 images/s (two alternating same-box pairs).  The
+// 16 x 16 form stays behind rick_conv_tuning(RICK_TUNE_UFD_TILE16) with its bit-equality test; 8 x 8 x 64 ships.
 template <int DOWN, int TOH, int TOW, bool TAIL, bool XO = false, int CB4 = 16>
 __global__ __launch_bounds__(256) void upfirdn2d_nhwc_k4_kernel(const float *__restrict__ in,
                                                                 const float *__restrict__ kern,
