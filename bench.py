@@ -170,6 +170,18 @@ def main():
     from rick_amd.train import RickTrainer, TrainConfig
     import torch.distributed as dist
 
+    # stdout carries exactly ONE line, the JSON: everything libraries write to fd 1 through C stdio (RCCL prints a version
+    # banner on rank 0) goes to stderr instead; the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.write(json_fd, (json.dumps(obj) + '\n').encode())
+
     rank, local, world = init_from_env()
     if os.environ.get('RICK_BENCH_DRYRUN'):
         # launcher check for hosts without a GPU (tests/test_host_logic.py): rendezvous, one all-reduce over the ranks,
@@ -179,7 +191,7 @@ def main():
             dist.all_reduce(t)
             dist.barrier()
         if rank == 0:
-            print(json.dumps({'dry_run': True, 'n_gpus': world, 'rank_sum': float(t), 'backend': dist.get_backend() if world > 1 else None}))
+            emit({'dry_run': True, 'n_gpus': world, 'rank_sum': float(t), 'backend': dist.get_backend() if world > 1 else None})
         if world > 1:
             dist.destroy_process_group()
         return
@@ -487,12 +499,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg.size)
     if rank == 0:
-        # RCCL prints a version banner through C stdio (buffered until exit when stdout is a pipe): flush it first, so that
-        # the JSON line is the LAST line of the output whatever the backend wrote
-        import ctypes
-        sys.stdout.flush()
-        ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
