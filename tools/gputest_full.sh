@@ -1,6 +1,6 @@
 #!/bin/bash
 # Three consecutive full `pytest -m gpu` runs on the sources as they are (fresh box), summary lines + source hash + HEAD.
-out=gpurun_out/r05_gputest_full.txt
+out=${1:-gpurun_out/r06_gputest_full.txt}
 mkdir -p gpurun_out
 {
   echo "kernel source hash: $(python3 -c 'import bench; print(bench.kernel_source_hash())')"
