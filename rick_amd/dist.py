@@ -55,6 +55,7 @@ class DataParallelGrads:
         self.bucket_elems = max(1, bucket_bytes // 4)
         self._state = {}       # id(flat) -> dict(buckets, pending, works, hooks)
         self.hooks_enabled = True   # False: no launches from autograd hooks (backward replayed from a hipGraph)
+        self.coalesce = True        # launch(): one collective when no bucket has left yet (False: always per bucket)
 
     # ------------------------------------------------------------------ bucket bookkeeping
     def attach(self, *flats):
@@ -87,9 +88,12 @@ class DataParallelGrads:
         st['launched'] = [False] * len(st['buckets'])
         st['works'] = []
 
-    def _launch(self, st, b):
+    def _launch(self, st, b, whole=False):
+        """bucket b — or (`whole`) the contiguous range of ALL buckets as one collective"""
         bk = st['buckets'][b]
         view = st['flat'].grad[bk['lo']:bk['hi']]
+        if whole:
+            view = st['flat'].grad[min(k['lo'] for k in st['buckets']):max(k['hi'] for k in st['buckets'])]
         if view.is_cuda and dist.get_backend(self.group) == 'gloo':
             # functional-test path only (two ranks sharing one GPU cannot use RCCL): stage through the host
             host = view.cpu()
@@ -101,6 +105,8 @@ class DataParallelGrads:
             st['works'].append((dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True), view, None))
         else:
             st['works'].append((dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True), view, 1.0 / self.world))
+        if whole:
+            st['launched'] = [True] * len(st['buckets'])
         st['launched'][b] = True
 
     def _make_hook(self, st, i):
@@ -126,6 +132,13 @@ class DataParallelGrads:
         if not self.active:
             return
         st = self._state[id(flat)]
+        if self.coalesce and len(st['buckets']) > 1 and not any(st['launched']):
+            # nothing has left yet (graph mode: the whole backward was ONE replayed graph, so bucketing buys no overlap): one
+            # collective over the contiguous gradient range instead of one per bucket — on one GPU each collective costs
+            # ~0.15 ms of stream hand-overs (bench.py dp1_forced: 0.955 -> see DESIGN.md section 6), on N GPUs one long ring
+            # pays its latency terms once.  Same elementwise mean.
+            self._launch(st, 0, whole=True)
+            return
         for b in range(len(st['buckets'])):
             if not st['launched'][b]:
                 self._launch(st, b)
