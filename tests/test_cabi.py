@@ -36,3 +36,16 @@ def test_ops_refuse_cpu_tensors():
         op.fused_leaky_relu(torch.zeros(2, 4), torch.zeros(4))
     with pytest.raises(RuntimeError):
         op.conv2d(torch.zeros(1, 4, 4, 4), torch.zeros(4, 4, 3, 3), 1, 1)
+
+
+def test_conv_tuning_is_a_host_side_switch():
+    """rick_conv_tuning (include/rick_hip.h): returns the previous value, -1 for an unknown key; the shipped defaults select the
+    forms that measured fastest (eight-wave igemm off, in-launch split-K fix-up off, 8 x 8 FIR tile) — no GPU involved."""
+    from rick_amd._lib import lib
+    defaults = {0: 0, 1: 192, 2: 0, 3: 0}
+    for key, dflt in defaults.items():
+        prev = lib.rick_conv_tuning(key, 7)
+        assert prev == dflt, (key, prev)
+        assert lib.rick_conv_tuning(key, prev) == 7
+        assert lib.rick_conv_tuning(key, prev) == prev
+    assert lib.rick_conv_tuning(99, 1) == -1 and lib.rick_conv_tuning(-1, 1) == -1
