@@ -463,7 +463,8 @@ def main():
             port = s_.getsockname()[1]
             s_.close()
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-            dist.init_process_group('nccl', rank=0, world_size=1)
+            import datetime
+            dist.init_process_group('nccl', rank=0, world_size=1, timeout=datetime.timedelta(seconds=90))   # (an extra must not stall the line)
             torch.manual_seed(1)
             g2 = Generator(cfg.size, cfg.latent, cfg.n_mlp, cfg.channel_multiplier).to(dev)
             d2 = Discriminator(cfg.size, cfg.channel_multiplier).to(dev)
