@@ -284,6 +284,8 @@ int rick_saturation_count(unsigned *count, int reset);
 #define RICK_TUNE_IGEMM_W8 0
 #define RICK_TUNE_IGEMM_W8_MINBLK 1
 #define RICK_TUNE_SPLITK_FUSED 2
+#define RICK_TUNE_IGEMM_S2W8 4      /* (default 2) 3x3 stride-2 launches with Co % 256 == 0 and >= RICK_TUNE_IGEMM_W8_MINBLK blocks: eight-wave 256 co x 128
+                                     * position blocks (conv.hip, igemm_body WDMA = 5: +8 ... +16 % per launch, +1.05 % end to end); 1: Ci >= 256 only; 0: four-wave */
 #define RICK_TUNE_UFD_TILE16 3      /* (default 0: measured 0.5 % slower end to end) 1 = 4x4 FIR, up = down = 1, outputs >= 32 x 32: 16 x 16 tiles on 32-channel slabs instead of 8 x 8 x 64 */
 int rick_conv_tuning(int key, int value);
 /* Producers.  rick_upfirdn2d_f32 / rick_upfirdn2d_act_f32 (tail may be NULL) with the extended result handling, channels-last

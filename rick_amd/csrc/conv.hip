@@ -245,6 +245,22 @@ static size_t igemm_w8_lds_bytes(const ConvTiling &t) {
 // occupancy at constant power, so a schedule that keeps the pipe fuller buys nothing.  In bench.py mode 1 (fp32 operands with
 // >= 16 channel chunks) measured 168.80 vs 168.79 images/s.  Mode 0 ships; the form stays behind rick_conv_tuning with its
 // parity tests (tests/test_gpu_ops.py: fp64 at 2e-6, bit-equal to the four-wave form on split images).
+// Eight-wave STRIDE-2 form (igemm_body, WDMA = 5): 3x3 stride-2 geometries with Co % 256 == 0 whose 16 x 8 position tiles fill
+// the chip; t->ncot counts 256-channel block columns.  rick_conv_tuning RICK_TUNE_IGEMM_S2W8: 0 never, 1 channel chunks >= 8, 2 all.
+static size_t igemm_s2w8_lds_bytes(const ConvTiling &t) {
+    return 4 * CV_WSTEP_BYTES + 2 * (size_t)(t.NPP + 1) * 64 + (size_t)((t.NPP + 3) & ~3) * 4 + (size_t)t.nbe * t.cps * CV_CK * 4 + 64;
+}
+static bool igemm_s2w8_plan(const rick_conv_geom *g, ConvTiling *t) {
+    const int mode = rick_internal_tune(RICK_TUNE_IGEMM_S2W8);
+    if (!mode || g->split != 2 || g->ntaps != 9 || g->is != 2 || (g->Ci & 3) || (g->Co & 255) || g->GH < 8 || g->GW < 16) return false;
+    if (make_tiling(g, CV_BN, t)) return false;
+    if (t->nb != 1 || t->NPP > 64 * 9 || t->nchunks < (mode == 1 ? 8 : 4)) return false;
+    t->ncot = g->Co / 256;
+    if (t->ntx * t->nty * t->ntn * t->ncot < rick_internal_tune(RICK_TUNE_IGEMM_W8_MINBLK)) return false;
+    if ((int64_t)g->N * g->IH * g->IW * g->Ci * 4 >= (1LL << 32) - 256) return false;
+    return igemm_s2w8_lds_bytes(*t) <= 160 * 1024 && t->PH <= 1023 && t->PW <= 1023;
+}
+
 static bool igemm_w8_plan(const rick_conv_geom *g, ConvTiling *t, bool pkx) {
     const int w8 = rick_internal_tune(RICK_TUNE_IGEMM_W8), w8_minblk = rick_internal_tune(RICK_TUNE_IGEMM_W8_MINBLK);
     if (w8 == 1 && (pkx || g->Ci < 16 * CV_CK)) return false;
@@ -345,10 +361,11 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cv_fp16_saturate();
     constexpr int NTHR = NW * 64;
-    static_assert(NW == 4 || (NW == 8 && WDMA == 4 && NJ == 4 && NT == 9 && SPLIT == 2 && VEC && !DEEP), "eight-wave form");
-    static_assert((WDMA == 4) == (NW == 8), "the 4-slot ring belongs to the eight-wave form");
+    static_assert(NW == 4 || (NW == 8 && (WDMA == 4 || WDMA == 5) && NJ == 4 && NT == 9 && SPLIT == 2 && VEC && !DEEP), "eight-wave forms");
+    static_assert((WDMA == 4 || WDMA == 5) == (NW == 8), "WDMA = 4 / 5 are the eight-wave forms");
+    constexpr int COT = WDMA == 5 ? 2 : 1;                  // 128-channel co tiles per block (WDMA = 5: 256 co x 128 positions, stride 2)
     unsigned char *wbuf = smem;                               // [2][16 KB]
-    unsigned char *ph = smem + (WDMA >= 3 ? WDMA : 2) * CV_WSTEP_BYTES;   // [NPP + 1][64 B]  (WDMA = 3 / 4: a ring of 3 / 4 weight tiles)
+    unsigned char *ph = smem + (WDMA == 5 ? 4 : WDMA >= 3 ? WDMA : 2) * CV_WSTEP_BYTES;   // [NPP + 1][64 B]  (WDMA = 3 / 4: a ring of 3 / 4 weight tiles; 5: 2 slots of 2 tiles)
     unsigned char *pl = ph + (t.NPP + 1) * 64;                // (+1: spare row for out-of-patch items)
     const int pbuf_bytes = 2 * (t.NPP + 1) * 64;              // WDMA = 4: two patch buffers [hi | lo], buffer b at ph + b * pbuf_bytes
     unsigned *ptab = reinterpret_cast<unsigned *>(pl + (t.NPP + 1) * 64 + (WDMA == 4 ? pbuf_bytes : 0));   // [NPP]
@@ -356,6 +373,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     build_patch_table(ptab, t, NTHR);
 
     const int lid = xcd_remap(bid, nwg);
+    const int ncot128 = (g.Co + CV_BM - 1) / CV_BM;          // co tiles of the packed weight image (t.ncot counts BLOCK columns)
     const int npos_tiles = t.ntx * t.nty * t.ntn;
     // Block order.  Position tile fastest gives each co tile its own XCDs: a co tile's weights stay in few L2s, but every input
     // patch crosses the fabric ncot times.  Stride-2 launches (37 KB patches, 4x the input per output position) run the co tile
@@ -399,14 +417,14 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     float satm = 0.f;          // largest |scaled operand| this thread converts (cv_sat_report)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = NW == 8 ? wave >> 2 : wave >> 1, wn = NW == 8 ? wave & 3 : wave & 1;
+    const int wm = WDMA == 5 ? wave >> 1 : NW == 8 ? wave >> 2 : wave >> 1, wn = WDMA == 5 ? wave & 1 : NW == 8 ? wave & 3 : wave & 1;
     const int l15 = lane & 15, kg = lane >> 4;
 
     int a_off[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int row = wm * 64 + i * 16 + l15;
-        a_off[i] = row * 64 + cv_swz(kg, row) * 16;
+        const int row = (WDMA == 5 ? wm & 1 : wm) * 64 + i * 16 + l15;       // (WDMA = 5: wave rows 0..255 = tile wm >> 1, row (wm & 1) * 64 + ..)
+        a_off[i] = (WDMA == 5 ? (wm >> 1) * CV_WSTEP_BYTES : 0) + row * 64 + cv_swz(kg, row) * 16;
     }
     int pb[NJ];   // NJ = position tiles of 16 per wave: 4 (128-position block) or 2 (64-position block, stride-2 input)
     const int tw_mask = (1 << t.tw_log2) - 1, th_mask = (1 << t.th_log2) - 1;
@@ -426,7 +444,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     // ahead, so a load has two chunks' worth of MFMAs to land instead of one.
     // register prefetch slots per set: the unrolled 128-position form only serves patches of <= 192 pixels
     // (eight waves: 64 pixels per item round, 6 rounds cover the 18 x 18 patch of a 16 x 16 tile)
-    constexpr int PSET = (DEEP || (NT > 0 && NJ == 4)) ? IG_PSET_DEEP : IG_PMAX;
+    constexpr int PSET = WDMA == 5 ? 9 : (DEEP || (NT > 0 && NJ == 4)) ? IG_PSET_DEEP : IG_PMAX;   // (WDMA = 5: 33 x 17 patch, 64 pixels per round)
     constexpr int PREGS = DEEP ? 2 * IG_PSET_DEEP : PSET;
     const int p_items = t.NPP * 8;
     const int c4 = threadIdx.x & 7;                      // NTHR % 8 == 0: same channel quad for all items
@@ -518,13 +536,13 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
     // issue_patch(c_begin) and commit_patch(c_begin).
     auto block_exponent = [&]() {
         if constexpr (PKX) {   // the image's own exponent (header) x the packed weights' (trailer); nothing to measure
-            unscale = cv_uniform(iscale[1] * *reinterpret_cast<const float *>(wpk + (int64_t)t.ncot * t.nchunks * g.nslices * CV_WSTEP_BYTES));
+            unscale = cv_uniform(iscale[1] * *reinterpret_cast<const float *>(wpk + (int64_t)ncot128 * t.nchunks * g.nslices * CV_WSTEP_BYTES));
             return;
         }
         float *red = sct + t.nbe * cspan;                             // 16 floats behind the scale table, used for nothing else
 #ifdef RICK_ABLATION
         if (t.debug & 8) {   // timing-only ablation (RICK_CONV_DEBUG=8): no exponent (values are wrong for data far from 1)
-            unscale = *reinterpret_cast<const float *>(wpk + (int64_t)t.ncot * t.nchunks * g.nslices * CV_WSTEP_BYTES);
+            unscale = *reinterpret_cast<const float *>(wpk + (int64_t)ncot128 * t.nchunks * g.nslices * CV_WSTEP_BYTES);
             return;
         }
 #endif
@@ -568,7 +586,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         cv_pow2_scale(m, xs, xu);
         xscale = cv_uniform(xs);
         // packed-weight exponent (trailer of the packed image)
-        unscale = cv_uniform(xu * *reinterpret_cast<const float *>(wpk + (int64_t)t.ncot * t.nchunks * g.nslices * CV_WSTEP_BYTES));
+        unscale = cv_uniform(xu * *reinterpret_cast<const float *>(wpk + (int64_t)ncot128 * t.nchunks * g.nslices * CV_WSTEP_BYTES));
         if (iscale) {                   // fold 2^e into the scale table
             for (int i = threadIdx.x; i < t.nbe * cspan; i += NTHR) sct[i] *= xscale;
             __syncthreads();
@@ -584,7 +602,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
         for (int j = 0; j < NJ; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nks = (c_end - c_begin) * g.ntaps;
-    const unsigned char *wbase = wpk + (int64_t)cot * t.nchunks * g.nslices * CV_WSTEP_BYTES;
+    const unsigned char *wbase = wpk + (int64_t)cot * COT * t.nchunks * g.nslices * CV_WSTEP_BYTES;
     constexpr int WCOPY = (SPLIT == 2 ? CV_WSTEP_BYTES : CV_WTILE_BYTES) / (256 * 16);   // uint4 per thread: 4 or 2
     uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;   // named (not an array): stays in VGPRs
 #define CV_WLOAD(src)                                                   \
@@ -746,6 +764,131 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 static_for<0, NT>(kstep);
             }
             cv_wait_vm<0>();       // (the ring runs three tiles ahead: nothing may land in LDS after the block has left)
+        };
+        if (!PKX && iscale) mainloop(std::true_type{});
+        else mainloop(std::false_type{});
+    } else if constexpr (WDMA == 5) {
+        // ---- eight-wave STRIDE-2 form (round 6, verdict item 2b): 256 co x 128 positions, waves 4 (co) x 2 (positions) of 64 x 64.
+        // The four-wave stride-2 block is 128 co x 64 positions (each wave 64 x 32: 2 MFMAs per ds_read_b128, its 37 KB patch staged
+        // per 128 co); here a wave has the stride-1 shape (3 MFMAs per read) and the 72 KB patch of a 16 x 8 tile is staged ONCE for
+        // 256 co.  LDS: 2 slots x 2 weight tiles (64 KB, LDS-DMA, tile pair of k-step ks + 1 issued behind the barrier of ks) + the
+        // patch (one buffer; the next chunk's 9 items per thread wait in registers, one issued per tap, stored at the chunk boundary).
+        static_assert(NT == 9 && PSET == NT, "one patch item per tap");
+        const int pix0 = threadIdx.x >> 3;
+        auto item_lds = [&](int k) {
+            const int pix = pix0 + 64 * k;
+            const int slot = pix < t.NPP ? cv_patch_slot(pix, ptab[pix < t.NPP ? pix : 0], t, 2) : t.NPP;
+            return slot * 64 + cv_swz(c4 >> 1, slot) * 16 + (c4 & 1) * 8;
+        };
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(x), 0, (unsigned)((int64_t)g.N * g.IH * g.IW * g.Ci * 4), 0x00020000);
+        const unsigned xt_bytes = (unsigned)((((n0 * g.IH + iy0) * g.IW + ix0) * g.Ci + c4 * 4) * 4);
+        auto issue_item = [&](auto KC, int chunk) {
+            constexpr int K = decltype(KC)::value;
+            const int pix = pix0 + 64 * K;
+            const unsigned e = ptab[pix < t.NPP ? pix : 0];
+            const unsigned rel = (unsigned)(((int)((e >> 10) & 1023) * g.IW + (int)(e & 1023)) * g.Ci * 4);
+            const bool ok = (cur_ok[0] >> K) & 1u;
+            const igemm_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (xt_bytes + rel + (unsigned)chunk * (CV_CK * 4)) | (ok ? 0u : 0xfffffff0u), 0, 0);
+            pq[K] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        };
+        const int64_t cot_stride = (int64_t)t.nchunks * g.nslices * CV_WSTEP_BYTES;      // packed bytes of one 128-channel co tile
+        auto issue_wdma5 = [&](int wchunk, int wtap, int slot) {
+            const unsigned char *src = wbase + ((int64_t)wchunk * g.nslices + g.wt[wtap]) * CV_WSTEP_BYTES;
+            unsigned char *dst = wbuf + slot * (2 * CV_WSTEP_BYTES);
+#pragma unroll
+            for (int q = 0; q < 4; q++)          // pieces 0..1023: co tile 2 cot, 1024..2047: co tile 2 cot + 1
+                __builtin_amdgcn_global_load_lds((cv_gbl_u8 *)(src + (q >> 1) * cot_stride + ((q & 1) * NTHR + threadIdx.x) * 16),
+                                                 (cv_lds_u8 *)(dst + (q * NTHR + wave * 64) * 16), 16, 0, 0);
+        };
+        struct Frag2 { f16x8 h[2], l[2]; };
+        auto read_a = [&](const unsigned char *wb, int half) {
+            Frag2 f;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                f.h[i] = *reinterpret_cast<const f16x8 *>(wb + a_off[half * 2 + i]);
+                f.l[i] = *reinterpret_cast<const f16x8 *>(wb + CV_WTILE_BYTES + a_off[half * 2 + i]);
+            }
+            return f;
+        };
+        auto read_b = [&](int tap, int half) {
+            Frag2 f;
+            const int toff = (g.dy[tap] - t.dymin) * t.PW + cv_patch_col(g.dx[tap] - t.dxmin, t.PW, 2);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int pp = pb[half * 2 + j] + toff;
+                const int off = pp * 64 + cv_swz(kg, pp) * 16;
+                f.h[j] = *reinterpret_cast<const f16x8 *>(ph + off);
+                f.l[j] = *reinterpret_cast<const f16x8 *>(pl + off);
+            }
+            return f;
+        };
+        auto quad = [&](const Frag2 &a, const Frag2 &b, auto IH, auto JH) {
+            constexpr int i0 = decltype(IH)::value * 2, j0 = decltype(JH)::value * 2;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l[i], b.h[j], acc[i0 + i][j0 + j], 0, 0, 0);
+                    acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h[i], b.l[j], acc[i0 + i][j0 + j], 0, 0, 0);
+                    acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h[i], b.h[j], acc[i0 + i][j0 + j], 0, 0, 0);
+                }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        auto mainloop = [&](auto ISC) {
+            auto commit_item = [&](auto KC, int chunk) {
+                constexpr int K = decltype(KC)::value;
+                const int off = item_lds(K);
+                if constexpr (PKX) {
+                    const float4 pv = pq[K];
+                    *reinterpret_cast<float2 *>(ph + off) = make_float2(pv.x, pv.y);
+                    *reinterpret_cast<float2 *>(pl + off) = make_float2(pv.z, pv.w);
+                } else {
+                    uint2 hi, lo;
+                    if constexpr (decltype(ISC)::value)
+                        split4v<SPLIT>(pq[K], *reinterpret_cast<const float4 *>(sct + c4 * 4 + (chunk - c_begin) * CV_CK), hi, lo, satm);
+                    else split4s<SPLIT>(pq[K], xscale, hi, lo, satm);
+                    *reinterpret_cast<uint2 *>(ph + off) = hi;
+                    *reinterpret_cast<uint2 *>(pl + off) = lo;
+                }
+            };
+            issue_wdma5(c_begin, 0, 0);
+            issue_patch(c_begin, S0{});
+            block_exponent();
+            static_for<0, PSET>([&](auto KC) { commit_item(KC, c_begin); });
+            cv_wait_vm<0>();
+            cv_lds_barrier();
+            int ks0 = 0;
+            for (int chunk = c_begin; chunk < c_end; chunk++, ks0 += NT) {
+                const int cnext = chunk + 1 < c_end ? chunk + 1 : chunk;
+                auto kstep = [&](auto TC) {
+                    constexpr int tap = decltype(TC)::value;
+                    const int ks = ks0 + tap;
+                    if (tap > 0 || ks0 > 0) {       // (compile-time for tap > 0; the block's very first k-step follows the prologue's barrier)
+                        cv_wait_vm<1>();            // tile pair ks (issued one k-step ago); behind it: that k-step's patch item
+                        cv_lds_barrier();           // all pieces landed; slot (ks + 1) & 1 (read in k-step ks - 1) is free
+                    }
+                    issue_wdma5(tap + 1 < NT ? chunk : cnext, (tap + 1) % NT, (ks + 1) & 1);
+                    asm volatile("" ::: "memory");
+                    if constexpr (tap == 0) cur_ok[0] = cnext * CV_CK + c4 * 4 < g.Ci ? p_ok : 0u;
+                    issue_item(TC, cnext);
+                    const unsigned char *wb = wbuf + (ks & 1) * (2 * CV_WSTEP_BYTES);
+                    const Frag2 a0 = read_a(wb, 0), b0 = read_b(tap, 0);
+                    const Frag2 b1 = read_b(tap, 1);
+                    quad(a0, b0, I0{}, I0{});
+                    const Frag2 a1 = read_a(wb, 1);
+                    quad(a0, b1, I0{}, I1{});
+                    quad(a1, b1, I1{}, I1{});
+                    quad(a1, b0, I1{}, I0{});
+                    if constexpr (tap == NT - 1) {     // chunk boundary: every wave is done with the patch
+                        cv_lds_barrier();
+                        static_for<0, PSET>([&](auto KC) { commit_item(KC, cnext); });
+                    }
+                };
+                static_for<0, NT>(kstep);
+            }
+            cv_wait_vm<0>();
         };
         if (!PKX && iscale) mainloop(std::true_type{});
         else mainloop(std::false_type{});
@@ -983,7 +1126,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 float *wrow = ws + (((int64_t)split * g.N + n) * g.GH * g.GW + (int64_t)gy * g.GW + gx) * g.Co;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const int co = cot * CV_BM + wm * 64 + i * 16 + kg * 4;
+                    const int co = cot * (COT * CV_BM) + wm * 64 + i * 16 + kg * 4;
                     if (co >= g.Co) continue;
                     // (partial sums leave the block without its operand exponents: blocks of one output tile may differ)
                     if (covec && t.tickets) {      // in-launch fix-up: WRITE-THROUGH (sc1) stores, so that no block pays a release fence
@@ -1008,7 +1151,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                 float4 sc[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const int co = cot * CV_BM + wm * 64 + i * 16 + kg * 4;
+                    const int co = cot * (COT * CV_BM) + wm * 64 + i * 16 + kg * 4;
                     sc[i] = make_float4(oalpha, oalpha, oalpha, oalpha);
                     if (OS) {
                         const float4 o = *reinterpret_cast<const float4 *>(oscale + (int64_t)n * g.Co + (co < g.Co ? co : 0));
@@ -1021,7 +1164,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
                                          (int64_t)(gy * g.os + g.oy0) * g.OW + gx * g.os + g.ox0];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const int co = cot * CV_BM + wm * 64 + i * 16 + kg * 4;
+                    const int co = cot * (COT * CV_BM) + wm * 64 + i * 16 + kg * 4;
                     if (co < g.Co) {
                         float4 v = make_float4(acc[i][j][0] * sc[i].x, acc[i][j][1] * sc[i].y, acc[i][j][2] * sc[i].z,
                                                acc[i][j][3] * sc[i].w);
@@ -1054,7 +1197,7 @@ __device__ __forceinline__ void igemm_body(const float *__restrict__ x, const un
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int co = cot * CV_BM + wm * 64 + i * 16 + kg * 4;
+                const int co = cot * (COT * CV_BM) + wm * 64 + i * 16 + kg * 4;
                 if (co >= g.Co) continue;
                 f32x4 v = acc[i][j] * oalpha;
                 if (OS) {
@@ -1300,7 +1443,7 @@ extern "C" int rick_conv_igemm_split_f32(const void *x_split, const float *x_hdr
 extern "C" int rick_conv_igemm_split_supported(const rick_conv_geom *g) {
     if (check_geom(g) || (g->Ci & 31) || g->split != 2) return 0;
     ConvTiling t;
-    if (igemm_w8_plan(g, &t, true)) return 1;
+    if (igemm_w8_plan(g, &t, true) || igemm_s2w8_plan(g, &t)) return 1;
     if (make_tiling(g, igemm_tile_positions(g), &t)) return 0;
     igemm_plan_split(&t, g->ntaps);
     const size_t lds = igemm_lds_bytes(t, false);
@@ -1334,6 +1477,14 @@ static int igemm_run(const float *x, const void *packed_w, float *out, const flo
         const unsigned char *wp8 = (const unsigned char *)packed_w;
         if (pkx) launch_igemm_k<2, true, false, 4, 9, 4, true, 8>((unsigned)nwg8, lds8, st, x, wp8, out, iscale, oscale, nullptr, g, t, epi);
         else launch_igemm_k<2, true, false, 4, 9, 4, false, 8>((unsigned)nwg8, lds8, st, x, wp8, out, iscale, oscale, nullptr, g, t, epi);
+        RICK_LAUNCH_STATUS();
+    }
+    if (igemm_s2w8_plan(g, &t)) {             // eight-wave 256 co x 128 position blocks, stride 2 (igemm_body, WDMA = 5)
+        const int64_t nwg8 = (int64_t)t.ntx * t.nty * t.ntn * t.ncot;
+        const size_t lds8 = igemm_s2w8_lds_bytes(t);
+        const unsigned char *wp8 = (const unsigned char *)packed_w;
+        if (pkx) launch_igemm_k<2, true, false, 4, 9, 5, true, 8>((unsigned)nwg8, lds8, st, x, wp8, out, iscale, oscale, nullptr, g, t, epi);
+        else launch_igemm_k<2, true, false, 4, 9, 5, false, 8>((unsigned)nwg8, lds8, st, x, wp8, out, iscale, oscale, nullptr, g, t, epi);
         RICK_LAUNCH_STATUS();
     }
     if (make_tiling(g, igemm_tile_positions(g), &t)) return RICK_EINVAL;

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void split_unpack_kernel(const unsigned char *
 }
 
 // ---- kernel-form switches (include/rick_hip.h: rick_conv_tuning) -------------------------------------------------------------------
-static int g_tune[4] = {0, 192, 0, 0};
+static int g_tune[5] = {0, 192, 0, 0, 2};
 extern "C" int rick_conv_tuning(int key, int value) {
     if (key < 0 || key >= (int)(sizeof(g_tune) / sizeof(g_tune[0]))) return -1;
     const int prev = g_tune[key];

@@ -40,9 +40,9 @@ def test_ops_refuse_cpu_tensors():
 
 def test_conv_tuning_is_a_host_side_switch():
     """rick_conv_tuning (include/rick_hip.h): returns the previous value, -1 for an unknown key; the shipped defaults select the
-    forms that measured fastest (eight-wave igemm off, in-launch split-K fix-up off, 8 x 8 FIR tile) — no GPU involved."""
+    forms that measured fastest (eight-wave stride-1 igemm off, eight-wave stride-2 igemm on, in-launch split-K fix-up off, 8 x 8 FIR tile) — no GPU involved."""
     from rick_amd._lib import lib
-    defaults = {0: 0, 1: 192, 2: 0, 3: 0}
+    defaults = {0: 0, 1: 192, 2: 0, 3: 0, 4: 2}
     for key, dflt in defaults.items():
         prev = lib.rick_conv_tuning(key, 7)
         assert prev == dflt, (key, prev)

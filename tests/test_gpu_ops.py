@@ -181,7 +181,7 @@ def test_conv2d_vs_fp64(case):
 def _conv_tuning(**kv):
     """rick_conv_tuning (include/rick_hip.h) for the duration of a test: which kernel FORM a launch takes, never its values."""
     from rick_amd._lib import lib
-    keys = {'igemm_w8': 0, 'igemm_w8_minblk': 1, 'splitk_fused': 2, 'ufd_tile16': 3}
+    keys = {'igemm_w8': 0, 'igemm_w8_minblk': 1, 'splitk_fused': 2, 'ufd_tile16': 3, 'igemm_s2w8': 4}
     prev = {k: lib.rick_conv_tuning(keys[k], v) for k, v in kv.items()}
     try:
         yield
@@ -241,6 +241,51 @@ def test_igemm_eight_wave_form_vs_fp64(case):
     assert rel_err(y, ref) < 2e-6, 'modulated forward'
     assert rel_err(y0, ref0) < 2e-6, 'plain forward'
     assert rel_err(gx, refT) < 2e-6, 'data gradient'
+
+
+@pytest.mark.parametrize('case', [('co256', 2, 128, 256, 33), ('ragged_tiles', 1, 160, 256, 41), ('three_images', 3, 256, 512, 17)],
+                         ids=lambda c: c[0])
+def test_igemm_stride2_eight_wave_form_vs_fp64(case):
+    """The eight-wave STRIDE-2 igemm block (conv.hip, igemm_body WDMA = 5: 256 co x 128 positions, two weight tiles per k-step
+    by LDS-DMA, the 33 x 17 patch staged once for 256 channels) — the discriminator's downsampling 3x3 convolutions
+    (model_probe_tune.py:609-629) — forced onto small geometries, with demodulation-style output scales, against torch CPU fp64 at
+    the four-wave form's tolerance: position tiles hanging over the image, channel counts that are no multiple of 32."""
+    from rick_amd.op import conv as cv
+    tag, n, ci, co, r = case
+    x = synth_tensor(f's2w8/{tag}/x', (n, ci, r, r)) * torch.exp2(torch.randint(-6, 3, (n, ci, 1, 1), generator=torch.Generator().manual_seed(2)).float())
+    wt = synth_tensor(f's2w8/{tag}/w', (co, ci, 3, 3))
+    si, so = synth_tensor(f's2w8/{tag}/si', (n, ci)).abs() + 0.5, synth_tensor(f's2w8/{tag}/so', (n, co)).abs() + 0.5
+    ref = F.conv2d(x.double() * si.double()[:, :, None, None], wt.double(), stride=2) * so.double()[:, :, None, None]
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    wp = cv._pack(wt.to(DEV), 1.0)
+    with _conv_tuning(igemm_s2w8=2, igemm_w8_minblk=1):
+        y = cv._conv_launch(xd, wp, co, 3, 3, 2, 0, iscale=si.to(DEV), oscale=so.to(DEV))
+        y0 = cv._conv_launch(xd, wp, co, 3, 3, 2, 0)
+        torch.cuda.synchronize()
+    assert rel_err(y, ref) < 2e-6, 'scaled forward'
+    assert rel_err(y0, F.conv2d(x.double(), wt.double(), stride=2)) < 2e-6, 'plain forward'
+
+
+def test_igemm_stride2_eight_wave_form_bit_equal_on_split_images():
+    """Same MFMA order per accumulator as the four-wave 128 x 64 blocks: bit-equal on split images (geometries that fill the chip
+    with four-wave blocks, so neither form splits K), the fused bias + LeakyReLU tail included; fp32 operands differ by the
+    per-block exponents only.  (The 256-px model tests — goldens, loop body, teacher-forced steps — run the discriminator's
+    128 -> 256 and 256 -> 512 downsampling convolutions through this form.)"""
+    from rick_amd.op import conv as cv, split as sp
+    n, ci, co, r = 8, 128, 256, 129
+    x = torch.randn(n, ci, r, r, device=DEV, generator=torch.Generator(DEV).manual_seed(7)).contiguous(memory_format=torch.channels_last)
+    wt = synth_tensor('s2w8/eq/w', (co, ci, 3, 3)).to(DEV)
+    bias = synth_tensor('s2w8/eq/b', (co,)).to(DEV)
+    wp = cv._pack(wt, 1.0)
+    xs = sp.split_pack(x)
+    epi = cv._epilogue(bias, None, None, 0.2, 2 ** 0.5)
+    outs = {}
+    for mode in (0, 2):
+        with _conv_tuning(igemm_s2w8=mode):
+            outs[mode] = (cv._conv_launch(None, wp, co, 3, 3, 2, 0, epi=epi, x_split=xs), cv._conv_launch(x, wp, co, 3, 3, 2, 0))
+            torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[2][0]), 'forward on a split image'
+    assert rel_err(outs[2][1], outs[0][1]) < 2e-6, 'fp32 operands: per-block exponents only'
 
 
 def test_igemm_eight_wave_form_bit_equal_on_split_images():
